@@ -1,0 +1,111 @@
+/* knerf.h -- C ABI of libknerf_hip.so: the MI355X (gfx950) NeRF train/render hot path.
+ *
+ * The reference (naufalso/keras_nerf) has no FFI layer: its hot path is the Python class surface
+ * keras_nerf/model/nerf/{nerf,utils,mlp}.py on stock TensorFlow ops.  Each entry point below names the reference
+ * code it replaces; the modules under keras_nerf_amd/model/nerf bind them with ctypes behind the reference's class names.
+ *
+ * Conventions: every function returns 0 on success or a negative knerf_status; knerf_last_error() gives the text.
+ * All array arguments are DEVICE pointers to contiguous row-major fp32 unless marked host.  `stream` is a
+ * hipStream_t (may be NULL).  Nothing is retained past a call; the context owns weights, gradients, Adam slots
+ * and workspaces.  One context per GPU, not thread safe.
+ */
+#ifndef KNERF_H
+#define KNERF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct knerf_ctx knerf_ctx;
+
+typedef enum knerf_status {
+    KNERF_OK = 0,
+    KNERF_ERR_INVALID = -1,       /* bad argument / unsupported architecture                      */
+    KNERF_ERR_HIP = -2,           /* a HIP runtime call failed                                    */
+    KNERF_ERR_NONFINITE = -3,     /* a gradient is not finite (reference: assert_all_finite)      */
+    KNERF_ERR_NODEVICE = -4       /* no gfx950 device visible                                     */
+} knerf_status;
+
+/* NeRF(...) constructor arguments (reference nerf.py:11-14) + compile() arguments (nerf.py:78) + Adam defaults
+ * of tf.keras.optimizers.get('adam') (nerf.py:163-165). */
+typedef struct knerf_config {
+    int32_t n_coarse, n_fine;          /* 64, 128 */
+    int32_t pos_emb_xyz, pos_emb_dir;  /* 10, 4   */
+    int32_t n_layers, dense_units, skip_layer; /* 8, 256, 4 : the only MLP shape the fused kernels accept */
+    int32_t white_background;          /* compile(white_background=...) */
+    int32_t oob_clamp;                 /* 0: out-of-range mid-point gather yields 0 (tf.gather on GPU); 1: clamp */
+    float lr, beta1, beta2, epsilon;   /* 1e-3, 0.9, 0.999, 1e-7 */
+} knerf_config;
+
+enum { KNERF_COARSE = 0, KNERF_FINE = 1 };
+
+/* number of trainable scalars per MLP (595,844 for the default shape; reference mlp.py:11-27) */
+size_t knerf_param_count(void);
+
+int knerf_create(const knerf_config* cfg, knerf_ctx** out);
+int knerf_destroy(knerf_ctx* ctx);
+const char* knerf_last_error(const knerf_ctx* ctx);   /* ctx may be NULL: error of the last failed create */
+
+/* Weights of one MLP as ONE flat fp32 vector in Keras trainable_variables order
+ * (layer_0/kernel[in,out], layer_0/bias, ..., sigma, features, rgb_features, rgb); HOST pointers.
+ * Replaces NeRFMLP weight creation / load_weights / save_weights (nerf.py:116-136, 45-64). */
+int knerf_set_weights(knerf_ctx* ctx, int net, const float* host_flat, size_t n);
+int knerf_get_weights(knerf_ctx* ctx, int net, float* host_flat, size_t n);
+/* device views for collectives: weights of one net; the gradient accumulators of BOTH nets as one buffer
+ * [coarse | fine] (2*param_count floats) so that a single all-reduce covers the step (train.py:75). */
+int knerf_weights_device(knerf_ctx* ctx, int net, float** dev, size_t* n);
+int knerf_grads_device(knerf_ctx* ctx, float** dev, size_t* n);
+/* re-derive the bf16 MFMA weight streams from the fp32 master weights (after an external write to them) */
+int knerf_refresh_weights(knerf_ctx* ctx, void* stream);
+
+/* NeRF._predict_and_render_chunk (nerf.py:175-216) for one net on given t-values:
+ * encode -> MLP -> composite.  o,d [R,3]; t [R,S]; outputs image [R,3], depth [R], weights [R,S]. */
+int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, const float* d, const float* t,
+                        int n_rays, int n_samples, float* image, float* depth, float* weights);
+
+/* the fine branch's sampling (nerf.py:182-191, utils.py:60-97): t_out [R, n_coarse+n_fine] sorted.
+ * u [R,n_fine] in [0,1) or NULL for the built-in Philox stream keyed by (seed, stream_id, ray_offset + ray). */
+int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const float* w_coarse, const float* u,
+                      uint64_t seed, uint64_t stream_id, uint64_t ray_offset, int n_rays, float* t_out);
+
+/* NeRF.predict_and_render_chunk (nerf.py:218-227): coarse pass, sampling, fine pass. Any output may be NULL
+ * except the two images.  t_fine [R, n_coarse+n_fine] receives the merged t-values. */
+int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u,
+                       uint64_t seed, uint64_t ray_offset, int n_rays,
+                       float* c_image, float* c_depth, float* c_weights,
+                       float* f_image, float* f_depth, float* f_weights, float* t_fine);
+
+/* One iteration of train_step's chunk loop (nerf.py:351-421): coarse forward+backward, fine forward+backward,
+ * gradients accumulated as acc += g * inv_chunks, chunk losses accumulated into loss[0] (coarse) / loss[1] (fine)
+ * (device, 2 floats, caller zeroes them per step).  target [R,3]. */
+int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t,
+                      const float* target, const float* u, uint64_t seed, uint64_t ray_offset, int n_rays,
+                      float inv_chunks, float* loss, float* c_image, float* f_image);
+
+/* coarse_optimizer.apply_gradients + fine_optimizer.apply_gradients + accumulator reset (nerf.py:455-471).
+ * Call after the optional all-reduce of knerf_grads_device().  Returns KNERF_ERR_NONFINITE (weights untouched)
+ * when a gradient is not finite (nerf.py:381-382).  Synchronises the stream. */
+int knerf_apply_adam(knerf_ctx* ctx, void* stream);
+int knerf_zero_grads(knerf_ctx* ctx, void* stream);
+int knerf_step_count(const knerf_ctx* ctx);
+int knerf_set_step_count(knerf_ctx* ctx, int step);
+
+/* RaysGenerator.__call__ (keras_nerf/data/rays.py:69-130) on device: c2w [B,4,4], noise [B,H,W,N] in [0,1) or
+ * NULL for Philox; writes o,d [B,H,W,3] and t [B,H,W,N]. */
+int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const float* noise, uint64_t seed,
+                        uint64_t stream_id, int batch, int height, int width, int n_samples, float focal,
+                        float near_plane, float far_plane, float* o, float* d, float* t);
+
+/* ---- introspection used by the CPU-side layout tests (no device work) ---- */
+/* kind 0: forward A-fragment table, 1: forward bias table, 2: dgrad A-fragment table, 3: wgrad destination table.
+ * Entries are indices into the flat parameter vector or -1.  Pass out=NULL to query the length. */
+int knerf_debug_table(int kind, int32_t* out, size_t* n);
+/* device buffers of the last knerf_train_chunk for kernel-level tests: 0 act, 1 mask, 2 dz, 3 raw, 4 draw */
+int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNERF_H */

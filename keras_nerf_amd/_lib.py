@@ -1,0 +1,80 @@
+"""ctypes binding of libknerf_hip.so (include/knerf.h).  There is no CPU fallback: a missing library or a missing
+gfx950 device is an error, never a silent detour."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknerf_hip.so")
+
+KNERF_OK, KNERF_ERR_INVALID, KNERF_ERR_HIP, KNERF_ERR_NONFINITE, KNERF_ERR_NODEVICE = 0, -1, -2, -3, -4
+COARSE, FINE = 0, 1
+
+
+class KnerfConfig(C.Structure):
+    _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pos_emb_xyz", C.c_int32), ("pos_emb_dir", C.c_int32),
+                ("n_layers", C.c_int32), ("dense_units", C.c_int32), ("skip_layer", C.c_int32),
+                ("white_background", C.c_int32), ("oob_clamp", C.c_int32),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float)]
+
+
+_P = C.c_void_p
+_F = C.c_void_p  # device float* passed as integers (tensor.data_ptr())
+# name -> (restype, argtypes): exactly the declarations of include/knerf.h
+SIGNATURES = {
+    "knerf_param_count": (C.c_size_t, []),
+    "knerf_create": (C.c_int, [C.POINTER(KnerfConfig), C.POINTER(_P)]),
+    "knerf_destroy": (C.c_int, [_P]),
+    "knerf_last_error": (C.c_char_p, [_P]),
+    "knerf_set_weights": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "knerf_get_weights": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "knerf_weights_device": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "knerf_grads_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "knerf_refresh_weights": (C.c_int, [_P, _P]),
+    "knerf_forward_chunk": (C.c_int, [_P, _P, C.c_int, _F, _F, _F, C.c_int, C.c_int, _F, _F, _F]),
+    "knerf_sample_fine": (C.c_int, [_P, _P, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _F]),
+    "knerf_render_chunk": (C.c_int, [_P, _P, _F, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_int, _F, _F, _F, _F, _F, _F, _F]),
+    "knerf_train_chunk": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_float, _F, _F, _F]),
+    "knerf_apply_adam": (C.c_int, [_P, _P]),
+    "knerf_zero_grads": (C.c_int, [_P, _P]),
+    "knerf_step_count": (C.c_int, [_P]),
+    "knerf_set_step_count": (C.c_int, [_P, C.c_int]),
+    "knerf_generate_rays": (C.c_int, [_P, _P, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, C.c_float, _F, _F, _F]),
+    "knerf_debug_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
+    "knerf_debug_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+class KnerfError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KnerfError(f"{LIB_PATH} is missing: run `python keras_nerf_amd/build.py` (hipcc, gfx950). "
+                             "keras_nerf_amd has no CPU path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def debug_table(kind: int):
+    import numpy as np
+    lib = load()
+    n = C.c_size_t(0)
+    if lib.knerf_debug_table(kind, None, C.byref(n)) != 0:
+        raise KnerfError("knerf_debug_table failed")
+    out = np.empty(n.value, np.int32)
+    if lib.knerf_debug_table(kind, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)) != 0:
+        raise KnerfError("knerf_debug_table failed")
+    return out

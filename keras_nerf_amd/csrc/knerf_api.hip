@@ -1,0 +1,423 @@
+// knerf_api.hip -- extern "C" entry points of libknerf_hip.so (see include/knerf.h for the contract and the reference
+// lines each one replaces).  Host-side only: owns device memory, sequences the kernels on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/knerf.h"
+#include "chain.h"
+#include "kernels.h"
+#include "layout.h"
+
+using namespace knerf;
+
+namespace {
+
+std::string g_create_error;
+
+struct Net {
+    float *w = nullptr, *m = nullptr, *v = nullptr, *g = nullptr;   // g points into ctx->grads
+    char *fwd_stream = nullptr, *bwd_stream = nullptr;
+    float* bias = nullptr;
+};
+
+struct Tables {
+    PackTables host;
+    std::vector<int32_t> wgrad;        // concatenated per-job destination tables
+    std::vector<int32_t> wgrad_off;    // kWgradJobs+1 offsets
+    int *d_fwd = nullptr, *d_bias = nullptr, *d_bwd = nullptr, *d_wgrad = nullptr;
+};
+
+}  // namespace
+
+struct knerf_ctx {
+    knerf_config cfg;
+    std::string err;
+    Net net[2];
+    float* grads = nullptr;
+    Tables tab;
+    int step = 0;
+    int* d_flag = nullptr;
+    // workspaces (grow-only)
+    int ws_rays = 0; bool ws_train = false;
+    float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
+    char *act = nullptr, *mask = nullptr, *dz = nullptr;
+    size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
+};
+
+namespace {
+
+void build_wgrad_tables(Tables& t) {
+    auto tt = tensor_table();
+    t.wgrad.clear(); t.wgrad_off.clear();
+    for (int jb = 0; jb < kWgradJobs; ++jb) {
+        t.wgrad_off.push_back((int32_t)t.wgrad.size());
+        WgradJob J = wgrad_job(jb);
+        if (J.layer < 0) continue;
+        const int rows = J.n_it * 32 + 1, cols = J.n_ot * 32;     // last row = bias
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) t.wgrad.push_back(wgrad_dst(tt, jb, r == rows - 1 ? -2 : r, c));
+    }
+    t.wgrad_off.push_back((int32_t)t.wgrad.size());
+}
+
+const Tables& host_tables() {
+    static Tables t;
+    static bool done = false;
+    if (!done) { build_fwd(t.host); build_bwd(t.host); build_wgrad_tables(t); done = true; }
+    return t;
+}
+
+int fail(knerf_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, KNERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+constexpr size_t kFwdStreamBytes = (size_t)(kFwdBlocks + kTailPages * kPageBlocks) * 1024;
+constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
+
+int repack(knerf_ctx* ctx, int n, hipStream_t s) {
+    Net& N = ctx->net[n];
+    HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)kFwdBlocks * 512, s));
+    HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)kBwdBlocks * 512, s));
+    HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)kFwdBiasTiles * 32, s));
+    return KNERF_OK;
+}
+
+size_t tiles_for(long long n_samples) {
+    size_t t = (size_t)((n_samples + kTile - 1) / kTile);
+    return (t + kWaves - 1) / kWaves * kWaves;   // whole workgroups
+}
+
+template <class T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
+    if (n_rays <= ctx->ws_rays && (!train || ctx->ws_train)) return KNERF_OK;
+    const int R = n_rays > ctx->ws_rays ? n_rays : ctx->ws_rays;
+    const int Na = ctx->cfg.n_coarse + ctx->cfg.n_fine;
+    train = train || ctx->ws_train;
+    free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
+    free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
+    ctx->ws_rays = 0;
+    const size_t ns = (size_t)R * Na;
+    ctx->raw_bytes = ns * 4 * sizeof(float);
+    HIPCHK(hipMalloc(&ctx->raw, ctx->raw_bytes));
+    HIPCHK(hipMalloc(&ctx->w_c, (size_t)R * ctx->cfg.n_coarse * sizeof(float)));
+    HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
+    HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
+    if (train) {
+        const size_t tiles = tiles_for((long long)ns);
+        ctx->act_bytes = tiles * kActBlocks * 1024; ctx->mask_bytes = tiles * kMaskBlocks * 1024; ctx->dz_bytes = tiles * kDzBlocks * 1024;
+        HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
+        HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
+        HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
+        HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
+    }
+    ctx->ws_rays = R; ctx->ws_train = train;
+    return KNERF_OK;
+}
+
+int check_net(knerf_ctx* ctx, int net) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (net != KNERF_COARSE && net != KNERF_FINE) return fail(ctx, KNERF_ERR_INVALID, "net must be 0 (coarse) or 1 (fine)");
+    return KNERF_OK;
+}
+
+// forward (+ optional training half) of one net on given t-values; leaves raw/draw/act/dz in the workspace
+int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float* d, const float* t, int R, int S,
+             float* image, float* depth, float* weights, const float* target, float inv_chunks, float* loss) {
+    const bool train = target != nullptr;
+    FwdArgs fa{};
+    fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
+    fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw; fa.act = ctx->act; fa.mask = ctx->mask;
+    fa.n_samples = (long long)R * S; fa.S = S;
+    HIPCHK(launch_mlp_fwd(fa, train, s));
+    CompositeArgs ca{};
+    ca.raw = ctx->raw; ca.t = t; ca.target = target; ca.image = image; ca.depth = depth; ca.weights = weights;
+    ca.draw = train ? ctx->draw : nullptr; ca.loss = loss; ca.R = R; ca.S = S; ca.white = ctx->cfg.white_background;
+    ca.grad_scale = 2.0f / (3.0f * (float)R) * inv_chunks;
+    ca.loss_scale = inv_chunks / (3.0f * (float)R);
+    HIPCHK(launch_composite(ca, s));
+    if (train) {
+        BwdArgs ba{};
+        ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
+        ba.n_samples = fa.n_samples;
+        HIPCHK(launch_mlp_bwd(ba, s));
+        WgradArgs wa{};
+        wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
+        wa.n_tiles = (long long)tiles_for(fa.n_samples);
+        HIPCHK(launch_wgrad(wa, s));
+    }
+    return KNERF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t knerf_param_count(void) { return (size_t)kParamCount; }
+
+const char* knerf_last_error(const knerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int knerf_debug_table(int kind, int32_t* out, size_t* n) {
+    if (!n) return KNERF_ERR_INVALID;
+    const Tables& t = host_tables();
+    const std::vector<int32_t>* v = nullptr;
+    std::vector<int32_t> tmp;
+    switch (kind) {
+        case 0: v = &t.host.fwd; break;
+        case 1: v = &t.host.fwd_bias; break;
+        case 2: v = &t.host.bwd; break;
+        case 3: v = &t.wgrad; break;
+        case 4: v = &t.wgrad_off; break;
+        default: return KNERF_ERR_INVALID;
+    }
+    if (out) {
+        if (*n < v->size()) return KNERF_ERR_INVALID;
+        memcpy(out, v->data(), v->size() * sizeof(int32_t));
+    }
+    *n = v->size();
+    return KNERF_OK;
+}
+
+int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
+    knerf_ctx* ctx = nullptr;
+    if (!cfg || !out) return fail(nullptr, KNERF_ERR_INVALID, "null argument");
+    if (cfg->n_layers != 8 || cfg->dense_units != 256 || cfg->skip_layer != 4 || cfg->pos_emb_xyz != kLx || cfg->pos_emb_dir != kLd)
+        return fail(nullptr, KNERF_ERR_INVALID,
+                    "the fused gfx950 kernels implement NeRFMLP(n_layers=8, dense_units=256, skip_layer=4) with pos_emb_xyz=10, pos_emb_dir=4 only");
+    if (cfg->n_coarse < 2 || cfg->n_coarse > 256 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 512)
+        return fail(nullptr, KNERF_ERR_INVALID, "need 2 <= n_coarse <= 256 and n_coarse + n_fine <= 512");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KNERF_ERR_NODEVICE, "no HIP device visible");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(nullptr, KNERF_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, KNERF_ERR_NODEVICE, std::string("libknerf_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+    ctx = new knerf_ctx();
+    ctx->cfg = *cfg;
+    const Tables& ht = host_tables();
+    ctx->tab.host = ht.host; ctx->tab.wgrad = ht.wgrad; ctx->tab.wgrad_off = ht.wgrad_off;
+    auto up = [&](int*& dptr, const std::vector<int32_t>& v) -> hipError_t {
+        hipError_t e = hipMalloc(&dptr, v.size() * sizeof(int32_t));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(dptr, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    };
+#define CREATECHK(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+            knerf_destroy(ctx);                                                                                  \
+            return fail(nullptr, KNERF_ERR_HIP, m_);                                                             \
+        }                                                                                                        \
+    } while (0)
+    CREATECHK(up(ctx->tab.d_fwd, ctx->tab.host.fwd));
+    CREATECHK(up(ctx->tab.d_bias, ctx->tab.host.fwd_bias));
+    CREATECHK(up(ctx->tab.d_bwd, ctx->tab.host.bwd));
+    CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
+    CREATECHK(hipMalloc(&ctx->grads, 2 * (size_t)kParamCount * sizeof(float)));
+    CREATECHK(hipMemset(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float)));
+    CREATECHK(hipMalloc(&ctx->d_flag, sizeof(int)));
+    CREATECHK(hipMemset(ctx->d_flag, 0, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
+    for (int n = 0; n < 2; ++n) {
+        Net& N = ctx->net[n];
+        CREATECHK(hipMalloc(&N.w, kParamCount * sizeof(float)));
+        CREATECHK(hipMalloc(&N.m, kParamCount * sizeof(float)));
+        CREATECHK(hipMalloc(&N.v, kParamCount * sizeof(float)));
+        CREATECHK(hipMemset(N.w, 0, kParamCount * sizeof(float)));
+        CREATECHK(hipMemset(N.m, 0, kParamCount * sizeof(float)));
+        CREATECHK(hipMemset(N.v, 0, kParamCount * sizeof(float)));
+        N.g = ctx->grads + (size_t)n * kParamCount;
+        CREATECHK(hipMalloc(&N.fwd_stream, kFwdStreamBytes));
+        CREATECHK(hipMalloc(&N.bwd_stream, kBwdStreamBytes));
+        CREATECHK(hipMemset(N.fwd_stream, 0, kFwdStreamBytes));
+        CREATECHK(hipMemset(N.bwd_stream, 0, kBwdStreamBytes));
+        CREATECHK(hipMalloc(&N.bias, kFwdBiasTiles * 32 * sizeof(float)));
+        CREATECHK(hipMemset(N.bias, 0, kFwdBiasTiles * 32 * sizeof(float)));
+    }
+#undef CREATECHK
+    *out = ctx;
+    return KNERF_OK;
+}
+
+int knerf_destroy(knerf_ctx* ctx) {
+    if (!ctx) return KNERF_OK;
+    for (int n = 0; n < 2; ++n) {
+        Net& N = ctx->net[n];
+        free_dev(N.w); free_dev(N.m); free_dev(N.v); free_dev(N.fwd_stream); free_dev(N.bwd_stream); free_dev(N.bias);
+    }
+    free_dev(ctx->grads); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp);
+    free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad);
+    free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
+    free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
+    delete ctx;
+    return KNERF_OK;
+}
+
+int knerf_set_weights(knerf_ctx* ctx, int net, const float* host_flat, size_t n) {
+    if (int r = check_net(ctx, net)) return r;
+    if (!host_flat || n != (size_t)kParamCount) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(kParamCount) + " floats");
+    HIPCHK(hipMemcpy(ctx->net[net].w, host_flat, n * sizeof(float), hipMemcpyHostToDevice));
+    if (int r = repack(ctx, net, nullptr)) return r;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return KNERF_OK;
+}
+
+int knerf_get_weights(knerf_ctx* ctx, int net, float* host_flat, size_t n) {
+    if (int r = check_net(ctx, net)) return r;
+    if (!host_flat || n != (size_t)kParamCount) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(kParamCount) + " floats");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_flat, ctx->net[net].w, n * sizeof(float), hipMemcpyDeviceToHost));
+    return KNERF_OK;
+}
+
+int knerf_weights_device(knerf_ctx* ctx, int net, float** dev, size_t* n) {
+    if (int r = check_net(ctx, net)) return r;
+    if (dev) *dev = ctx->net[net].w;
+    if (n) *n = (size_t)kParamCount;
+    return KNERF_OK;
+}
+
+int knerf_grads_device(knerf_ctx* ctx, float** dev, size_t* n) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (dev) *dev = ctx->grads;
+    if (n) *n = 2 * (size_t)kParamCount;
+    return KNERF_OK;
+}
+
+int knerf_refresh_weights(knerf_ctx* ctx, void* stream) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    for (int n = 0; n < 2; ++n) if (int r = repack(ctx, n, (hipStream_t)stream)) return r;
+    return KNERF_OK;
+}
+
+int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, const float* d, const float* t,
+                        int n_rays, int n_samples, float* image, float* depth, float* weights) {
+    if (int r = check_net(ctx, net)) return r;
+    if (!o || !d || !t || !image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: null/empty argument");
+    if (n_samples < 1 || n_samples > ctx->cfg.n_coarse + ctx->cfg.n_fine) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: n_samples out of range");
+    if (int r = ensure_ws(ctx, n_rays, false)) return r;
+    return run_pass(ctx, (hipStream_t)stream, net, o, d, t, n_rays, n_samples, image, depth, weights, nullptr, 1.f, nullptr);
+}
+
+int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const float* w_coarse, const float* u,
+                      uint64_t seed, uint64_t stream_id, uint64_t ray_offset, int n_rays, float* t_out) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (!t_coarse || !w_coarse || !t_out || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "sample_fine: null/empty argument");
+    SampleArgs sa{};
+    sa.t_coarse = t_coarse; sa.w_coarse = w_coarse; sa.u = u; sa.t_out = t_out; sa.R = n_rays;
+    sa.Nc = ctx->cfg.n_coarse; sa.Nf = ctx->cfg.n_fine; sa.oob_clamp = ctx->cfg.oob_clamp;
+    sa.seed = seed; sa.stream_id = stream_id; sa.ray_offset = ray_offset;
+    HIPCHK(launch_sample_fine(sa, (hipStream_t)stream));
+    return KNERF_OK;
+}
+
+int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u,
+                       uint64_t seed, uint64_t ray_offset, int n_rays, float* c_image, float* c_depth, float* c_weights,
+                       float* f_image, float* f_depth, float* f_weights, float* t_fine) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (!o || !d || !t || !c_image || !f_image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "render_chunk: null/empty argument");
+    if (int r = ensure_ws(ctx, n_rays, false)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
+    float* wc = c_weights ? c_weights : ctx->w_c;
+    float* tf = t_fine ? t_fine : ctx->t_f;
+    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, c_image, c_depth, wc, nullptr, 1.f, nullptr)) return r;
+    if (int r = knerf_sample_fine(ctx, stream, t, wc, u, seed, 0, ray_offset, n_rays, tf)) return r;
+    return run_pass(ctx, s, KNERF_FINE, o, d, tf, n_rays, Na, f_image, f_depth, f_weights, nullptr, 1.f, nullptr);
+}
+
+int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
+                      const float* u, uint64_t seed, uint64_t ray_offset, int n_rays, float inv_chunks, float* loss,
+                      float* c_image, float* f_image) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (!o || !d || !t || !target || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "train_chunk: null/empty argument");
+    if (int r = ensure_ws(ctx, n_rays, true)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
+    float* ci = c_image ? c_image : ctx->img_tmp;
+    float* fi = f_image ? f_image : ctx->img_tmp + (size_t)n_rays * 4;
+    float* ls = loss ? loss : ctx->loss_tmp;
+    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, ci, nullptr, ctx->w_c, target, inv_chunks, ls)) return r;
+    if (int r = knerf_sample_fine(ctx, stream, t, ctx->w_c, u, seed, 0, ray_offset, n_rays, ctx->t_f)) return r;
+    return run_pass(ctx, s, KNERF_FINE, o, d, ctx->t_f, n_rays, Na, fi, nullptr, nullptr, target, inv_chunks, ls + 1);
+}
+
+int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // finite check first so that a bad step leaves the weights untouched (reference aborts fit at nerf.py:381-382)
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
+    HIPCHK(launch_check_finite(ctx->grads, 2 * kParamCount, ctx->d_flag, s));
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag) return fail(ctx, KNERF_ERR_NONFINITE, "Gradient is not finite");
+    ctx->step += 1;
+    const double b1 = ctx->cfg.beta1, b2 = ctx->cfg.beta2;
+    const float lr_t = (float)((double)ctx->cfg.lr * std::sqrt(1.0 - std::pow(b2, ctx->step)) / (1.0 - std::pow(b1, ctx->step)));
+    for (int n = 0; n < 2; ++n) {
+        AdamArgs a{};
+        a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = kParamCount;
+        a.lr_t = lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
+        HIPCHK(launch_adam(a, s));
+        if (int r = repack(ctx, n, s)) return r;
+    }
+    return KNERF_OK;
+}
+
+int knerf_zero_grads(knerf_ctx* ctx, void* stream) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    HIPCHK(hipMemsetAsync(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float), (hipStream_t)stream));
+    return KNERF_OK;
+}
+
+int knerf_step_count(const knerf_ctx* ctx) { return ctx ? ctx->step : KNERF_ERR_INVALID; }
+int knerf_set_step_count(knerf_ctx* ctx, int step) {
+    if (!ctx || step < 0) return KNERF_ERR_INVALID;
+    ctx->step = step;
+    return KNERF_OK;
+}
+
+int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const float* noise, uint64_t seed, uint64_t stream_id,
+                        int batch, int height, int width, int n_samples, float focal, float near_plane, float far_plane,
+                        float* o, float* d, float* t) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (!c2w || !o || !d || !t || batch <= 0 || height <= 0 || width <= 0 || n_samples <= 0)
+        return fail(ctx, KNERF_ERR_INVALID, "generate_rays: null/empty argument");
+    RayGenArgs a{};
+    a.c2w = c2w; a.noise = noise; a.o = o; a.d = d; a.t = t; a.B = batch; a.H = height; a.W = width; a.N = n_samples;
+    a.focal = focal; a.near_ = near_plane; a.far_ = far_plane; a.seed = seed; a.stream_id = stream_id;
+    HIPCHK(launch_raygen(a, (hipStream_t)stream));
+    return KNERF_OK;
+}
+
+int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes) {
+    if (!ctx || !dev || !bytes) return KNERF_ERR_INVALID;
+    (void)net;
+    switch (which) {
+        case 0: *dev = ctx->act; *bytes = ctx->act_bytes; break;
+        case 1: *dev = ctx->mask; *bytes = ctx->mask_bytes; break;
+        case 2: *dev = ctx->dz; *bytes = ctx->dz_bytes; break;
+        case 3: *dev = ctx->raw; *bytes = ctx->raw_bytes; break;
+        case 4: *dev = ctx->draw; *bytes = ctx->raw_bytes; break;
+        default: return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: unknown buffer");
+    }
+    return KNERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// layout.h -- host-side description of every device data layout of the fused NeRF MLP kernels.
+//
+// Pure C++ (no HIP): included by the HIP library and exercised on the CPU by tests/test_layout_sim.py through
+// knerf_debug_* entry points, where a NumPy lane-level model of v_mfma_f32_32x32x16_bf16 replays the kernels'
+// dataflow against the oracle.  Everything the kernels assume about operand order lives here, once.
+//
+// Architecture covered: NeRFMLP(n_layers=8, dense_units=256, skip_layer=4) with 63-d / 27-d encodings
+// (reference keras_nerf/model/nerf/mlp.py:5-50, nerf.py:118-130).  Other shapes are rejected by knerf_create.
+//
+// MFMA 32x32x16 bf16 operand maps (gfx950):
+//   A: lane l (r = l&31, h = l>>5) element j holds A[row r][k = 8h+j]
+//   B: lane l (c = l&31, h = l>>5) element j holds B[k = 8h+j][col c]
+//   C/D: lane l, reg i holds D[row = (i&3) + 8*(i>>2) + 4*(l>>5)][col = l&31]
+// The kernels compute H^T = W^T X^T: rows = features, cols = samples (one sample per lane&31).  A 32x32 f32
+// result converted pairwise to bf16 IS the B operand of the next layer (regs 8s..8s+7 -> k-step s), with the
+// k order permuted: element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3).  The packed weights carry the
+// same permutation, so no lane ever moves data.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace knerf {
+
+constexpr int kUnits = 256;
+constexpr int kLx = 10, kLd = 4;
+constexpr int kXyzDim = 63, kDirDim = 27;
+constexpr int kNumTensors = 24;
+
+// ---- flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias
+struct TensorInfo { int offset, rows, cols; };  // bias: rows = 1
+inline std::vector<TensorInfo> tensor_table() {
+    const int fi[12] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
+    const int fo[12] = {256, 256, 256, 256, 256, 256, 256, 256, 1, 256, 128, 3};
+    std::vector<TensorInfo> t;
+    int off = 0;
+    for (int l = 0; l < 12; ++l) {
+        t.push_back({off, fi[l], fo[l]}); off += fi[l] * fo[l];
+        t.push_back({off, 1, fo[l]});     off += fo[l];
+    }
+    return t;
+}
+constexpr int kParamCount = 595844;
+enum Layer { L0 = 0, L1, L2, L3, L4, L5, L6, L7, LSIG, LFEAT, LRF, LRGB };
+
+// ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
+// encoded position: 64 slots (4 k-steps).  half 0: x, y, sin(2^i p_c);  half 1: z, pad, cos(2^i p_c).
+inline int enc_feature(int q, int h, int j, int L) {
+    int m = 8 * q + j;                  // 0..(8*nq-1) within the lane half
+    if (m == 0) return h == 0 ? 0 : 2;  // x | z
+    if (m == 1) return h == 0 ? 1 : -1; // y | pad
+    int i = (m - 2) / 3, c = (m - 2) % 3;
+    if (i >= L) return -1;
+    return 3 + 6 * i + (h ? 3 : 0) + c; // positional_encoding order: [x, sin(2^0 x), cos(2^0 x), ...] (utils.py:176-186)
+}
+// hidden activations: slot (q,h,j) of a 256-wide tensor (16 k-steps)
+inline int hid_feature(int q, int h, int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---- description of one fused "dense" stage: list of input k-steps and output tiles
+struct KStep { int kind; int q; };   // kind: 0 hidden(prev out), 1 enc, 2 dir, 3 rgb-channels(bwd), 4 sigma(bwd); q = k-step inside that tensor
+struct Stage {
+    std::vector<KStep> ks;
+    int n_ot;                 // output tiles of 32 rows
+    // element source: param index for (k-step, half, j, out row) or -1
+};
+
+// index into the flat param buffer for kernel tensor `layer` at [in_row][out_col], -1 when out of range
+inline int kidx(const std::vector<TensorInfo>& tt, int layer, int in_row, int out_col) {
+    const TensorInfo& k = tt[2 * layer];
+    if (in_row < 0 || out_col < 0 || in_row >= k.rows || out_col >= k.cols) return -1;
+    return k.offset + in_row * k.cols + out_col;
+}
+inline int bidx(const std::vector<TensorInfo>& tt, int layer, int out_col) {
+    const TensorInfo& b = tt[2 * layer + 1];
+    if (out_col < 0 || out_col >= b.cols) return -1;
+    return b.offset + out_col;
+}
+
+// =====================================================================================================
+// forward stream: 1184 blocks of 1 KiB (64 lanes x 8 bf16).  Order: stage, out tile, k-step.
+// stage list: L0 | L1..L4 | L5 (16 hidden + 4 enc k-steps) | L6 L7 | FS = features(8 tiles)+sigma(1 tile) |
+//             RF = rgb_features (16 feat + 2 dir k-steps, 4 tiles) | RGB (8 k-steps, 1 tile)
+// =====================================================================================================
+constexpr int kFwdBlocks = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184
+constexpr int kFwdBiasTiles = 8 * 8 + 9 + 4 + 1;                            // 78 tiles of 32 fp32
+
+struct PackTables {
+    std::vector<int32_t> fwd;       // kFwdBlocks*512 entries: param index or -1
+    std::vector<int32_t> fwd_bias;  // kFwdBiasTiles*32
+    std::vector<int32_t> bwd;       // kBwdBlocks*512
+};
+
+// input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
+inline int fwd_in_row(int st, int ks, int h, int j) {
+    switch (st) {
+        case 0: return enc_feature(ks, h, j, kLx);                       // layer_0: 63 inputs in 4 k-steps
+        case 5: return ks < 16 ? hid_feature(ks, h, j)                   // layer_5: [h(256), xyz_enc(63)] (mlp.py:36-38)
+                               : (enc_feature(ks - 16, h, j, kLx) < 0 ? -1 : 256 + enc_feature(ks - 16, h, j, kLx));
+        case 9: return ks < 16 ? hid_feature(ks, h, j)                   // rgb_features: [features(256), dir_enc(27)]
+                               : (enc_feature(ks - 16, h, j, kLd) < 0 ? -1 : 256 + enc_feature(ks - 16, h, j, kLd));
+        default: return hid_feature(ks, h, j);                           // 256-wide (RGB stage: 128-wide, 8 k-steps)
+    }
+}
+struct FwdStage { int layer; int nks; int n_ot; };
+// stage index: 0..7 trunk, 8 = FS, 9 = RF, 10 = RGB
+inline FwdStage fwd_stage(int st) {
+    switch (st) {
+        case 0: return {L0, 4, 8};
+        case 5: return {L5, 20, 8};
+        case 8: return {LFEAT, 16, 9};
+        case 9: return {LRF, 18, 4};
+        case 10: return {LRGB, 8, 1};
+        default: return {st, 16, 8};
+    }
+}
+constexpr int kFwdStages = 11;
+
+inline void build_fwd(PackTables& pt) {
+    auto tt = tensor_table();
+    pt.fwd.assign((size_t)kFwdBlocks * 512, -1);
+    pt.fwd_bias.assign((size_t)kFwdBiasTiles * 32, -1);
+    size_t blk = 0; int btile = 0;
+    for (int st = 0; st < kFwdStages; ++st) {
+        FwdStage s = fwd_stage(st);
+        for (int ot = 0; ot < s.n_ot; ++ot) {
+            for (int r = 0; r < 32; ++r) {
+                int layer = s.layer, col = 32 * ot + r;
+                if (st == 8 && ot == 8) { layer = LSIG; col = r; }       // sigma head rides as the 9th tile (row 0 real)
+                pt.fwd_bias[(size_t)btile * 32 + r] = bidx(tt, layer, col);
+            }
+            ++btile;
+            for (int ks = 0; ks < s.nks; ++ks, ++blk) {
+                for (int l = 0; l < 64; ++l) {
+                    int r = l & 31, h = l >> 5;
+                    for (int j = 0; j < 8; ++j) {
+                        int layer = s.layer, col = 32 * ot + r;
+                        if (st == 8 && ot == 8) { layer = LSIG; col = r; }
+                        pt.fwd[blk * 512 + l * 8 + j] = kidx(tt, layer, fwd_in_row(st, ks, h, j), col);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// backward (dgrad) stream: A = W (rows = the layer's INPUT features, k = its OUTPUT features).
+// stage order (reverse of forward):
+//   B0: dz_rgb (1 k-step: channels at half 0, j<3)      -> df2   (4 tiles)    W_rgb[f2][c]
+//   B1: df2 (8 k-steps)                                 -> dfeat (8 tiles)    W_rf[feat][f2]   (dir rows unused)
+//   B2: dfeat (16) + dz_sigma (1 k-step: half 0, j=0)   -> dh7   (8 tiles)    W_f[h][feat], w_s[h][0]
+//   B3..B9: dz_l (16) -> dh_{l-1} (8 tiles) for l = 7,6,5,4,3,2,1   (layer 5: rows 0..255 of its 319)
+// =====================================================================================================
+constexpr int kBwdBlocks = 4 + 64 + 8 * 17 + 7 * 128;   // 1100
+constexpr int kBwdStages = 10;
+struct BwdStage { int nks; int n_ot; };
+inline BwdStage bwd_stage(int st) {
+    switch (st) {
+        case 0: return {1, 4};
+        case 1: return {8, 8};
+        case 2: return {17, 8};
+        default: return {16, 8};
+    }
+}
+inline void build_bwd(PackTables& pt) {
+    auto tt = tensor_table();
+    pt.bwd.assign((size_t)kBwdBlocks * 512, -1);
+    size_t blk = 0;
+    for (int st = 0; st < kBwdStages; ++st) {
+        BwdStage s = bwd_stage(st);
+        for (int ot = 0; ot < s.n_ot; ++ot)
+            for (int ks = 0; ks < s.nks; ++ks, ++blk)
+                for (int l = 0; l < 64; ++l) {
+                    int r = l & 31, h = l >> 5, row = 32 * ot + r;   // row = input feature of the layer
+                    for (int j = 0; j < 8; ++j) {
+                        int v = -1;
+                        if (st == 0) { int c = 8 * h + j; v = kidx(tt, LRGB, row, c < 3 ? c : -1); }
+                        else if (st == 1) v = kidx(tt, LRF, row, hid_feature(ks, h, j) < 128 ? hid_feature(ks, h, j) : -1);
+                        else if (st == 2) v = ks < 16 ? kidx(tt, LFEAT, row, hid_feature(ks, h, j))
+                                                      : kidx(tt, LSIG, row, (h == 0 && j == 0) ? 0 : -1);
+                        else v = kidx(tt, L7 - (st - 3), row, hid_feature(ks, h, j));
+                        pt.bwd[blk * 512 + l * 8 + j] = v;
+                    }
+                }
+    }
+}
+
+// =====================================================================================================
+// saved tensors (training): per sample tile (32 samples) a run of 1 KiB B-operand blocks, lane-linear
+//   [lane l = (h<<5)|s][8 bf16]  ->  byte offset l*16
+// forward "act" run (158 blocks):  h0 h1 h2 h3 h4 enc h5 h6 h7 feat dir f2
+// backward "dz" run  (156 blocks): dz0 .. dz7  dfeat dzsig(2) df2 dzrgb(2)
+// so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5.
+// =====================================================================================================
+constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, kActFeat = 132, kActDir = 148,
+              kActF2 = 150, kActBlocks = 158;
+constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
+constexpr int kDzFeat = 128, kDzSig = 144, kDzF2 = 146, kDzRgb = 154, kDzBlocks = 156;
+constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
+
+// wgrad jobs: dW[in_row][out_col] += sum_s act[s][in] * dz[s][out], db[out_col] += sum_s dz[s][out]
+struct WgradJob {
+    int act_blk, n_it;    // first act block, number of 32-row input tiles (2 blocks each)
+    int dz_blk, n_ot;     // first dz block, number of 32-col output tiles
+    int layer;            // destination kernel/bias (FS job also writes LSIG from its 9th tile)
+};
+constexpr int kWgradJobs = 12;
+inline WgradJob wgrad_job(int j) {
+    switch (j) {
+        case 0: return {kActEnc, 2, 0, 8, L0};
+        case 5: return {kActH4, 10, 16 * 5, 8, L5};
+        case 8: return {kActH7, 8, kDzFeat, 9, LFEAT};          // [dfeat ; dz_sigma]
+        case 9: return {kActFeat, 9, kDzF2, 4, LRF};            // [feat ; dir]
+        case 10: return {kActF2, 4, kDzRgb, 1, LRGB};
+        case 11: return {0, 0, 0, 0, -1};
+        default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 1-4, 6, 7
+    }
+}
+// in_row of job jb for tile-row index tr (0..32*n_it-1) in *natural tr-read order*: the transposed read un-permutes
+// hidden tensors (row = feature), and presents enc/dir blocks in slot order (q = tr>>4, c16 = tr&15 ->
+// h = (c16>>2)&1, j = 4*(c16>>3) + (c16&3)).
+inline int slot_from_c16_h(int c16) { return (c16 >> 2) & 1; }
+inline int slot_from_c16_j(int c16) { return 4 * (c16 >> 3) + (c16 & 3); }
+inline int wgrad_in_row(int jb, int tr) {
+    auto encrow = [](int tr_, int L) { int q = tr_ >> 4, c = tr_ & 15; return enc_feature(q, slot_from_c16_h(c), slot_from_c16_j(c), L); };
+    switch (jb) {
+        case 0: return encrow(tr, kLx);
+        case 5: return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
+        case 9: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
+        case 10: return tr < 128 ? tr : -1;
+        default: return tr;
+    }
+}
+// destination (param index) of wgrad output element; in_row == -2 selects the bias row
+inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) {
+    WgradJob J = wgrad_job(jb);
+    int layer = J.layer, col = tc;
+    if (jb == 8 && tc >= 256) { layer = LSIG; col = tc - 256; }
+    if (tr == -2) return bidx(tt, layer, col);
+    return kidx(tt, layer, wgrad_in_row(jb, tr), col);
+}
+
+}  // namespace knerf

@@ -1,0 +1,184 @@
+// mlp_fwd.hip -- fused positional encoding + 8x256 ReLU trunk + sigma / rgb heads for one NeRF MLP (gfx950).
+//
+// Replaces, per sample: NeRFUtils.encode_position_and_directions (reference keras_nerf/model/nerf/utils.py:188-210),
+// NeRFUtils.positional_encoding (utils.py:176-186) and NeRFMLP.call (mlp.py:29-50).
+// Input: ray origins/directions [R,3] and t-values [R,S] (fp32).  Output: raw[R*S] = (r,g,b,sigma) fp32 after
+// sigmoid / relu.  SAVE additionally writes every layer's bf16 activations (B-operand blocks, layout.h) and the
+// ReLU masks for the backward kernels.
+#include "chain.h"
+#include "kernels.h"
+#include "layout.h"
+
+namespace knerf {
+
+// sin / cos of 2^i * x, i = 0..L-1, for the three components, written straight into B-operand slots.
+// Range reduction is exact: r = x/(2pi) as hi+lo floats, fract(2^i * r_hi) is exact in fp32, the v_sin_f32 argument
+// is in revolutions.  cos = sin shifted by a quarter revolution, so both lane halves run the same instruction.
+template <int L, int NQ>
+__device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 (&out)[NQ]) {
+    const float C1 = 0.15915494f;             // fl(1/(2 pi))
+    const float C2 = 6.4206383e-09f;          // 1/(2 pi) - C1   (0.15915494309189535 - 0.15915493667125702)
+    float v[3] = {x, y, z};
+    float rh[3], rl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rh[c] = v[c] * C1;
+        rl[c] = __builtin_fmaf(v[c], C1, -rh[c]) + v[c] * C2;
+    }
+    const float phase = h ? 0.25f : 0.0f;
+    float e[NQ * 8];
+#pragma unroll
+    for (int m = 0; m < NQ * 8; ++m) e[m] = 0.f;
+    e[0] = h ? z : x;
+    e[1] = h ? 0.f : y;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float s = (float)(1 << i);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = rh[c] * s;
+            float f = a - __builtin_floorf(a);
+            float arg = f + (rl[c] * s + phase);
+            e[2 + 3 * i + c] = __builtin_amdgcn_sinf(arg);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = reinterpret_cast<float*>(smem + kRingBytes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+
+    // biases -> LDS (plain loads, before any LDS-DMA is in flight)
+    for (int i = tid; i < kFwdBiasTiles * 32; i += kThreads) bias_lds[i] = a.bias[i];
+
+    const long long tile = (long long)blockIdx.x * kWaves + wave;
+    long long g = tile * kTile + col;
+    const bool valid = g < a.n_samples;
+    if (!valid) g = a.n_samples - 1;
+    const long long ray = g / a.S;
+    const float t = a.t[g];
+    const float ox = a.o[ray * 3 + 0], oy = a.o[ray * 3 + 1], oz = a.o[ray * 3 + 2];
+    const float dx = a.d[ray * 3 + 0], dy = a.d[ray * 3 + 1], dz = a.d[ray * 3 + 2];
+    // p = o + d * t  (two roundings, as the reference's mul then add; utils.py:193-194)
+    const float px = __fadd_rn(ox, __fmul_rn(dx, t)), py = __fadd_rn(oy, __fmul_rn(dy, t)), pz = __fadd_rn(oz, __fmul_rn(dz, t));
+    __syncthreads();
+
+    Ring ring{a.stream, smem, tid};
+    ring.prologue_issue();
+
+    bf16x8 enc[4], dirc[2];
+    encode<kLx, 4>(px, py, pz, h, enc);
+    encode<kLd, 2>(dx, dy, dz, h, dirc);
+
+    char* act = nullptr; char* maskp = nullptr;
+    if (SAVE) {
+        act = a.act + (size_t)tile * kActBlocks * 1024;
+        maskp = a.mask + (size_t)tile * kMaskBlocks * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_block(act, kActEnc + q, lane, enc[q]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
+    }
+
+    ring.prologue_wait();
+    Prefetch pf;
+    pf.start<kFwdBlocks>(ring, lane);
+
+    bf16x8 x[16], y[16];
+    // relu epilogue of a trunk layer: out -> y (or x), activations + mask saved in training
+    auto relu_epi = [&](bf16x8 (&out)[16], int layer, unsigned (&mbits)[4]) {
+        return [&, layer](int ot, f32x16 acc) {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (SAVE) m |= (acc[i] > 0.f ? 1u : 0u) << i;
+                acc[i] = __builtin_amdgcn_fmed3f(acc[i], 0.f, __builtin_inff());
+            }
+            pack_acc(acc, out[2 * ot], out[2 * ot + 1]);
+            if (SAVE) {
+                store_block(act, act_h(layer) + 2 * ot, lane, out[2 * ot]);
+                store_block(act, act_h(layer) + 2 * ot + 1, lane, out[2 * ot + 1]);
+                if (ot & 1) mbits[ot >> 1] |= m << 16; else mbits[ot >> 1] = m;
+                if (ot == 7) *reinterpret_cast<u32x4*>(maskp + layer * 1024 + lane * 16) = u32x4{mbits[0], mbits[1], mbits[2], mbits[3]};
+            }
+        };
+    };
+    unsigned mb[4];
+    int btile = 0;
+    auto bias_init = [&](int base) { return [&, base](int ot) { return bias_acc(bias_lds, base + ot, h); }; };
+
+    // layer_0: 63 -> 256
+    dense_stage<0, 4, 8, kFwdBlocks>(ring, pf, lane, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
+    // layer_1..4
+    dense_stage<32, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(8), [&](int ks) { return x[ks]; }, relu_epi(y, 1, mb));
+    dense_stage<160, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(16), [&](int ks) { return y[ks]; }, relu_epi(x, 2, mb));
+    dense_stage<288, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(24), [&](int ks) { return x[ks]; }, relu_epi(y, 3, mb));
+    dense_stage<416, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(32), [&](int ks) { return y[ks]; }, relu_epi(x, 4, mb));
+    // layer_5: [h4, xyz_enc] -> 256   (skip concat: h first, input second; mlp.py:36-38)
+    dense_stage<544, 20, 8, kFwdBlocks>(ring, pf, lane, bias_init(40), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : enc[ks >= 16 ? ks - 16 : 0]; },
+                            relu_epi(y, 5, mb));
+    dense_stage<704, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(48), [&](int ks) { return y[ks]; }, relu_epi(x, 6, mb));
+    dense_stage<832, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(56), [&](int ks) { return x[ks]; }, relu_epi(y, 7, mb));
+    (void)btile;
+    // features (linear, 8 tiles) + sigma (relu, 9th tile row 0)
+    float sigma = 0.f;
+    dense_stage<960, 16, 9, kFwdBlocks>(ring, pf, lane, bias_init(64), [&](int ks) { return y[ks]; }, [&](int ot, f32x16 acc) {
+        if (ot < 8) {
+            pack_acc(acc, x[2 * (ot < 8 ? ot : 0)], x[2 * (ot < 8 ? ot : 0) + 1]);
+            if (SAVE) {
+                store_block(act, kActFeat + 2 * ot, lane, x[2 * (ot < 8 ? ot : 0)]);
+                store_block(act, kActFeat + 2 * ot + 1, lane, x[2 * (ot < 8 ? ot : 0) + 1]);
+            }
+        } else {
+            sigma = acc[0] > 0.f ? acc[0] : 0.f;   // lanes of half 0 hold row 0
+        }
+    });
+    // rgb_features: [features, dir_enc] -> 128, LINEAR in this reference (mlp.py:23-24,46)
+    bf16x8 f2[8];
+    dense_stage<1104, 18, 4, kFwdBlocks>(ring, pf, lane, bias_init(73), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
+                             [&](int ot, f32x16 acc) {
+                                 pack_acc(acc, f2[2 * ot], f2[2 * ot + 1]);
+                                 if (SAVE) {
+                                     store_block(act, kActF2 + 2 * ot, lane, f2[2 * ot]);
+                                     store_block(act, kActF2 + 2 * ot + 1, lane, f2[2 * ot + 1]);
+                                 }
+                             });
+    // rgb: 128 -> 3, sigmoid
+    dense_stage<1176, 8, 1, kFwdBlocks>(ring, pf, lane, bias_init(77), [&](int ks) { return f2[ks]; }, [&](int, f32x16 acc) {
+        if (valid && h == 0) {
+            f32x4 r;
+            r[0] = 1.f / (1.f + expf(-acc[0]));
+            r[1] = 1.f / (1.f + expf(-acc[1]));
+            r[2] = 1.f / (1.f + expf(-acc[2]));
+            r[3] = sigma;
+            reinterpret_cast<f32x4*>(a.raw)[g] = r;
+        }
+    });
+    ring.drain();
+}
+
+hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
+    const long long tiles = (a.n_samples + kTile - 1) / kTile;
+    const int grid = (int)((tiles + kWaves - 1) / kWaves);
+    const size_t lds = kRingBytes + kFwdBiasTiles * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (save) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace knerf

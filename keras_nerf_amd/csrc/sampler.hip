@@ -1,0 +1,118 @@
+// sampler.hip -- inverse-CDF hierarchical sampling + merge with the coarse t-values, one wavefront per ray (gfx950).
+//
+// Restates NeRF._predict_and_render_chunk's fine branch (reference keras_nerf/model/nerf/nerf.py:182-191) and
+// NeRFUtils.fine_hierarchical_sampling_chunk (utils.py:60-97):
+//   mids = 0.5*(t[1:]+t[:-1]);  w += 1e-5; pdf = w/sum(w); cdf = [0, cumsum(pdf)];
+//   idx = searchsorted(cdf, u, 'right'); below = max(0, idx-1); above = min(Nc, idx);
+//   gather cdf and mids (mids has only Nc-1 entries: an out-of-range gather yields 0 -- tf.gather on GPU -- or is
+//   clamped); denom<1e-5 -> 1; sample = m_b + (u-cdf_b)/denom*(m_a-m_b);
+//   t_all = sort(concat(t_coarse, samples)).
+// u is either caller-provided (parity tests) or Philox4x32-10 keyed by (seed; block, ray, stream).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace knerf {
+
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)c[0] * 0xD2511F53ull;
+    const unsigned long long p1 = (unsigned long long)c[2] * 0xCD9E8D57ull;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+// u[ray][j]: counter (j/4, ray, stream, 0), key (seed_lo, seed_hi), word j%4, u = (x>>8) * 2^-24
+__device__ __forceinline__ float philox_u(unsigned long long seed, unsigned stream_id, unsigned ray, int j) {
+    unsigned c[4] = {(unsigned)(j >> 2), ray, stream_id, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned x = c[j & 3];
+    return (float)(x >> 8) * 5.9604644775390625e-08f;
+}
+
+constexpr int kMaxCoarse = 256, kMaxAll = 768;
+
+__global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
+    __shared__ float s_t[4][kMaxCoarse];
+    __shared__ float s_cdf[4][kMaxCoarse + 1];
+    __shared__ float s_all[4][kMaxAll];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= a.R) return;
+    const int Nc = a.Nc, Nf = a.Nf, Na = Nc + Nf;
+    float* tt = s_t[wv]; float* cdf = s_cdf[wv]; float* all = s_all[wv];
+    const float* tc = a.t_coarse + (size_t)ray * Nc;
+    const float* wc = a.w_coarse + (size_t)ray * Nc;
+
+    // weights += 1e-5, total
+    const int C = (Nc + 63) / 64;
+    float tot = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        if (i < Nc) { const float tv = tc[i]; tt[i] = tv; all[i] = tv; tot += wc[i] + 1e-5f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    // cdf = [0, cumsum(pdf)]: lane-local run, then wave scan of the run totals
+    float run = 0.f;
+    for (int c = 0; c < C; ++c) { const int i = lane * C + c; if (i < Nc) run += (wc[i] + 1e-5f) / tot; }
+    float inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    float acc = inc - run;
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        if (i < Nc) { acc += (wc[i] + 1e-5f) / tot; cdf[i + 1] = acc; }
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    const int nm = Nc - 1;   // number of mid-points
+    for (int j = lane; j < Nf; j += 64) {
+        const float u = a.u ? a.u[(size_t)ray * Nf + j]
+                            : philox_u(a.seed, (unsigned)a.stream_id, (unsigned)(a.ray_offset + ray), j);
+        // searchsorted(side='right'): number of cdf entries (Nc+1 of them) that are <= u
+        int lo = 0, hi = Nc + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+        const int idx = lo;
+        const int below = max(0, idx - 1), above = min(Nc, idx);
+        const float cb = cdf[below], ca = cdf[above];
+        float mb, ma;
+        if (a.oob_clamp) {
+            const int ib = min(below, nm - 1), ia = min(above, nm - 1);
+            mb = 0.5f * (tt[ib + 1] + tt[ib]); ma = 0.5f * (tt[ia + 1] + tt[ia]);
+        } else {
+            mb = below < nm ? 0.5f * (tt[below + 1] + tt[below]) : 0.f;
+            ma = above < nm ? 0.5f * (tt[above + 1] + tt[above]) : 0.f;
+        }
+        float denom = __fsub_rn(ca, cb);
+        if (denom < 1e-5f) denom = 1.f;
+        const float q = __fdiv_rn(__fsub_rn(u, cb), denom);
+        all[Nc + j] = __fadd_rn(mb, __fmul_rn(q, __fsub_rn(ma, mb)));
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // rank sort (stable): Na values, each lane ranks ceil(Na/64) of them against all
+    float* out = a.t_out + (size_t)ray * Na;
+    for (int e = lane; e < Na; e += 64) {
+        const float v = all[e];
+        int rank = 0;
+        for (int k = 0; k < Na; ++k) {
+            const float o = all[k];
+            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+        }
+        out[rank] = v;
+    }
+}
+
+hipError_t launch_sample_fine(const SampleArgs& a, hipStream_t stream) {
+    if (a.Nc > kMaxCoarse || a.Nc + a.Nf > kMaxAll || a.Nc < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_fine_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace knerf

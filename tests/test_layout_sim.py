@@ -1,0 +1,51 @@
+"""CPU check of the device layouts: the real library's packing tables (knerf_debug_table) are replayed through a
+lane-level NumPy model of the MFMA instruction and must reproduce the oracle MLP (bf16-emulating mode)."""
+import numpy as np
+import pytest
+
+from keras_nerf_amd import _lib
+from oracle import nerf_oracle as O
+from tests import mfma_sim as M
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg = O.NerfConfig()
+    rng = np.random.default_rng(3)
+    params = O.init_params(cfg, 11)
+    for b in params[1::2]:
+        b += rng.normal(0, 0.05, b.shape).astype(np.float32)
+    flat = O.flatten_params(params)
+    o = rng.normal(0, 1.5, (32, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (32, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = rng.uniform(2, 6, (32, 1)).astype(np.float32)
+    p = (o + d * t).astype(np.float32)
+    return cfg, params, flat, p, d
+
+
+def test_tables_cover_every_parameter_exactly_where_expected():
+    fwd, bias = _lib.debug_table(0), _lib.debug_table(1)
+    n = _lib.load().knerf_param_count()
+    used = np.zeros(n, bool)
+    used[fwd[fwd >= 0]] = True
+    used[bias[bias >= 0]] = True
+    assert used.all()                                   # every weight and bias is reachable by the forward stream
+    vals, counts = np.unique(fwd[fwd >= 0], return_counts=True)
+    assert counts.max() == 1                            # and appears once
+    assert fwd.size == 1184 * 512 and bias.size == 78 * 32
+    bwd = _lib.debug_table(2)
+    assert bwd.size == 1100 * 512
+    vals, counts = np.unique(bwd[bwd >= 0], return_counts=True)
+    assert counts.max() == 1
+
+
+def test_forward_chain_matches_oracle(setup):
+    cfg, params, flat, p, d = setup
+    rgb, sigma, _ = M.forward_chain(_lib.debug_table(0), _lib.debug_table(1), flat, p, d)
+    xyz = O.positional_encoding(p, 10)[None]
+    dire = O.positional_encoding(d, 4)[None]
+    rgb_o, sigma_o = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=True)
+    np.testing.assert_allclose(rgb, rgb_o[0], atol=1e-3)   # a bf16 rounding flip of one activation moves an output by ~1e-4
+    np.testing.assert_allclose(sigma, sigma_o[0, :, 0], atol=1e-3, rtol=1e-2)
+    rgb32, sigma32 = O.mlp_forward(params, xyz, dire, cfg)
+    assert np.abs(rgb - rgb32[0]).max() < 2e-2          # bf16 operands vs fp32: the kernel's stated tolerance class
