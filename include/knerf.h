@@ -102,8 +102,13 @@ int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const fl
 /* kind 0: forward A-fragment table, 1: forward bias table, 2: dgrad A-fragment table, 3: wgrad destination table.
  * Entries are indices into the flat parameter vector or -1.  Pass out=NULL to query the length. */
 int knerf_debug_table(int kind, int32_t* out, size_t* n);
-/* device buffers of the last knerf_train_chunk for kernel-level tests: 0 act, 1 mask, 2 dz, 3 raw, 4 draw */
+/* device buffers of the last knerf_train_chunk for kernel-level tests: 0 act, 1 mask, 2 dz, 3 raw, 4 draw,
+ * 5 merged fine t-values, 6 coarse weights */
 int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes);
+/* hardware-fact probes for tests: kind 0 = one v_mfma_f32_32x32x16_bf16 (in0 = A fragments [64][8] bf16, in1 = B
+ * fragments, out = [64][16] f32); kind 1 = one ds_read_b64_tr_b16 (in0 = 4 KiB LDS image, in1 = [64] int32 byte
+ * offsets, out = [64][4] u16).  All device pointers. */
+int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream);
 
 #ifdef __cplusplus
 }

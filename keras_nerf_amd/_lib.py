@@ -44,6 +44,7 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_float, _F, _F, _F]),
     "knerf_debug_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "knerf_debug_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "knerf_debug_probe": (C.c_int, [C.c_int, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -120,8 +120,10 @@ __device__ __forceinline__ void dense_stage(const Ring& ring, Prefetch& pf, int 
     }
 }
 
+// saved B-operand block (layout.h saved_off): lane (h = lane>>5, s = lane&31) -> (2*(s ^ 4*(block&1)) + h) * 16
 __device__ __forceinline__ void store_block(char* base, size_t block, int lane, const bf16x8& v) {
-    *reinterpret_cast<bf16x8*>(base + block * 1024 + lane * 16) = v;
+    const int s = lane & 31, h = lane >> 5;
+    *reinterpret_cast<bf16x8*>(base + block * 1024 + (2 * (s ^ (((int)block & 1) << 2)) + h) * 16) = v;
 }
 
 }  // namespace knerf

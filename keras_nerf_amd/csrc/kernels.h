@@ -33,8 +33,11 @@ struct WgradArgs {
     const char* act;        // [tiles][kActBlocks][1 KiB]
     const char* dz;         // [tiles][kDzBlocks][1 KiB]
     float* grad;            // flat fp32 gradient accumulator of this net (kParamCount)
-    const int* dst;         // per job: destination index tables (see knerf_api.hip)
+    const int* dst;         // concatenated per-job destination tables: [(32*n_it + 1) rows][32*n_ot cols] param index or -1
+    const void* plan;       // device array of WgradPlan, one per workgroup
     long long n_tiles;
+    int n_plan;
+    int job_off[14];        // offset of each job's table inside dst
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
 

@@ -29,8 +29,23 @@ struct Tables {
     PackTables host;
     std::vector<int32_t> wgrad;        // concatenated per-job destination tables
     std::vector<int32_t> wgrad_off;    // kWgradJobs+1 offsets
-    int *d_fwd = nullptr, *d_bias = nullptr, *d_bwd = nullptr, *d_wgrad = nullptr;
+    int *d_fwd = nullptr, *d_bias = nullptr, *d_bwd = nullptr, *d_wgrad = nullptr, *d_plan = nullptr;
+    int n_plan = 0;
 };
+
+// workgroups per wgrad job in proportion to the bytes the job streams per sample tile (the kernel is HBM-bound),
+// about one workgroup per CU in total
+std::vector<int32_t> build_wgrad_plan(int n_wg) {
+    int bytes[kWgradJobs], total = 0;
+    for (int j = 0; j < kWgradJobs; ++j) { WgradJob J = wgrad_job(j); bytes[j] = J.layer < 0 ? 0 : 2 * (J.n_it + J.n_ot); total += bytes[j]; }
+    std::vector<int32_t> plan;
+    for (int j = 0; j < kWgradJobs; ++j) {
+        if (!bytes[j]) continue;
+        int ns = bytes[j] * n_wg / total; if (ns < 1) ns = 1;
+        for (int s = 0; s < ns; ++s) { plan.push_back(j); plan.push_back(s); plan.push_back(ns); plan.push_back(0); }
+    }
+    return plan;
+}
 
 }  // namespace
 
@@ -122,6 +137,8 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
         HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
+        HIPCHK(hipMemset(ctx->dz, 0, ctx->dz_bytes));     // blocks kDzSig+1 / kDzRgb+1 are never written and must read 0
+        HIPCHK(hipMemset(ctx->act, 0, ctx->act_bytes));
     }
     ctx->ws_rays = R; ctx->ws_train = train;
     return KNERF_OK;
@@ -156,6 +173,8 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
+        wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan;
+        for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
         HIPCHK(launch_wgrad(wa, s));
     }
     return KNERF_OK;
@@ -228,6 +247,11 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(up(ctx->tab.d_bias, ctx->tab.host.fwd_bias));
     CREATECHK(up(ctx->tab.d_bwd, ctx->tab.host.bwd));
     CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
+    {
+        std::vector<int32_t> plan = build_wgrad_plan(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        ctx->tab.n_plan = (int)plan.size() / 4;
+        CREATECHK(up(ctx->tab.d_plan, plan));
+    }
     CREATECHK(hipMalloc(&ctx->grads, 2 * (size_t)kParamCount * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->d_flag, sizeof(int)));
@@ -261,7 +285,7 @@ int knerf_destroy(knerf_ctx* ctx) {
         free_dev(N.w); free_dev(N.m); free_dev(N.v); free_dev(N.fwd_stream); free_dev(N.bwd_stream); free_dev(N.bias);
     }
     free_dev(ctx->grads); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp);
-    free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad);
+    free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
     delete ctx;
@@ -415,6 +439,8 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
         case 2: *dev = ctx->dz; *bytes = ctx->dz_bytes; break;
         case 3: *dev = ctx->raw; *bytes = ctx->raw_bytes; break;
         case 4: *dev = ctx->draw; *bytes = ctx->raw_bytes; break;
+        case 5: *dev = ctx->t_f; *bytes = (size_t)ctx->ws_rays * (ctx->cfg.n_coarse + ctx->cfg.n_fine) * sizeof(float); break;
+        case 6: *dev = ctx->w_c; *bytes = (size_t)ctx->ws_rays * ctx->cfg.n_coarse * sizeof(float); break;
         default: return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: unknown buffer");
     }
     return KNERF_OK;

@@ -185,12 +185,15 @@ inline void build_bwd(PackTables& pt) {
 }
 
 // =====================================================================================================
-// saved tensors (training): per sample tile (32 samples) a run of 1 KiB B-operand blocks, lane-linear
-//   [lane l = (h<<5)|s][8 bf16]  ->  byte offset l*16
+// saved tensors (training): per sample tile (32 samples) a run of 1 KiB B-operand blocks; lane (h, s) of block b
+// stores its 8 bf16 at byte offset saved_off(b, h, s) = (2*(s ^ 4*(b&1)) + h) * 16: the two feature halves of a
+// sample are adjacent (32 B per sample) and odd blocks rotate their sample quads, which makes the wgrad kernel's
+// ds_read_b64_tr_b16 transposed reads bank-conflict free while the store stays one coalesced 1 KiB write.
 // forward "act" run (158 blocks):  h0 h1 h2 h3 h4 enc h5 h6 h7 feat dir f2
 // backward "dz" run  (156 blocks): dz0 .. dz7  dfeat dzsig(2) df2 dzrgb(2)
 // so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5.
 // =====================================================================================================
+constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
 constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, kActFeat = 132, kActDir = 148,
               kActF2 = 150, kActBlocks = 158;
 constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
@@ -203,15 +206,16 @@ struct WgradJob {
     int dz_blk, n_ot;     // first dz block, number of 32-col output tiles
     int layer;            // destination kernel/bias (FS job also writes LSIG from its 9th tile)
 };
-constexpr int kWgradJobs = 12;
+constexpr int kWgradJobs = 13;
 inline WgradJob wgrad_job(int j) {
     switch (j) {
         case 0: return {kActEnc, 2, 0, 8, L0};
-        case 5: return {kActH4, 10, 16 * 5, 8, L5};
-        case 8: return {kActH7, 8, kDzFeat, 9, LFEAT};          // [dfeat ; dz_sigma]
-        case 9: return {kActFeat, 9, kDzF2, 4, LRF};            // [feat ; dir]
-        case 10: return {kActF2, 4, kDzRgb, 1, LRGB};
-        case 11: return {0, 0, 0, 0, -1};
+        case 5: return {kActH4, 10, 16 * 5, 8, L5};             // [h4 ; enc]
+        case 8: return {kActH7, 8, kDzFeat, 8, LFEAT};
+        case 9: return {kActH7, 8, kDzSig, 1, LSIG};
+        case 10: return {kActFeat, 9, kDzF2, 4, LRF};           // [feat ; dir]
+        case 11: return {kActF2, 4, kDzRgb, 1, LRGB};
+        case 12: return {0, 0, 0, 0, -1};
         default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 1-4, 6, 7
     }
 }
@@ -225,8 +229,8 @@ inline int wgrad_in_row(int jb, int tr) {
     switch (jb) {
         case 0: return encrow(tr, kLx);
         case 5: return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
-        case 9: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
-        case 10: return tr < 128 ? tr : -1;
+        case 10: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
+        case 11: return tr < 128 ? tr : -1;
         default: return tr;
     }
 }
@@ -234,7 +238,6 @@ inline int wgrad_in_row(int jb, int tr) {
 inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) {
     WgradJob J = wgrad_job(jb);
     int layer = J.layer, col = tc;
-    if (jb == 8 && tc >= 256) { layer = LSIG; col = tc - 256; }
     if (tr == -2) return bidx(tt, layer, col);
     return kidx(tt, layer, wgrad_in_row(jb, tr), col);
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ float philox_u(unsigned long long seed, unsigned stre
     return (float)(x >> 8) * 5.9604644775390625e-08f;
 }
 
-constexpr int kMaxCoarse = 256, kMaxAll = 768;
+constexpr int kMaxCoarse = 256, kMaxAll = 768;   // kMaxAll >= 2*kMaxCoarse: the fine half doubles as scratch
 
 __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
     __shared__ float s_t[4][kMaxCoarse];
@@ -46,25 +46,18 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
     const float* tc = a.t_coarse + (size_t)ray * Nc;
     const float* wc = a.w_coarse + (size_t)ray * Nc;
 
-    // weights += 1e-5, total
-    const int C = (Nc + 63) / 64;
+    // stage t and w + 1e-5 in LDS
+    float* wl = all + Nc;            // scratch: the fine half of `all` is not written until the cdf exists
+    for (int i = lane; i < Nc; i += 64) { const float tv = tc[i]; tt[i] = tv; all[i] = tv; wl[i] = __fadd_rn(wc[i], 1e-5f); }
+    __builtin_amdgcn_wave_barrier();
+    // total and cdf = [0, cumsum(pdf)] strictly left to right (the oracle's declared order; every lane computes the
+    // same values, lane 0 stores them): the knot positions decide searchsorted and the denom<1e-5 branch bit for bit
     float tot = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const int i = lane * C + c;
-        if (i < Nc) { const float tv = tc[i]; tt[i] = tv; all[i] = tv; tot += wc[i] + 1e-5f; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    // cdf = [0, cumsum(pdf)]: lane-local run, then wave scan of the run totals
-    float run = 0.f;
-    for (int c = 0; c < C; ++c) { const int i = lane * C + c; if (i < Nc) run += (wc[i] + 1e-5f) / tot; }
-    float inc = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { float v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-    float acc = inc - run;
-    for (int c = 0; c < C; ++c) {
-        const int i = lane * C + c;
-        if (i < Nc) { acc += (wc[i] + 1e-5f) / tot; cdf[i + 1] = acc; }
+    for (int i = 0; i < Nc; ++i) tot = __fadd_rn(tot, wl[i]);
+    float acc = 0.f;
+    for (int i = 0; i < Nc; ++i) {
+        acc = __fadd_rn(acc, __fdiv_rn(wl[i], tot));
+        if (lane == 0) cdf[i + 1] = acc;
     }
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_wave_barrier();

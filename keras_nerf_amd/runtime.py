@@ -1,0 +1,183 @@
+"""Thin object wrapper over the C ABI (include/knerf.h): torch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import COARSE, FINE, KnerfConfig, KnerfError  # noqa: F401
+
+
+class NonFiniteGradientError(ArithmeticError):
+    """Counterpart of the InvalidArgumentError raised by tf.debugging.assert_all_finite (reference nerf.py:381-382)."""
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(x, device) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _CudaView:
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class KnerfContext:
+    """Owns one knerf_ctx on the current CUDA(HIP) device."""
+
+    def __init__(self, n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4,
+                 white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None):
+        self._ctx = C.c_void_p()
+        if not torch.cuda.is_available():
+            raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        if oob not in ("zero", "clamp"):
+            raise ValueError("oob must be 'zero' or 'clamp'")
+        self.cfg = KnerfConfig(n_coarse, n_fine, pos_emb_xyz, pos_emb_dir, n_layers, dense_units, skip_layer,
+                               int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon)
+        self.n_coarse, self.n_fine = n_coarse, n_fine
+        rc = self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
+        if rc != 0:
+            msg = self.lib.knerf_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
+        self.param_count = int(self.lib.knerf_param_count())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.knerf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        msg = self.lib.knerf_last_error(self._ctx).decode()
+        if rc == _lib.KNERF_ERR_NONFINITE:
+            raise NonFiniteGradientError(msg)
+        if rc == _lib.KNERF_ERR_INVALID:
+            raise ValueError(msg)
+        raise KnerfError(f"knerf error {rc}: {msg}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def f32(self, x) -> torch.Tensor:
+        return _f32(x, self.device)
+
+    # ---- weights
+    def set_weights(self, net: int, flat):
+        flat = np.ascontiguousarray(np.asarray(flat, dtype=np.float32).reshape(-1))
+        self._check(self.lib.knerf_set_weights(self._ctx, net, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size))
+
+    def get_weights(self, net: int) -> np.ndarray:
+        out = np.empty(self.param_count, np.float32)
+        self._check(self.lib.knerf_get_weights(self._ctx, net, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def weights_view(self, net: int) -> torch.Tensor:
+        """torch view (no copy) of the library-owned fp32 master weights of one net"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.knerf_weights_device(self._ctx, net, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_CudaView(p.value, n.value, "<f4"), device=self.device)
+
+    def grads_view(self) -> torch.Tensor:
+        """torch view (no copy) of the gradient accumulators [coarse | fine]: the buffer a DP step all-reduces"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.knerf_grads_device(self._ctx, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_CudaView(p.value, n.value, "<f4"), device=self.device)
+
+    def refresh_weights(self):
+        self._check(self.lib.knerf_refresh_weights(self._ctx, self._stream()))
+
+    # ---- forward
+    def forward_chunk(self, net: int, o, d, t):
+        o, d, t = self.f32(o), self.f32(d), self.f32(t)
+        R, S = t.shape
+        image = torch.empty((R, 3), device=self.device); depth = torch.empty((R,), device=self.device)
+        weights = torch.empty((R, S), device=self.device)
+        self._check(self.lib.knerf_forward_chunk(self._ctx, self._stream(), net, _ptr(o), _ptr(d), _ptr(t), R, S,
+                                                 _ptr(image), _ptr(depth), _ptr(weights)))
+        return image, depth, weights
+
+    def sample_fine(self, t_coarse, w_coarse, u=None, seed=0, stream_id=0, ray_offset=0):
+        t_coarse, w_coarse = self.f32(t_coarse), self.f32(w_coarse)
+        u = None if u is None else self.f32(u)
+        R = t_coarse.shape[0]
+        out = torch.empty((R, self.n_coarse + self.n_fine), device=self.device)
+        self._check(self.lib.knerf_sample_fine(self._ctx, self._stream(), _ptr(t_coarse), _ptr(w_coarse), _ptr(u), seed,
+                                               stream_id, ray_offset, R, _ptr(out)))
+        return out
+
+    def render_chunk(self, o, d, t, u=None, seed=0, ray_offset=0, out=None):
+        """out: optional dict of preallocated [R,...] tensors (c_image, c_depth, c_weights, f_image, f_depth, f_weights,
+        t_fine); only the two images are mandatory"""
+        o, d, t = self.f32(o), self.f32(d), self.f32(t)
+        u = None if u is None else self.f32(u)
+        R = t.shape[0]
+        Na = self.n_coarse + self.n_fine
+        if out is None:
+            def e(*s):
+                return torch.empty(s, device=self.device)
+            out = dict(c_image=e(R, 3), c_depth=e(R), c_weights=e(R, self.n_coarse), f_image=e(R, 3), f_depth=e(R),
+                       f_weights=e(R, Na), t_fine=e(R, Na))
+        self._check(self.lib.knerf_render_chunk(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(u), seed,
+                                                ray_offset, R, _ptr(out["c_image"]), _ptr(out.get("c_depth")),
+                                                _ptr(out.get("c_weights")), _ptr(out["f_image"]), _ptr(out.get("f_depth")),
+                                                _ptr(out.get("f_weights")), _ptr(out.get("t_fine"))))
+        return out
+
+    # ---- training
+    def train_chunk(self, o, d, t, target, u=None, seed=0, ray_offset=0, inv_chunks=1.0, loss=None, c_image=None,
+                    f_image=None):
+        o, d, t, target = self.f32(o), self.f32(d), self.f32(t), self.f32(target)
+        u = None if u is None else self.f32(u)
+        self._check(self.lib.knerf_train_chunk(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(target), _ptr(u),
+                                               seed, ray_offset, t.shape[0], float(inv_chunks), _ptr(loss), _ptr(c_image),
+                                               _ptr(f_image)))
+
+    def apply_adam(self):
+        self._check(self.lib.knerf_apply_adam(self._ctx, self._stream()))
+
+    def zero_grads(self):
+        self._check(self.lib.knerf_zero_grads(self._ctx, self._stream()))
+
+    @property
+    def step(self) -> int:
+        return int(self.lib.knerf_step_count(self._ctx))
+
+    @step.setter
+    def step(self, v: int):
+        self._check(self.lib.knerf_set_step_count(self._ctx, int(v)))
+
+    def generate_rays(self, c2w, focal, height, width, near, far, n_samples, noise=None, seed=0, stream_id=0):
+        c2w = self.f32(c2w).reshape(-1, 4, 4)
+        B = c2w.shape[0]
+        noise = None if noise is None else self.f32(noise)
+        o = torch.empty((B, height, width, 3), device=self.device); d = torch.empty_like(o)
+        t = torch.empty((B, height, width, n_samples), device=self.device)
+        self._check(self.lib.knerf_generate_rays(self._ctx, self._stream(), _ptr(c2w), _ptr(noise), seed, stream_id, B, height,
+                                                 width, n_samples, float(focal), float(near), float(far), _ptr(o), _ptr(d),
+                                                 _ptr(t)))
+        return o, d, t
+
+    def debug_buffer(self, which: int) -> torch.Tensor:
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.knerf_debug_buffer(self._ctx, 0, which, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_CudaView(p.value, n.value, "|u1"), device=self.device)

@@ -198,10 +198,16 @@ def render_backward(cache, dimage):
 
 
 def cdf_from_weights(weights):
-    """utils.py:63-69: w += 1e-5; pdf = w / sum(w); cdf = [0, cumsum(pdf)]  (width S+1)."""
+    """utils.py:63-69: w += 1e-5; pdf = w / sum(w); cdf = [0, cumsum(pdf)]  (width S+1).
+
+    Both sums run left to right (np.cumsum order).  TensorFlow's own summation order (Eigen packets on CPU, a
+    parallel scan on GPU) is not written in the reference; the searchsorted / `denom < 1e-5` decisions downstream
+    depend on the last bits, so the order is part of the oracle's DECLARED semantics and the HIP sampler follows it
+    bit for bit."""
     dt = weights.dtype.type
     w = weights + dt(1e-5)
-    pdf = w / np.sum(w, axis=-1, keepdims=True)
+    total = np.cumsum(w, axis=-1, dtype=weights.dtype)[..., -1:]
+    pdf = w / total
     cdf = np.cumsum(pdf, axis=-1, dtype=weights.dtype)
     return np.concatenate([np.zeros_like(cdf[..., :1]), cdf], axis=-1)
 

@@ -94,3 +94,131 @@ def forward_chain(fwd_tab, bias_tab, flat, p, d):
     z = raw[0][:32, :3]
     rgb = 1.0 / (1.0 + np.exp(-z))
     return rgb, sigma, dict(enc=enc, dirc=dirc, h=act, feat=feat, f2=f2, masks=masks)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward: dgrad chain + saved blocks + wgrad (transposed LDS reads), mirroring mlp_bwd.hip / wgrad.hip
+# ---------------------------------------------------------------------------------------------------------------
+BWD_STAGES = [(0, 1, 4), (4, 8, 8), (68, 17, 8)] + [(204 + 128 * i, 16, 8) for i in range(7)]
+ACT_H = lambda l: 16 * l if l <= 4 else 84 + 16 * (l - 5)
+K_ACT_ENC, K_ACT_H7, K_ACT_FEAT, K_ACT_DIR, K_ACT_F2, K_ACT_BLOCKS = 80, 116, 132, 148, 150, 158
+K_DZ_FEAT, K_DZ_SIG, K_DZ_F2, K_DZ_RGB, K_DZ_BLOCKS = 128, 144, 146, 154, 156
+
+
+def saved_block_image(frag, blk):
+    """[64,8] B-operand fragment -> 512 bf16 in memory order (layout.h saved_off)"""
+    img = np.zeros(512, np.float32)
+    for l in range(64):
+        s, h = l & 31, l >> 5
+        off = (2 * (s ^ ((blk & 1) << 2)) + h) * 16
+        img[off // 2: off // 2 + 8] = frag[l]
+    return img
+
+
+def act_run(saved):
+    """forward_chain's saved dict -> [158*512] memory image of one tile's act run"""
+    run = np.zeros(K_ACT_BLOCKS * 512, np.float32)
+
+    def put(b0, frags):
+        for i, f in enumerate(frags):
+            run[(b0 + i) * 512:(b0 + i + 1) * 512] = saved_block_image(f, b0 + i)
+    for l in range(8):
+        put(ACT_H(l), saved["h"][l])
+    put(K_ACT_ENC, saved["enc"]); put(K_ACT_DIR, saved["dirc"]); put(K_ACT_FEAT, saved["feat"]); put(K_ACT_F2, saved["f2"])
+    return run
+
+
+def backward_chain(bwd_tab, flat, rgb, sigma, drgb, dsigma, masks):
+    """Mirror of mlp_bwd_kernel for one wave.  Returns the dz run memory image [156*512]."""
+    frags = gather_blocks(bwd_tab, flat)
+    run = np.zeros(K_DZ_BLOCKS * 512, np.float32)
+
+    def put(b0, fr):
+        for i, f in enumerate(fr):
+            run[(b0 + i) * 512:(b0 + i + 1) * 512] = saved_block_image(f, b0 + i)
+    zrgb = np.zeros((64, 8), np.float32); zsig = np.zeros((64, 8), np.float32)
+    zrgb[:32, :3] = drgb * rgb * (1 - rgb)
+    zsig[:32, 0] = np.where(sigma > 0, dsigma, 0)
+    zrgb, zsig = round_bf16(zrgb), round_bf16(zsig)
+    put(K_DZ_RGB, [zrgb]); put(K_DZ_SIG, [zsig])
+
+    def stage(st, inputs, mask=None):
+        b0, nks, n_ot = BWD_STAGES[st]
+        outs = []
+        for ot in range(n_ot):
+            acc = np.zeros((64, 16), np.float32)
+            for ks in range(nks):
+                acc = mfma(frags[b0 + ot * nks + ks], inputs[ks], acc)
+            if mask is not None:
+                acc = np.where(mask[ot], acc, 0)
+            lo, hi = pack_acc(acc)
+            outs += [lo, hi]
+        return outs
+    df2 = stage(0, [zrgb]); put(K_DZ_F2, df2)
+    dfeat = stage(1, df2); put(K_DZ_FEAT, dfeat)
+    dz = stage(2, dfeat + [zsig], masks[7]); put(16 * 7, dz)
+    for st in range(3, 10):
+        layer = 6 - (st - 3)
+        dz = stage(st, dz, masks[layer]); put(16 * layer, dz)
+    return run
+
+
+def tr_read(img, addr):
+    """ds_read_b64_tr_b16 (pinned on hardware by tests/test_gpu_probe.py): img = fp32 view of a bf16 LDS image
+    indexed by element, addr [64] byte offsets -> [64,4]"""
+    out = np.zeros((64, 4), np.float32)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for q in range(4):
+            src = 16 * g + 4 * q + (i >> 2)
+            out[l, q] = img[addr[src] // 2 + (i & 3)]
+    return out
+
+
+def tr_frag(region, pair, kk):
+    lane_off = np.zeros((2, 64), np.int64)
+    for l in range(64):
+        grp, il = l >> 4, l & 15
+        par, h, q, p = grp & 1, grp >> 1, il >> 2, il & 3
+        for r in range(2):
+            lane_off[r, l] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8
+    base = pair * 2048 + kk * 512
+    return np.concatenate([tr_read(region, base + lane_off[0]), tr_read(region, base + lane_off[1])], axis=1)
+
+
+WGRAD_JOBS = {0: (K_ACT_ENC, 2, 0, 8), 5: (64, 10, 80, 8), 8: (K_ACT_H7, 8, K_DZ_FEAT, 8), 9: (K_ACT_H7, 8, K_DZ_SIG, 1),
+              10: (K_ACT_FEAT, 9, K_DZ_F2, 4), 11: (K_ACT_F2, 4, K_DZ_RGB, 1)}
+for _j in (1, 2, 3, 4, 6, 7):
+    WGRAD_JOBS[_j] = (ACT_H(_j - 1), 8, 16 * _j, 8)
+
+
+def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params):
+    """Mirror of wgrad_kernel over a list of tiles: returns the flat gradient."""
+    grad = np.zeros(n_params, np.float64)
+    ones = np.ones((64, 8), np.float32)
+    for jb, (ab, n_it, db, n_ot) in WGRAD_JOBS.items():
+        dst = dst_tab[job_off[jb]:job_off[jb + 1]].reshape(n_it * 32 + 1, n_ot * 32)
+        acc = {(it, ot): np.zeros((64, 16), np.float32) for it in range(n_it + 1) for ot in range(n_ot)}
+        for act, dz in zip(act_runs, dz_runs):
+            in_reg = act[ab * 512:(ab + 2 * n_it) * 512]
+            dz_reg = dz[db * 512:(db + 2 * n_ot) * 512]
+            for kk in range(2):
+                for ot in range(n_ot):
+                    b = tr_frag(dz_reg, ot, kk)
+                    for it in range(n_it + 1):
+                        a = tr_frag(in_reg, it, kk) if it < n_it else ones
+                        acc[(it, ot)] = mfma(a, b, acc[(it, ot)])
+        for (it, ot), A in acc.items():
+            for l in range(64):
+                c, hh = l & 31, l >> 5
+                if it < n_it:
+                    for i in range(16):
+                        row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh
+                        d = dst[row, 32 * ot + c]
+                        if d >= 0:
+                            grad[d] += A[l, i]
+                elif hh == 0:
+                    d = dst[n_it * 32, 32 * ot + c]
+                    if d >= 0:
+                        grad[d] += A[l, 0]
+    return grad.astype(np.float32)

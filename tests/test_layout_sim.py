@@ -49,3 +49,36 @@ def test_forward_chain_matches_oracle(setup):
     np.testing.assert_allclose(sigma, sigma_o[0, :, 0], atol=1e-3, rtol=1e-2)
     rgb32, sigma32 = O.mlp_forward(params, xyz, dire, cfg)
     assert np.abs(rgb - rgb32[0]).max() < 2e-2          # bf16 operands vs fp32: the kernel's stated tolerance class
+
+
+def test_backward_chain_and_wgrad_match_oracle(setup):
+    """dgrad stream table, saved-block swizzle, transposed-read addressing and the wgrad destination tables, replayed
+    on the CPU for two sample tiles, reproduce the oracle's 24 gradient tensors (bf16-emulating mode)."""
+    cfg, params, flat, p, d = setup
+    fwd, bias, bwd = _lib.debug_table(0), _lib.debug_table(1), _lib.debug_table(2)
+    dst_tab, job_off = _lib.debug_table(3), _lib.debug_table(4)
+    rng = np.random.default_rng(8)
+    acts, dzs, xs, ds, drgbs, dsigs = [], [], [], [], [], []
+    for tile in range(2):
+        pt = (p + rng.normal(0, 0.3, p.shape)).astype(np.float32)
+        rgb, sigma, saved = M.forward_chain(fwd, bias, flat, pt, d)
+        drgb = rng.normal(0, 1, (32, 3)).astype(np.float32)
+        dsig = rng.normal(0, 1, (32,)).astype(np.float32)
+        acts.append(M.act_run(saved))
+        dzs.append(M.backward_chain(bwd, flat, rgb, sigma, drgb, dsig, saved["masks"]))
+        xs.append(pt); ds.append(d); drgbs.append(drgb); dsigs.append(dsig)
+    grad = M.wgrad(acts, dzs, dst_tab, job_off, flat.size)
+    xyz = O.positional_encoding(np.concatenate(xs), 10)[None]
+    dire = O.positional_encoding(np.concatenate(ds), 4)[None]
+    _, _, cache = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=True, want_cache=True)
+    g_o = O.flatten_params(O.mlp_backward(params, cache, np.concatenate(drgbs), np.concatenate(dsigs), cfg))
+    scale = np.abs(g_o).max()
+    err = np.abs(grad - g_o).max() / scale
+    assert err < 2e-2, err
+    # per tensor, so that a mis-routed small tensor (biases, sigma, rgb heads) cannot hide behind a large one
+    off = 0
+    for name, fi, fo in O.layer_shapes(cfg):
+        for n in (fi * fo, fo):
+            a, b = grad[off:off + n], g_o[off:off + n]
+            assert np.abs(a - b).max() <= 3e-2 * max(np.abs(b).max(), 1e-6), (name, n)
+            off += n
