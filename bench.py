@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- NeRF train-step throughput on MI355X, in BASELINE.json's metric (rays*samples/s).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full NeRF.train_step (reference keras_nerf/model/nerf/nerf.py:332-473) on one synthetic batch that is
+already resident in HBM: chunk loop (coarse fwd+bwd, inverse-CDF sampling, fine fwd+bwd, gradient accumulation), the
+data-parallel all-reduce(SUM) of the accumulated gradients when N > 1, both Adam updates and the bf16 weight re-pack.
+PSNR/SSIM bookkeeping is excluded.  Per-GPU work is fixed as N grows ("weak" scaling, the
+reference's train.py semantics: global batch = batch_size x replicas).
+
+One JSON line is printed by rank 0; see the task contract for the fields.  `roofline` is measured live with HIP events
+around the dominant kernel (knerf_profile_*), `cpu_baseline` times the op-for-op torch-CPU restatement of the reference
+path (oracle/torch_ref.py, kind "port") on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_FLOP = 2 * 593408                      # per ray*sample, SURVEY.md section 2.2 / 8d
+DGRAD_FLOP = 2 * (128 * 3 + 256 * 128 + 256 * 257 + 7 * 256 * 256)
+WGRAD_FLOP = 2 * 593408
+TRAIN_FLOP = 3 * FWD_FLOP                  # the 3x-forward figure
+MFMA_PEAK_TFLOPS = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    # name: (img_wh, batch per GPU, ray_chunks, description)
+    "cfg2": (128, 2, 4096, "lego-shaped 128x128, batch 2 per GPU, ray_chunks 4096, coarse64+fine128"),
+    "cfg3": (400, 1, 16000, "400x400, batch 1, ray_chunks 16000 (16384 does not divide 160000), coarse64+fine128"),
+    "cfg4": (128, 1, 4096, "chair-shaped 128x128, 1 image per GPU, ray_chunks 4096, coarse64+fine128"),
+}
+
+
+def make_batch(nerf, wh, batch, rank, seed=42):
+    """Synthetic nerf_synthetic-shaped batch generated on the device: pose_spherical poses,
+    fov 0.6911112070083618, jittered coarse t, uniform random targets."""
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    focal = get_focal_from_fov(0.6911112070083618, wh)
+    poses = np.stack([pose_spherical(360.0 * (rank * batch + i) / 97.0, -30.0, 4.0) for i in range(batch)])
+    o, d, t = nerf._ctx.generate_rays(poses, focal, wh, wh, 2.0, 6.0, nerf.n_coarse, None, seed=seed, stream_id=rank)
+    g = torch.Generator(device="cuda"); g.manual_seed(seed + rank)
+    images = torch.rand((batch, wh, wh, 3), device="cuda", generator=g)
+    return images, (o, d, t)
+
+
+def cpu_baseline(n_rays=1024, chunk=512, repeats=3):
+    """op-for-op torch-CPU restatement of the reference train step (oracle/torch_ref.py) on a bounded sample"""
+    from oracle import nerf_oracle as O
+    from oracle import torch_ref as T
+    cfg = O.NerfConfig()
+    rng = np.random.default_rng(42)
+    wh = 32
+    c2w = O.pose_spherical(20.0, -30.0, 4.0)
+    o, d, t = O.generate_rays(c2w, O.get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, 64, rng.random((wh, wh, 64)))
+    o, d, t = [torch.tensor(a.reshape(wh * wh, -1)[:n_rays]) for a in (o, d, t)]
+    img = torch.tensor(rng.random((n_rays, 3), dtype=np.float32))
+    u = torch.tensor(np.random.default_rng(7).random((n_rays, 128), dtype=np.float32))
+    cp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 0)]
+    fp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 1)]
+    oc, of_ = T.TorchKerasAdam(cp), T.TorchKerasAdam(fp)
+    times = []
+    for i in range(repeats + 1):
+        t0 = time.perf_counter()
+        T.train_step(cp, fp, oc, of_, img, o, d, t, u, cfg, chunk, False)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times[1:])
+    return {"value": n_rays * 256 / med, "unit": "rays*samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays} rays x 256 samples, ray_chunks {chunk}, coarse64+fine128 train step, median of {repeats} "
+                      f"after 1 warm-up; torch-CPU fp32 restatement of the reference's TF-CPU path ({os.cpu_count()} host cpus)",
+            "s_per_step": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    wh, batch, chunks, desc = CONFIGS[args.config]
+    nerf = NeRF(seed=0)
+    nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
+                 white_background=True)
+    data = make_batch(nerf, wh, batch, rank)
+    n_rays = batch * wh * wh
+    samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        nerf.train_step(data, with_metrics=False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nerf.train_step(data, with_metrics=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    value = world * n_rays * samples_per_ray * args.steps / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_profile:
+        nerf._ctx.profile_enable(True)
+        nerf._ctx.profile_read()
+        for _ in range(2):
+            nerf.train_step(data, with_metrics=False)
+        prof = nerf._ctx.profile_read()
+        nerf._ctx.profile_enable(False)
+        total = sum(ms for ms, _ in prof.values())
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, cnt = prof[dom]
+        avg_ms = ms / max(cnt, 1)
+        s_fine, s_coarse = chunks * (nerf.n_coarse + nerf.n_fine), chunks * nerf.n_coarse
+        per_launch_samples = s_coarse if dom.endswith("coarse") else s_fine
+        flop = {"mlp_fwd": FWD_FLOP, "mlp_bwd": DGRAD_FLOP, "wgrad": WGRAD_FLOP}.get(dom.rsplit("_", 1)[0], 0) * per_launch_samples
+        # wgrad streams the saved activations and dZ once: (158 + 156) KiB per 32-sample tile + re-read of enc/h7
+        if dom.startswith("wgrad"):
+            byts = per_launch_samples / 32 * 334 * 1024
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": byts / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
+        else:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": flop / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flop / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None}
+        roofline["avg_launch_ms"] = avg_ms
+        roofline["launches"] = cnt
+        roofline["kernel_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof.items()}
+        roofline["step_train_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP / (elapsed / args.steps) / 1e12
+        roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "rays*samples/sec (train step), lego 128^2 coarse64+fine128" if args.config == "cfg2"
+                      else f"rays*samples/sec (train step), {args.config}",
+            "value": value, "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
+                       "parallelism": f"dp{world}", "global_batch_images": batch * world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

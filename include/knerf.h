@@ -93,10 +93,29 @@ int knerf_step_count(const knerf_ctx* ctx);
 int knerf_set_step_count(knerf_ctx* ctx, int step);
 
 /* RaysGenerator.__call__ (keras_nerf/data/rays.py:69-130) on device: c2w [B,4,4], noise [B,H,W,N] in [0,1) or
- * NULL for Philox; writes o,d [B,H,W,3] and t [B,H,W,N]. */
+ * NULL for Philox; writes o,d [B,H,W,3] and t [B,H,W,N].  ctx may be NULL (stand-alone op). */
 int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const float* noise, uint64_t seed,
                         uint64_t stream_id, int batch, int height, int width, int n_samples, float focal,
                         float near_plane, float far_plane, float* o, float* d, float* t);
+
+/* ---- NeRFUtils as stand-alone ops (no context needed; the train/render path fuses the same arithmetic) ----
+ * positional_encoding (utils.py:176-186): x [n_rows,3] -> out [n_rows, 3+6L].
+ * composite = render_image_depth_chunk (utils.py:16-58): raw [R,S,4] = (r,g,b,sigma), t [R,S] -> image [R,3], depth [R]
+ *   or NULL, weights [R,S] or NULL.
+ * inverse_cdf = fine_hierarchical_sampling_chunk (utils.py:60-97) with u injected: mid_points [R,n_mid],
+ *   weights [R,n_weights], u [R,n_samples] -> out [R,n_samples] (unsorted). */
+int knerf_positional_encoding(void* stream, const float* x, long long n_rows, int L, float* out);
+int knerf_composite(void* stream, const float* raw, const float* t, int n_rays, int n_samples, int white_background,
+                    float* image, float* depth, float* weights);
+int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weights, const float* u, int n_rays, int n_mid,
+                      int n_weights, int n_samples, int oob_clamp, float* out);
+
+/* Per-kernel timing with HIP events recorded on the caller's stream around every launch (bench.py's roofline leg).
+ * Classes: 0 mlp_fwd coarse, 1 mlp_fwd fine, 2 composite, 3 sample_fine, 4 mlp_bwd coarse, 5 mlp_bwd fine,
+ * 6 wgrad coarse, 7 wgrad fine, 8 adam+repack.  read() synchronises the device, returns summed milliseconds and launch
+ * counts since enable/the previous read (n >= 9). */
+int knerf_profile_enable(knerf_ctx* ctx, int on);
+int knerf_profile_read(knerf_ctx* ctx, double* total_ms, int64_t* launches, int n);
 
 /* ---- introspection used by the CPU-side layout tests (no device work) ---- */
 /* kind 0: forward A-fragment table, 1: forward bias table, 2: dgrad A-fragment table, 3: wgrad destination table.

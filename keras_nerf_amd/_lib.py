@@ -42,6 +42,11 @@ SIGNATURES = {
     "knerf_set_step_count": (C.c_int, [_P, C.c_int]),
     "knerf_generate_rays": (C.c_int, [_P, _P, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_float, C.c_float, _F, _F, _F]),
+    "knerf_positional_encoding": (C.c_int, [_P, _F, C.c_longlong, C.c_int, _F]),
+    "knerf_composite": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F, _F]),
+    "knerf_inverse_cdf": (C.c_int, [_P, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "knerf_profile_enable": (C.c_int, [_P, C.c_int]),
+    "knerf_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "knerf_debug_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "knerf_debug_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "knerf_debug_probe": (C.c_int, [C.c_int, _P, _P, _P, _P]),
@@ -61,6 +66,9 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise KnerfError(f"{LIB_PATH} is missing: run `python keras_nerf_amd/build.py` (hipcc, gfx950). "
                              "keras_nerf_amd has no CPU path.")
+        # torch first: its bundled HIP runtime must be the one already mapped when libknerf_hip.so resolves
+        # libamdhip64, otherwise two runtimes coexist and the second one sees no device / foreign pointers
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

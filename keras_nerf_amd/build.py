@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libknerf_hip.so")
 SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "composite.hip", "sampler.hip", "optim.hip",
-           "raygen.hip", "probe.hip"]
+           "raygen.hip", "probe.hip", "utils_ops.hip"]
 HEADERS = ["chain.h", "kernels.h", "layout.h", os.path.join("..", "..", "include", "knerf.h")]
 # -ffp-contract=off: the parity-critical fp32 arithmetic (ray points, sampler, compositing) must round like the
 # reference's separate mul/add ops; fused multiply-adds are written explicitly (__builtin_fmaf) where wanted.

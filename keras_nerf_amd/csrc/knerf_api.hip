@@ -62,6 +62,10 @@ struct knerf_ctx {
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
     char *act = nullptr, *mask = nullptr, *dz = nullptr;
     size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
+    // optional per-kernel timing with HIP events on the caller's stream (knerf_profile_*)
+    bool prof_on = false;
+    struct ProfRec { int id; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -144,6 +148,21 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
     return KNERF_OK;
 }
 
+// kernel classes reported by knerf_profile_read
+enum ProfId { P_FWD_C = 0, P_FWD_F, P_COMPOSITE, P_SAMPLE, P_BWD_C, P_BWD_F, P_WGRAD_C, P_WGRAD_F, P_ADAM, P_COUNT };
+
+struct ProfScope {
+    knerf_ctx* c; hipStream_t s; int idx = -1;
+    ProfScope(knerf_ctx* ctx, hipStream_t st, int id) : c(ctx), s(st) {
+        if (!c->prof_on) return;
+        knerf_ctx::ProfRec r{id, nullptr, nullptr};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, s);
+        c->prof.push_back(r); idx = (int)c->prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, s); }
+};
+
 int check_net(knerf_ctx* ctx, int net) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (net != KNERF_COARSE && net != KNERF_FINE) return fail(ctx, KNERF_ERR_INVALID, "net must be 0 (coarse) or 1 (fine)");
@@ -158,24 +177,24 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
     fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw; fa.act = ctx->act; fa.mask = ctx->mask;
     fa.n_samples = (long long)R * S; fa.S = S;
-    HIPCHK(launch_mlp_fwd(fa, train, s));
+    { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F); HIPCHK(launch_mlp_fwd(fa, train, s)); }
     CompositeArgs ca{};
     ca.raw = ctx->raw; ca.t = t; ca.target = target; ca.image = image; ca.depth = depth; ca.weights = weights;
     ca.draw = train ? ctx->draw : nullptr; ca.loss = loss; ca.R = R; ca.S = S; ca.white = ctx->cfg.white_background;
     ca.grad_scale = 2.0f / (3.0f * (float)R) * inv_chunks;
     ca.loss_scale = inv_chunks / (3.0f * (float)R);
-    HIPCHK(launch_composite(ca, s));
+    { ProfScope ps(ctx, s, P_COMPOSITE); HIPCHK(launch_composite(ca, s)); }
     if (train) {
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
         ba.n_samples = fa.n_samples;
-        HIPCHK(launch_mlp_bwd(ba, s));
+        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
         wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
-        HIPCHK(launch_wgrad(wa, s));
+        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F); HIPCHK(launch_wgrad(wa, s)); }
     }
     return KNERF_OK;
 }
@@ -346,7 +365,7 @@ int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const
     sa.t_coarse = t_coarse; sa.w_coarse = w_coarse; sa.u = u; sa.t_out = t_out; sa.R = n_rays;
     sa.Nc = ctx->cfg.n_coarse; sa.Nf = ctx->cfg.n_fine; sa.oob_clamp = ctx->cfg.oob_clamp;
     sa.seed = seed; sa.stream_id = stream_id; sa.ray_offset = ray_offset;
-    HIPCHK(launch_sample_fine(sa, (hipStream_t)stream));
+    { ProfScope ps(ctx, (hipStream_t)stream, P_SAMPLE); HIPCHK(launch_sample_fine(sa, (hipStream_t)stream)); }
     return KNERF_OK;
 }
 
@@ -394,6 +413,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     ctx->step += 1;
     const double b1 = ctx->cfg.beta1, b2 = ctx->cfg.beta2;
     const float lr_t = (float)((double)ctx->cfg.lr * std::sqrt(1.0 - std::pow(b2, ctx->step)) / (1.0 - std::pow(b1, ctx->step)));
+    ProfScope ps(ctx, s, P_ADAM);
     for (int n = 0; n < 2; ++n) {
         AdamArgs a{};
         a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = kParamCount;
@@ -420,13 +440,32 @@ int knerf_set_step_count(knerf_ctx* ctx, int step) {
 int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const float* noise, uint64_t seed, uint64_t stream_id,
                         int batch, int height, int width, int n_samples, float focal, float near_plane, float far_plane,
                         float* o, float* d, float* t) {
-    if (!ctx) return KNERF_ERR_INVALID;
     if (!c2w || !o || !d || !t || batch <= 0 || height <= 0 || width <= 0 || n_samples <= 0)
         return fail(ctx, KNERF_ERR_INVALID, "generate_rays: null/empty argument");
     RayGenArgs a{};
     a.c2w = c2w; a.noise = noise; a.o = o; a.d = d; a.t = t; a.B = batch; a.H = height; a.W = width; a.N = n_samples;
     a.focal = focal; a.near_ = near_plane; a.far_ = far_plane; a.seed = seed; a.stream_id = stream_id;
-    HIPCHK(launch_raygen(a, (hipStream_t)stream));
+    if (launch_raygen(a, (hipStream_t)stream) != hipSuccess) return fail(ctx, KNERF_ERR_HIP, "generate_rays: launch failed");
+    return KNERF_OK;
+}
+
+int knerf_profile_enable(knerf_ctx* ctx, int on) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    ctx->prof_on = on != 0;
+    return KNERF_OK;
+}
+
+int knerf_profile_read(knerf_ctx* ctx, double* total_ms, int64_t* launches, int n) {
+    if (!ctx || !total_ms || !launches || n < P_COUNT) return KNERF_ERR_INVALID;
+    for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& r : ctx->prof) {
+        float ms = 0.f;
+        if (r.e0 && r.e1 && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { total_ms[r.id] += ms; launches[r.id] += 1; }
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    ctx->prof.clear();
     return KNERF_OK;
 }
 

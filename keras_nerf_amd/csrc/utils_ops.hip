@@ -1,0 +1,87 @@
+// utils_ops.hip -- the NeRFUtils methods as stand-alone device ops (gfx950), for callers that use the reference's
+// utility class directly (reference keras_nerf/model/nerf/utils.py).  The train/render path does not use these: there
+// the same arithmetic is fused into mlp_fwd.hip / sampler.hip.
+#include <hip/hip_runtime.h>
+#include "../../include/knerf.h"
+#include "kernels.h"
+
+namespace knerf {
+
+// NeRFUtils.positional_encoding (utils.py:176-186): [n,3] -> [n, 3+6L] = [x, sin(2^0 x), cos(2^0 x), ...]
+__global__ void posenc_kernel(const float* x, float* out, long long n, int L) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = 3 + 6 * L;
+    if (i >= n * width) return;
+    const long long row = i / width;
+    const int f = (int)(i % width);
+    if (f < 3) { out[i] = x[row * 3 + f]; return; }
+    const int k = (f - 3) / 6, r = (f - 3) % 6, c = r % 3;
+    const float a = __fmul_rn((float)(1 << k), x[row * 3 + c]);
+    out[i] = r < 3 ? sinf(a) : cosf(a);
+}
+
+// NeRFUtils.fine_hierarchical_sampling_chunk (utils.py:60-97) on caller-provided mid-points: unsorted samples.
+// One thread per ray builds the cdf (left to right, like sampler.hip); Nw <= 256 weights, M mid-points.
+__global__ void inverse_cdf_kernel(const float* mids, const float* w, const float* u, float* out, int R, int M, int Nw, int Nf,
+                                   int oob_clamp) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= R) return;
+    float* cdf = sm + wv * (Nw + 1);
+    const float* wr = w + (size_t)ray * Nw;
+    float tot = 0.f;
+    for (int i = 0; i < Nw; ++i) tot = __fadd_rn(tot, __fadd_rn(wr[i], 1e-5f));
+    float acc = 0.f;
+    for (int i = 0; i < Nw; ++i) {
+        acc = __fadd_rn(acc, __fdiv_rn(__fadd_rn(wr[i], 1e-5f), tot));
+        if (lane == 0) cdf[i + 1] = acc;
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const float* mr = mids + (size_t)ray * M;
+    for (int j = lane; j < Nf; j += 64) {
+        const float uu = u[(size_t)ray * Nf + j];
+        int lo = 0, hi = Nw + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+        const int below = max(0, lo - 1), above = min(Nw, lo);
+        const float cb = cdf[below], ca = cdf[above];
+        float mb, ma;
+        if (oob_clamp) { mb = mr[min(below, M - 1)]; ma = mr[min(above, M - 1)]; }
+        else { mb = below < M ? mr[below] : 0.f; ma = above < M ? mr[above] : 0.f; }
+        float denom = __fsub_rn(ca, cb);
+        if (denom < 1e-5f) denom = 1.f;
+        const float q = __fdiv_rn(__fsub_rn(uu, cb), denom);
+        out[(size_t)ray * Nf + j] = __fadd_rn(mb, __fmul_rn(q, __fsub_rn(ma, mb)));
+    }
+}
+
+}  // namespace knerf
+
+using namespace knerf;
+
+extern "C" int knerf_positional_encoding(void* stream, const float* x, long long n_rows, int L, float* out) {
+    if (!x || !out || n_rows <= 0 || L < 0 || L > 30) return KNERF_ERR_INVALID;
+    const long long total = n_rows * (3 + 6 * L);
+    hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n_rows, L);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
+
+extern "C" int knerf_composite(void* stream, const float* raw, const float* t, int n_rays, int n_samples, int white_background,
+                               float* image, float* depth, float* weights) {
+    if (!raw || !t || !image || n_rays <= 0 || n_samples <= 0) return KNERF_ERR_INVALID;
+    CompositeArgs ca{};
+    ca.raw = raw; ca.t = t; ca.image = image; ca.depth = depth; ca.weights = weights; ca.R = n_rays; ca.S = n_samples;
+    ca.white = white_background;
+    return launch_composite(ca, (hipStream_t)stream) == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
+
+extern "C" int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weights, const float* u, int n_rays,
+                                 int n_mid, int n_weights, int n_samples, int oob_clamp, float* out) {
+    if (!mid_points || !weights || !u || !out || n_rays <= 0 || n_mid < 1 || n_weights < 1 || n_weights > 4096 || n_samples < 1)
+        return KNERF_ERR_INVALID;
+    const size_t lds = 4 * (size_t)(n_weights + 1) * sizeof(float);
+    hipLaunchKernelGGL(inverse_cdf_kernel, dim3((n_rays + 3) / 4), dim3(256), lds, (hipStream_t)stream, mid_points, weights, u,
+                       out, n_rays, n_mid, n_weights, n_samples, oob_clamp);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}

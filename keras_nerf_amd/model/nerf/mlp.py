@@ -1,0 +1,156 @@
+"""NeRFMLP -- counterpart of reference keras_nerf/model/nerf/mlp.py:4-59.
+
+Holds the 24 trainable tensors of one MLP (Keras order: layer_0..layer_{n-1}, sigma, features, rgb_features, rgb; kernel
+[in,out] then bias) as a flat fp32 vector; the arithmetic lives in the fused HIP kernels (csrc/mlp_fwd.hip).  When the
+owning NeRF is compiled, the master copy is on the GPU and this object is a view onto it."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from ... import _lib
+
+
+def layer_shapes(n_layers: int, dense_units: int, skip_layer: int, xyz_dim: int, dir_dim: int) -> List[Tuple[str, int, int]]:
+    """(name, fan_in, fan_out) in layer-creation order (mlp.py:11-27); the skip concat [h, xyz_enc] follows layer i when
+    i % skip_layer == 0 and i > 0 (mlp.py:36-38)."""
+    shapes, fan_in = [], xyz_dim
+    for i in range(n_layers):
+        shapes.append((f"layer_{i}", fan_in, dense_units))
+        fan_in = dense_units
+        if i % skip_layer == 0 and i > 0:
+            fan_in = dense_units + xyz_dim
+    shapes += [("sigma", fan_in, 1), ("features", fan_in, dense_units),
+               ("rgb_features", dense_units + dir_dim, dense_units // 2), ("rgb", dense_units // 2, 3)]
+    return shapes
+
+
+class NeRFMLP:
+    def __init__(self, n_layers: int = 8, dense_units: int = 256, skip_layer=4, initializer="glorot_uniform", name=None,
+                 xyz_dim: int = 63, dir_dim: int = 27, seed=None, **kwargs):
+        if initializer != "glorot_uniform":
+            raise ValueError("only the reference's initializer 'glorot_uniform' is implemented")
+        self.n_layers, self.dense_units, self.skip_layer = n_layers, dense_units, skip_layer
+        self.name = name or "nerf_mlp"
+        self.xyz_dim, self.dir_dim = xyz_dim, dir_dim
+        self._shapes = layer_shapes(n_layers, dense_units, skip_layer, xyz_dim, dir_dim)
+        self._seed = seed
+        self._host = None          # flat fp32 weights until bound to a device context
+        self._ctx = None
+        self._net = None
+
+    # ---- weights
+    @property
+    def built(self) -> bool:
+        return self._host is not None or self._ctx is not None
+
+    def count_params(self) -> int:
+        return sum(i * o + o for _, i, o in self._shapes)
+
+    def build(self):
+        """glorot_uniform kernels U(+-sqrt(6/(fan_in+fan_out))), zero biases (Keras Dense defaults)."""
+        if self.built:
+            return
+        rng = np.random.default_rng(self._seed)
+        parts = []
+        for _, fi, fo in self._shapes:
+            lim = np.sqrt(6.0 / (fi + fo))
+            parts.append(rng.uniform(-lim, lim, size=fi * fo).astype(np.float32))
+            parts.append(np.zeros(fo, np.float32))
+        self._host = np.concatenate(parts)
+
+    def _bind(self, ctx, net: int):
+        self.build()
+        if self._host is not None:
+            ctx.set_weights(net, self._host)
+        self._ctx, self._net, self._host = ctx, net, None
+
+    def get_flat_weights(self) -> np.ndarray:
+        if self._ctx is not None:
+            return self._ctx.get_weights(self._net)
+        self.build()
+        return self._host.copy()
+
+    def set_flat_weights(self, flat):
+        flat = np.ascontiguousarray(np.asarray(flat, np.float32).reshape(-1))
+        if flat.size != self.count_params():
+            raise ValueError(f"{self.name}: expected {self.count_params()} weights, got {flat.size}")
+        if self._ctx is not None:
+            self._ctx.set_weights(self._net, flat)
+        else:
+            self._host = flat.copy()
+
+    def get_weights(self) -> List[np.ndarray]:
+        """list of 24 arrays, Keras get_weights() order"""
+        flat, out, off = self.get_flat_weights(), [], 0
+        for _, fi, fo in self._shapes:
+            out.append(flat[off:off + fi * fo].reshape(fi, fo)); off += fi * fo
+            out.append(flat[off:off + fo]); off += fo
+        return out
+
+    def set_weights(self, weights):
+        self.set_flat_weights(np.concatenate([np.asarray(w, np.float32).reshape(-1) for w in weights]))
+
+    @property
+    def trainable_variables(self):
+        return self.get_weights()
+
+    # the reference saves Keras HDF5 (nerf.py:63-64); h5py is not a dependency here, so the same tensors go to .npz with
+    # Keras' weight names as keys
+    def save_weights(self, path: str):
+        arrs = {}
+        for (name, _, _), k, b in zip(self._shapes, self.get_weights()[0::2], self.get_weights()[1::2]):
+            arrs[f"{name}/kernel:0"] = k
+            arrs[f"{name}/bias:0"] = b
+        with open(path, "wb") as f:
+            np.savez(f, **arrs)
+
+    def load_weights(self, path: str):
+        z = np.load(path)
+        ws = []
+        for name, fi, fo in self._shapes:
+            k, b = z[f"{name}/kernel:0"], z[f"{name}/bias:0"]
+            if k.shape != (fi, fo) or b.shape != (fo,):
+                raise ValueError(f"{path}: {name} has shape {k.shape}, expected {(fi, fo)}")
+            ws += [k, b]
+        self.set_weights(ws)
+
+    # ---- forward (rgb, sigma) = mlp((xyz_enc, dir_enc)): mlp.py:29-50
+    def __call__(self, inputs):
+        return self.call(inputs)
+
+    def call(self, inputs):
+        """Evaluates the MLP on already encoded inputs [..., xyz_dim] / [..., dir_dim].  The reference's NeRF never
+        calls its MLPs this way outside _build_model (weights creation) and a shape test; the fused kernels start from
+        ray origins/directions instead, so this entry point is served by a plain fp32 torch evaluation of the same
+        layer sequence (bias add, ReLU trunk with skip concat, ReLU sigma, linear features / rgb_features, sigmoid rgb)."""
+        xyz, dire = inputs
+        if not torch.cuda.is_available():
+            from ...runtime import KnerfError
+            raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
+        dev = self._ctx.device if self._ctx is not None else "cuda"
+        xyz = torch.as_tensor(np.asarray(xyz, np.float32) if not isinstance(xyz, torch.Tensor) else xyz).to(dev, torch.float32)
+        dire = torch.as_tensor(np.asarray(dire, np.float32) if not isinstance(dire, torch.Tensor) else dire).to(dev, torch.float32)
+        w = [torch.as_tensor(a).to(dev) for a in self.get_weights()]
+        h, p = xyz, 0
+        for i in range(self.n_layers):
+            h = torch.relu(h @ w[p] + w[p + 1]); p += 2
+            if i % self.skip_layer == 0 and i > 0:
+                h = torch.cat([h, xyz], dim=-1)
+        sigma = torch.relu(h @ w[p] + w[p + 1]); p += 2
+        feat = h @ w[p] + w[p + 1]; p += 2
+        f2 = torch.cat([feat, dire], dim=-1) @ w[p] + w[p + 1]; p += 2
+        rgb = torch.sigmoid(f2 @ w[p] + w[p + 1])
+        return rgb, sigma
+
+    def get_config(self):
+        return {"name": self.name, "n_layers": self.n_layers, "dense_units": self.dense_units, "skip_layer": self.skip_layer}
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{self.name}"')
+        for name, fi, fo in self._shapes:
+            print_fn(f"  {name:<14} Dense  in={fi:<4} out={fo:<4} params={fi * fo + fo}")
+        print_fn(f"Total params: {self.count_params():,}")

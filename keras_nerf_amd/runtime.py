@@ -177,6 +177,19 @@ class KnerfContext:
                                                  _ptr(t)))
         return o, d, t
 
+    PROFILE_CLASSES = ("mlp_fwd_coarse", "mlp_fwd_fine", "composite", "sample_fine", "mlp_bwd_coarse", "mlp_bwd_fine",
+                       "wgrad_coarse", "wgrad_fine", "adam_repack")
+
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.knerf_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self):
+        """{class: (total_ms, launches)} since the last read"""
+        n = len(self.PROFILE_CLASSES)
+        ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+        self._check(self.lib.knerf_profile_read(self._ctx, ms, cnt, n))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
+
     def debug_buffer(self, which: int) -> torch.Tensor:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self.lib.knerf_debug_buffer(self._ctx, 0, which, C.byref(p), C.byref(n)))
