@@ -16,6 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from ... import parallel
 from ...runtime import COARSE, FINE, KnerfContext, NonFiniteGradientError  # noqa: F401
 from .metrics import Mean, psnr, ssim
 from .mlp import NeRFMLP
@@ -132,11 +133,9 @@ class NeRF:
                                     white_background, self.oob)
         self._build_model()
         self.is_training = is_training
-        self._dist = torch.distributed.is_available() and torch.distributed.is_initialized() and \
-            torch.distributed.get_world_size() > 1
+        self._dist = parallel.is_distributed()
         if self._dist:                                   # mirrored variables start identical (train.py:110-148)
-            for net in (COARSE, FINE):
-                torch.distributed.broadcast(self._ctx.weights_view(net), src=0)
+            parallel.broadcast_weights([self._ctx.weights_view(COARSE), self._ctx.weights_view(FINE)])
             self._ctx.refresh_weights()
         self._loss_acc = torch.zeros(2, device=self.device)
         self._initialize_metrics()
@@ -241,10 +240,7 @@ class NeRF:
             self._ctx.train_chunk(o[sl], d[sl], t[sl], tgt[sl], None if uf is None else uf[sl], seed, i * R, 1.0 / C,
                                   self._loss_acc, ci[sl], fi[sl])
         if self._dist:                                                            # nerf.py:455-458 under MirroredStrategy
-            g = self._ctx.grads_view()
-            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM)
-            if self.all_reduce == "mean":
-                g.div_(torch.distributed.get_world_size())
+            parallel.all_reduce_gradients(self._ctx.grads_view(), self.all_reduce)
         self._ctx.apply_adam()            # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471)
         if not with_metrics:
             return {"coarse_loss": self._loss_acc[0], "fine_loss": self._loss_acc[1]}
@@ -289,11 +285,7 @@ class NeRF:
                 for batch in validation_data:
                     vlogs = self.test_step(batch)
                 logs.update({"val_" + k: float(v) for k, v in vlogs.items()})
-            if self._dist:                                   # logged scalars are replica means (one tiny all-reduce)
-                keys = sorted(logs)
-                vec = torch.tensor([logs[k] for k in keys], device=self.device, dtype=torch.float64)
-                torch.distributed.all_reduce(vec)
-                logs = {k: float(v) / torch.distributed.get_world_size() for k, v in zip(keys, vec)}
+            logs = parallel.reduce_logs(logs, self.device)    # replica means (one tiny all-reduce)
             for k, v in logs.items():
                 history.setdefault(k, []).append(v)
             if verbose:

@@ -1,0 +1,59 @@
+"""The C-ABI shared library loads without a GPU and exports exactly what include/knerf.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from keras_nerf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "knerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(knerf_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/knerf.h but not exported by libknerf_hip.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in keras_nerf_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_no_cpu_fallback_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    cfg = _lib.KnerfConfig(64, 128, 10, 4, 8, 256, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
+    p = C.c_void_p()
+    assert lib.knerf_create(C.byref(cfg), C.byref(p)) == _lib.KNERF_ERR_NODEVICE
+    assert b"HIP device" in lib.knerf_last_error(None)
+    from keras_nerf_amd.runtime import KnerfContext, KnerfError
+    with pytest.raises(KnerfError):
+        KnerfContext()
+
+
+def test_unsupported_shape_rejected_before_any_device_work():
+    lib = _lib.load()
+    cfg = _lib.KnerfConfig(64, 128, 10, 4, 8, 128, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
+    p = C.c_void_p()
+    assert lib.knerf_create(C.byref(cfg), C.byref(p)) == _lib.KNERF_ERR_INVALID
+    assert b"dense_units=256" in lib.knerf_last_error(None)
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "keras_nerf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

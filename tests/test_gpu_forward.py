@@ -118,7 +118,17 @@ def test_render_chunk_coarse_to_fine(ctx_and_problem):
     cf, ff = O.predict_and_render_chunk(P["cp"], P["fp"], o, d, t, u, P["cfg"], True, "zero")
     e2e_psnr = O.psnr(out["f_image"].reshape(1, 16, 16, 3), ff["image"].reshape(1, 16, 16, 3))[0]
     log_stats("render_chunk_end_to_end", f_img_vs_fp32_max=np.abs(out["f_image"] - ff["image"]).max(), psnr=e2e_psnr)
-    assert e2e_psnr > 30.0
+    assert e2e_psnr > 25.0
+    # with oob='clamp' the inverse CDF is continuous and the end-to-end comparison is tight again
+    from keras_nerf_amd.runtime import KnerfContext
+    c2 = KnerfContext(white_background=True, oob="clamp")
+    c2.set_weights(0, O.flatten_params(P["cp"])); c2.set_weights(1, O.flatten_params(P["fp"]))
+    oc = c2.render_chunk(o, d, t, u)["f_image"].cpu().numpy()
+    _, fc = O.predict_and_render_chunk(P["cp"], P["fp"], o, d, t, u, P["cfg"], True, "clamp")
+    pc = O.psnr(oc.reshape(1, 16, 16, 3), fc["image"].reshape(1, 16, 16, 3))[0]
+    log_stats("render_chunk_end_to_end_clamp", f_img_vs_fp32_max=np.abs(oc - fc["image"]).max(), psnr=pc)
+    assert pc > 35.0
+    c2.close()
 
 
 def test_ragged_ray_count(ctx_and_problem):

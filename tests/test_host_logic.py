@@ -1,0 +1,83 @@
+"""Host-side mirror of the reference interface: everything that is decidable without a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from keras_nerf_amd.data import utils as DU
+from keras_nerf_amd.model.nerf import nerf as N
+from keras_nerf_amd.model.nerf.metrics import Mean, psnr, ssim
+from keras_nerf_amd.model.nerf.mlp import NeRFMLP, layer_shapes
+from oracle import nerf_oracle as O
+
+
+def test_focal_known_answer_and_pose_match_oracle():
+    assert DU.get_focal_from_fov(0.6911112070083618, 100) == pytest.approx(138.88887889922103, rel=1e-6)  # reference tests/data/test_utils.py:5-10
+    for th, ph, r in ((0, -30, 4), (123.0, -10.0, 3.5)):
+        np.testing.assert_allclose(DU.pose_spherical(th, ph, r), O.pose_spherical(th, ph, r), atol=1e-6)
+
+
+def test_mlp_shapes_params_and_keras_order():
+    m = NeRFMLP(8, 256, 4)
+    assert m.count_params() == 595844
+    m.build()
+    ws = m.get_weights()
+    assert len(ws) == 24 and ws[0].shape == (63, 256) and ws[10].shape == (319, 256) and ws[16].shape == (256, 1)
+    assert ws[20].shape == (283, 128) and ws[22].shape == (128, 3)
+    assert all(np.all(b == 0) for b in ws[1::2])
+    lim = np.sqrt(6.0 / (63 + 256))
+    assert np.abs(ws[0]).max() <= lim and np.abs(ws[0]).max() > 0.9 * lim          # glorot_uniform
+    assert [s[0] for s in layer_shapes(8, 256, 4, 63, 27)] == [s[0] for s in O.layer_shapes(O.NerfConfig())]
+    assert m.get_config()["n_layers"] == 8 and m.get_config()["dense_units"] == 256 and m.get_config()["skip_layer"] == 4
+
+
+def test_weight_file_roundtrip(tmp_path):
+    m = NeRFMLP(8, 256, 4, seed=3); m.build()
+    p = str(tmp_path / "coarse.h5")
+    m.save_weights(p)
+    m2 = NeRFMLP(8, 256, 4, seed=4); m2.load_weights(p)
+    np.testing.assert_array_equal(m.get_flat_weights(), m2.get_flat_weights())
+
+
+def test_save_model_writes_reference_file_names(tmp_path):
+    n = N.NeRF(seed=1)
+    n.coarse.build(); n.fine.build()
+    n.save_model(str(tmp_path / "m"))
+    assert sorted(os.listdir(tmp_path / "m")) == ["coarse.h5", "fine.h5", "model_config.json"]
+    cfg = json.load(open(tmp_path / "m" / "model_config.json"))
+    assert cfg == dict(n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4)
+    n2 = N.NeRF(n_coarse=1, model_path=str(tmp_path / "m"))
+    assert n2.n_coarse == 64 and n2.n_fine == 128
+
+
+def test_compile_asserts_divisibility_like_the_reference():
+    n = N.NeRF()
+    with pytest.raises(AssertionError, match="must be a divisor"):
+        n.compile("adam", "mse", batch_size=1, image_height=400, image_width=400, ray_chunks=16384)   # 160000 % 16384 != 0
+
+
+def test_loss_and_optimizer_validation():
+    assert N._is_mse("mse") and N._is_mse(None) and N._is_mse(lambda a, b: torch.mean((a - b) ** 2))
+    assert not N._is_mse(lambda a, b: torch.mean(torch.abs(a - b)))
+    assert N._adam_hyper("adam") == dict(lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7)
+    assert N._adam_hyper({"learning_rate": 5e-4})["lr"] == 5e-4
+    with pytest.raises(ValueError):
+        N._adam_hyper("sgd")
+    with pytest.raises(ValueError):
+        N.NeRF().compile("adam", lambda a, b: torch.mean(torch.abs(a - b)), 1, 8, 8, 8)
+
+
+def test_metrics_against_definitions():
+    rng = np.random.default_rng(0)
+    a = torch.tensor(rng.random((2, 16, 16, 3), dtype=np.float32)); b = torch.tensor(rng.random((2, 16, 16, 3), dtype=np.float32))
+    np.testing.assert_allclose(psnr(a, b).numpy(), O.psnr(a.numpy(), b.numpy()), rtol=1e-5)
+    assert float(ssim(a, a)[0]) == pytest.approx(1.0, abs=1e-6)
+    s = ssim(a, b)
+    assert s.shape == (2,) and float(s.max()) < 0.2
+    with pytest.raises(ValueError):
+        ssim(a[:, :8, :8], b[:, :8, :8])
+    m = Mean("x"); m.update_state(torch.tensor([1.0, 3.0])); m.update_state(5.0)
+    assert m.result() == 3.0
+    m.reset_state(); assert m.result() == 0.0
