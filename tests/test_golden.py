@@ -1,0 +1,82 @@
+"""Oracle vs the committed golden vectors (tests/golden, made by oracle/make_golden.py) and -- on the GPU -- the HIP path
+vs the full-size golden case."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nerf_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_analytic_vectors():
+    z = np.load(os.path.join(G, "analytic.npz"))
+    assert O.get_focal_from_fov(float(z["focal_fov"][0]), int(z["focal_width"][0])) == pytest.approx(float(z["focal"][0]), rel=1e-6)
+    np.testing.assert_allclose(O.positional_encoding(z["pe_x"][None], 2)[0], z["pe_L2"], atol=1e-15)
+    S = z["slab_weights"].size
+    t = (2.0 + float(z["slab_delta"][0]) * np.arange(S))[None]
+    _, _, w = O.render_image_depth_chunk(np.ones((1, S, 3)), np.full((1, S, 1), float(z["slab_sigma"][0])), t, False)
+    np.testing.assert_allclose(w[0], z["slab_weights"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,dt,tol", [("f32", np.float32, 2e-6), ("f64", np.float64, 1e-12)])
+def test_small_case_regression(tag, dt, tol):
+    z = np.load(os.path.join(G, "small_r16.npz"))
+    cfg = O.NerfConfig(n_coarse=8, n_fine=16, pos_emb_xyz=4, pos_emb_dir=2, n_layers=8, dense_units=32, skip_layer=4)
+    cp = [(p * 3).astype(dt) for p in O.init_params(cfg, 1)]
+    fp = [(p * 3).astype(dt) for p in O.init_params(cfg, 2)]
+    a = [z[k][None].astype(dt) for k in ("o", "d", "t", "u", "img")]
+    for oob in ("zero", "clamp"):
+        c, f = O.predict_and_render_images(cp, fp, a[0], a[1], a[2], a[3], cfg, 8, True, oob)
+        np.testing.assert_allclose(c["image"], z[f"{tag}_{oob}_c_image"], atol=tol)
+        np.testing.assert_allclose(f["image"], z[f"{tag}_{oob}_f_image"], atol=50 * tol)
+        np.testing.assert_allclose(f["t"], z[f"{tag}_{oob}_t_fine"], atol=50 * tol)
+    oc, of_ = O.KerasAdam(cp), O.KerasAdam(fp)
+    for step in range(2):
+        m, _, _, (gc, gf) = O.train_step(cp, fp, oc, of_, a[4], a[0], a[1], a[2], a[3], cfg, 8, True)
+        np.testing.assert_allclose([m["coarse_loss"], m["fine_loss"]], z[f"{tag}_step{step}_losses"], rtol=1e-4 if dt == np.float32 else 1e-10)
+        if step == 0:
+            np.testing.assert_allclose(O.flatten_params(gc), z[f"{tag}_grad_c"], rtol=1e-3 if dt == np.float32 else 1e-8, atol=100 * tol)
+    # fp32 oracle tracks the fp64 oracle
+    np.testing.assert_allclose(z["f32_zero_c_image"], z["f64_zero_c_image"], atol=2e-4)
+    np.testing.assert_allclose(z["f32_step0_losses"], z["f64_step0_losses"], rtol=1e-3)
+
+
+def test_fullsize_oracle_regression():
+    from tests.problem import make_problem
+    z = np.load(os.path.join(G, "fullsize_r64.npz"))
+    P = make_problem(n_images=1, wh=8, seed=42, weight_scale=1.5, bias_std=0.05)
+    np.testing.assert_array_equal(P["o"].reshape(-1, 3), z["o"]); np.testing.assert_array_equal(P["t"].reshape(64, -1), z["t"])
+    assert O.flatten_params(P["cp"]).astype(np.float64).sum() == pytest.approx(float(z["w_c_checksum"][0]), rel=1e-9)
+    c = O.predict_and_render_chunk_single(P["cp"], z["o"], z["d"], z["t"], P["cfg"], True)
+    np.testing.assert_allclose(c["image"], z["f32_c_image"], atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_hip_path_against_fullsize_golden():
+    from keras_nerf_amd.runtime import KnerfContext
+    from tests.problem import make_problem
+    from tests.test_gpu_train import per_tensor_err  # noqa: F401
+    import torch
+    z = np.load(os.path.join(G, "fullsize_r64.npz"))
+    P = make_problem(n_images=1, wh=8, seed=42, weight_scale=1.5, bias_std=0.05)
+    ctx = KnerfContext(white_background=True)
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    out = {k: v.cpu().numpy() for k, v in ctx.render_chunk(z["o"], z["d"], z["t"], z["u"]).items()}
+    np.testing.assert_allclose(out["c_image"], z["bf16_c_image"], atol=1e-2)       # same arithmetic as the kernels
+    np.testing.assert_allclose(out["c_weights"], z["bf16_c_weights"], atol=1e-2)
+    np.testing.assert_allclose(out["c_image"], z["f32_c_image"], atol=2e-2)         # the reference's arithmetic
+    assert O.psnr(out["c_image"].reshape(1, 8, 8, 3), z["f32_c_image"].reshape(1, 8, 8, 3))[0] > 45.0
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(z["o"], z["d"], z["t"], z["img"], z["u"], loss=loss)
+    g = ctx.grads_view().cpu().numpy()[:ctx.param_count]
+    assert abs(float(loss[0]) - float(z["bf16_coarse_loss"][0])) < 2e-3
+    ref = z["bf16_grad_c_sample"]; got = g[z["bf16_grad_c_idx"]]
+    assert np.abs(got - ref).max() < 4e-2 * np.abs(ref).max()
+    off, l2 = 0, []
+    for name, fi, fo in O.layer_shapes(P["cfg"]):
+        for n in (fi * fo, fo):
+            l2.append(np.linalg.norm(g[off:off + n].astype(np.float64))); off += n
+    np.testing.assert_allclose(l2, z["bf16_grad_c_l2_per_tensor"], rtol=5e-2)
+    ctx.close()
