@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknerf_hip.so")
+LIB_PATH = os.environ.get("KNERF_LIB") or os.path.join(_HERE, "libknerf_hip.so")   # KNERF_LIB: A/B builds (tools/kbench.py)
 
 KNERF_OK, KNERF_ERR_INVALID, KNERF_ERR_HIP, KNERF_ERR_NONFINITE, KNERF_ERR_NODEVICE = 0, -1, -2, -3, -4
 COARSE, FINE = 0, 1

@@ -20,9 +20,12 @@ def _newer(a: str, b: str) -> bool:
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "") -> str:
+    """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
+    lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")
+    flags = FLAGS + ["-D" + d for d in defines]
     os.makedirs(objdir, exist_ok=True)
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
@@ -31,20 +34,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdr_paths):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *flags, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if procs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if procs or not os.path.exists(lib):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    var = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")), "")
+    build(force="--force" in sys.argv, defines=defs, variant=var)

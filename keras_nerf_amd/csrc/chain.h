@@ -4,9 +4,16 @@
 // different feature rows of the same sample).  Activations never leave registers between layers: the 32x32 f32
 // MFMA result, converted to bf16, is the next layer's B operand (layout.h).  Weights arrive as a linear stream of
 // 1 KiB A-fragment blocks pulled by LDS-DMA (global_load_lds_dwordx4) through a ring of 16 KiB pages.
+//
+// Stagger: the two waves that share a SIMD (wave w and w+4) run the same program; in lockstep their epilogues and
+// barrier waits coincide and the matrix pipe idles.  Waves 0-3 ("group A") therefore take the ring's barrier in the
+// middle of a page (block 16k+8) and waves 4-7 ("group B") at the start of the next one (block 16k+16): B runs half a
+// page ahead, so one wave's epilogue overlaps its SIMD partner's MFMAs.  Barrier k guarantees pages <= k+2 landed
+// (B prefetches into page k+2 before barrier k+1) and recycles the slot of page k-1 for page k+kSlots-1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace knerf {
 
@@ -14,17 +21,76 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 constexpr int kWaves = 8;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kTile = 32;                 // samples per wave
 constexpr int kPageBlocks = 16;           // 1 KiB blocks per ring page
 constexpr int kPageBytes = kPageBlocks * 1024;
-constexpr int kSlots = 6;                 // ring slots (96 KiB)
+#ifndef KNERF_SLOTS
+#define KNERF_SLOTS 6
+#endif
+#ifndef KNERF_PREFETCH
+#define KNERF_PREFETCH 4
+#endif
+constexpr int kSlots = KNERF_SLOTS;       // ring slots of 16 KiB
 constexpr int kRingBytes = kSlots * kPageBytes;
 constexpr int kGldsPerPage = kPageBytes / (kThreads * 16);   // 2 LDS-DMA instructions per thread per page
-constexpr int kWaitInFlight = kGldsPerPage * (kSlots - 3);   // vmcnt at a mid-page sync: pages P+2..P+kSlots-2 may fly
+constexpr int kWaitInFlight = kGldsPerPage * (kSlots - 4);   // LDS-DMA ops that may still fly at a barrier: pages k+3..k+kSlots-2
 constexpr int kTailPages = kSlots;        // dummy pages appended to every stream so that issue never needs a guard
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Static schedule of the global stores a chain kernel issues between its MFMA blocks (they share the in-order vmcnt
+// queue with the ring's LDS-DMA).  A stage writes `per_tile` stores in the epilogue of every out tile (`skip_last`: not
+// for its last tile) and `at_end` more after its last tile; `initial` stores precede block 0.
+struct StoreStage { int b0, nks, n_ot, per_tile, at_end, skip_last; };
+template <int NST>
+struct StoreSched {
+    StoreStage st[NST];
+    int initial;
+    // stores issued (program order) before the MFMA of block b
+    constexpr int before(int b) const {
+        if (b < 0) return 0;
+        int n = initial;
+        for (int i = 0; i < NST; ++i) {
+            const StoreStage& s = st[i];
+            for (int ot = 0; ot < s.n_ot; ++ot) {
+                const int last = s.b0 + ot * s.nks + s.nks - 1;     // the epilogue follows this block
+                if (last < b) {
+                    if (!(s.skip_last && ot == s.n_ot - 1)) n += s.per_tile;
+                    if (ot == s.n_ot - 1) n += s.at_end;
+                }
+            }
+        }
+        return n;
+    }
+    // vmcnt immediate of the barrier a wave takes in front of block b (b % 8 == 0): the page that must have landed was
+    // issued right after this wave's barrier kSlots-3 pages earlier (or in the prologue); everything issued since then
+    // may still be in flight
+    constexpr int wait_at(int b) const {
+        const int prev = b - (kSlots - 3) * kPageBlocks;
+        const int n = kWaitInFlight + before(b) - (prev < 0 ? 0 : before(prev));
+        return n > 60 ? 60 : n;
+    }
+};
+template <int NBLK>
+struct WaitTable { int n[NBLK / 8 + 3]; };        // indexed by b / 8
+template <int NST, int NBLK>
+constexpr WaitTable<NBLK> make_wait_table(const StoreSched<NST>& s) {
+    WaitTable<NBLK> t{};
+    for (int i = 0; i < NBLK / 8 + 3; ++i) t.n[i] = s.wait_at(i * 8);
+    return t;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -33,28 +99,33 @@ struct Ring {
     const char* stream;    // global: packed bf16 A-fragments, page after page
     char* lds;             // LDS base of the ring (16-byte aligned, offset 0 of the dynamic segment)
     int tid;
+    int wave;              // scalar (readfirstlane) wave index
 
-    // every thread moves 2 x 16 B of page `page` into slot page % kSlots
+    // every thread moves 2 x 16 B of page `page` into slot page % kSlots.  Uniform base + 32-bit lane offset keeps the
+    // address arithmetic on the scalar unit.
     __device__ __forceinline__ void issue(int page) const {
-        const char* src = stream + (size_t)page * kPageBytes + tid * 16;
-        char* dst = lds + (page % kSlots) * kPageBytes + (tid & ~63) * 16;   // wave-uniform base; HW adds lane*16
+        char* dst = lds + (page % kSlots) * kPageBytes + wave * 1024;         // wave-uniform base; HW adds lane*16
 #pragma unroll
-        for (int i = 0; i < kGldsPerPage; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + i * kThreads * 16), (lds_ptr_t)(dst + i * kThreads * 16), 16, 0, 0);
+        for (int i = 0; i < kGldsPerPage; ++i) {
+            const char* base = stream + (size_t)page * kPageBytes + i * kThreads * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (unsigned)(tid * 16)), (lds_ptr_t)(dst + i * kThreads * 16), 16, 0, 0);
+        }
     }
     __device__ __forceinline__ void prologue_issue() const {
 #pragma unroll
         for (int p = 0; p < kSlots - 1; ++p) issue(p);
     }
     __device__ __forceinline__ void prologue_wait() const {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGldsPerPage * (kSlots - 2)) : "memory");   // page 0 landed (mine)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGldsPerPage * (kSlots - 3)) : "memory");   // pages 0 and 1 landed (mine)
         __builtin_amdgcn_s_barrier();                                                          // ... and everyone's
     }
-    // called when block b == 8 (mod 16), P = b/16: make page P+1 readable, recycle the slot of page P-1
-    __device__ __forceinline__ void sync(int P) const {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitInFlight) : "memory");
+    // barrier k (group A: in front of block 16k+8, group B: in front of block 16k+16): pages <= k+2 readable,
+    // the slot of page k-1 is recycled for page k+kSlots-1
+    template <int WAIT>
+    __device__ __forceinline__ void sync(int k) const {
+        wait_vmcnt<WAIT>();
         __builtin_amdgcn_s_barrier();
-        issue(P + kSlots - 1);
+        issue(k + kSlots - 1);
     }
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -82,15 +153,68 @@ __device__ __forceinline__ f32x16 zero_acc() {
     return acc;
 }
 
-// f32x16 accumulator -> two bf16x8 B-operand k-steps (regs 0..7 -> k-step 0, regs 8..15 -> k-step 1)
+// f32x16 accumulator -> two bf16x8 B-operand k-steps (regs 0..7 -> k-step 0, regs 8..15 -> k-step 1); explicit pair
+// conversions so that each dword is ONE v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
 __device__ __forceinline__ void pack_acc(const f32x16& a, bf16x8& lo, bf16x8& hi) {
+    u32x4 l, h;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { lo[j] = (__bf16)a[j]; hi[j] = (__bf16)a[8 + j]; }
+    for (int k = 0; k < 4; ++k) { l[k] = cvt_pk_bf16(a[2 * k], a[2 * k + 1]); h[k] = cvt_pk_bf16(a[8 + 2 * k], a[8 + 2 * k + 1]); }
+    lo = __builtin_bit_cast(bf16x8, l); hi = __builtin_bit_cast(bf16x8, h);
+}
+
+// ReLU on PACKED bf16: as int16 a negative float is a negative integer, so one v_pk_max_i16 per pair does it
+// (relu(round(x)) == round(relu(x)): rounding keeps the sign).
+__device__ __forceinline__ bf16x8 relu_packed(const bf16x8& v) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    u32x4 x = __builtin_bit_cast(u32x4, v);
+    const s16x2 z = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned xk = x[k];                       // scalar copy: see the bit_cast note below
+        x[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, xk), z));   // v_pk_max_i16
+    }
+    return __builtin_bit_cast(bf16x8, x);
+}
+
+// ReLU mask of one out tile from its two packed (already ReLU'd) k-steps: flag = (half != 0) via v_pk_min_u16(x, 1),
+// packed pair k (k = 0..7: lo dwords then hi dwords) -> bit k (even element) and bit 16+k (odd element).
+__device__ __forceinline__ unsigned relu_mask_bits(const bf16x8& lo, const bf16x8& hi) {
+    const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+    unsigned f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(f[k]) : "v"(a[k]));
+        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(f[4 + k]) : "v"(b[k]));
+    }
+    unsigned w = f[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) w |= f[k] << k;       // v_lshl_or_b32
+    return w;
+}
+
+// dgrad side: zero the halves of packed dZ whose forward activation was not positive.  w = relu_mask_bits of that tile.
+__device__ __forceinline__ void apply_mask_packed(bf16x8& lo, bf16x8& hi, unsigned w) {
+    u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned fa = (w >> k) & 0x00010001u, fb = (w >> (4 + k)) & 0x00010001u;      // 0/1 per half
+        // NB scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 (hipcc 7.2)
+        const unsigned ak = a[k], bk = b[k];
+        a[k] = __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, ak) * __builtin_bit_cast(u16x2, fa)));
+        b[k] = __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, bk) * __builtin_bit_cast(u16x2, fb)));
+    }
+    lo = __builtin_bit_cast(bf16x8, a); hi = __builtin_bit_cast(bf16x8, b);
 }
 
 // A-fragment prefetch ring: block b's fragment is read from LDS kPrefetch MFMAs before it is used.  kPrefetch <= 8
 // keeps every read inside the half page that the last sync made readable (see Ring::sync).
-constexpr int kPrefetch = 4;
+constexpr int kPrefetch = KNERF_PREFETCH;
 struct Prefetch {
     bf16x8 a[kPrefetch];
     template <int NBLOCKS>
@@ -100,30 +224,67 @@ struct Prefetch {
     }
 };
 
-// One dense stage: for every out tile, acc = init(ot); acc += A(block) x in(ks) over the stage's k-steps; epi(ot, acc).
-// B0 = index of the stage's first block in the stream, NBLOCKS the stream length.  All indices fold to constants
-// after unrolling.
-template <int B0, int NKS, int NOT, int NBLOCKS, class Init, class In, class Epi>
-__device__ __forceinline__ void dense_stage(const Ring& ring, Prefetch& pf, int lane, Init&& init, In&& in, Epi&& epi) {
+// number of ring barriers each group takes over a stream of NBLOCKS blocks (A: b = 8, 24, ...; B: b = 16, 32, ...)
+constexpr int barriers_a(int nblocks) { return nblocks > 8 ? (nblocks - 9) / kPageBlocks + 1 : 0; }
+constexpr int barriers_b(int nblocks) { return nblocks > 16 ? (nblocks - 17) / kPageBlocks + 1 : 0; }
+// after its last block group B takes the barriers group A still has (the counts differ by at most one)
+template <int NBLOCKS>
+__device__ __forceinline__ void ring_finish(const Ring& ring, int grp) {
+    if (grp == 1) {
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
-        f32x16 acc = init(ot);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int b = B0 + ot * NKS + ks;
-            if (b % kPageBlocks == kPageBlocks / 2) ring.sync(b / kPageBlocks);
-            bf16x8 cur = pf.a[b % kPrefetch];
-            if (b + kPrefetch < NBLOCKS) pf.a[b % kPrefetch] = ring.frag(b + kPrefetch, lane);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, in(ks), acc, 0, 0, 0);
-        }
-        epi(ot, acc);
+        for (int i = barriers_b(NBLOCKS); i < barriers_a(NBLOCKS); ++i) __builtin_amdgcn_s_barrier();
     }
+    ring.drain();
 }
 
-// saved B-operand block (layout.h saved_off): lane (h = lane>>5, s = lane&31) -> (2*(s ^ 4*(block&1)) + h) * 16
-__device__ __forceinline__ void store_block(char* base, size_t block, int lane, const bf16x8& v) {
+// One dense stage: for every out tile, acc = init(ot); acc += A(block) x in(ks) over the stage's k-steps; epi(ot, acc).
+// B0 = index of the stage's first block in the stream, NBLOCKS the stream length; every index is a compile-time
+// constant (static_for).  W::tab.n[b/8] = vmcnt immediate of a barrier in front of block b (WaitTable).
+// grp = 0 for waves 0-3 (barrier at b % 16 == 8), 1 for waves 4-7 (barrier at b % 16 == 0); scalar.
+template <int B0, int NKS, int NOT, int NBLOCKS, class W, class Init, class In, class Epi>
+__device__ __forceinline__ void dense_stage(const Ring& ring, Prefetch& pf, int lane, int grp, W, Init&& init, In&& in, Epi&& epi) {
+    static_for<NOT>([&](auto ot_) {
+        constexpr int ot = decltype(ot_)::value;
+        f32x16 acc = init(ot);
+        static_for<NKS>([&](auto ks_) {
+            constexpr int ks = decltype(ks_)::value;
+            constexpr int b = B0 + ot * NKS + ks;
+            if constexpr (b % kPageBlocks == kPageBlocks / 2) {
+                if (grp == 0) ring.template sync<W::tab.n[b / 8]>(b / kPageBlocks);
+            } else if constexpr (b % kPageBlocks == 0 && b > 0) {
+                if (grp == 1) ring.template sync<W::tab.n[b / 8]>(b / kPageBlocks - 1);
+            }
+            bf16x8 cur = pf.a[b % kPrefetch];
+            if constexpr (b + kPrefetch < NBLOCKS) pf.a[b % kPrefetch] = ring.frag(b + kPrefetch, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, in(ks), acc, 0, 0, 0);
+        });
+        epi(ot, acc);
+    });
+}
+
+// 16-byte streaming store.  The saved activations / dZ are a pure output stream of several GB per launch; as plain
+// stores they evict the 1.2 MB weight stream that every workgroup re-reads from L2, and those re-reads then compete
+// with the stores for HBM (measured: forward 1.22 ms plain, 0.88 ms sc1 or nt; dgrad 1.02 ms sc1, 0.81 ms nt -- nt is
+// the default).  Inline asm: hipcc does not count it in vmcnt (the StoreSched table does) and the trailing s_nop keeps
+// the data registers intact until they have been read.
+__device__ __forceinline__ void store16_wt(char* base, unsigned off, const u32x4& v) {
+#ifdef KNERF_ABLATE_STORES      // timing experiment only: keeps the value alive, skips the store
+    asm volatile("" ::"v"(v));
+#elif defined(KNERF_PLAIN_STORES)
+    *reinterpret_cast<u32x4*>(base + off) = v;
+#else
+#ifndef KNERF_STORE_POLICY
+#define KNERF_STORE_POLICY "nt"
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, %2 " KNERF_STORE_POLICY "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+#endif
+}
+
+// saved B-operand block (layout.h saved_off): lane (h = lane>>5, s = lane&31) -> (2*(s ^ 4*(block&1)) + h) * 16.
+// `base` must be wave-uniform (it lives in SGPRs).
+__device__ __forceinline__ void store_block(char* base, int block, int lane, const bf16x8& v) {
     const int s = lane & 31, h = lane >> 5;
-    *reinterpret_cast<bf16x8*>(base + block * 1024 + (2 * (s ^ (((int)block & 1) << 2)) + h) * 16) = v;
+    store16_wt(base, (unsigned)(block * 1024 + (2 * (s ^ ((block & 1) << 2)) + h) * 16), __builtin_bit_cast(u32x4, v));
 }
 
 }  // namespace knerf

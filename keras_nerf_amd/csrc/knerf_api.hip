@@ -33,15 +33,24 @@ struct Tables {
     int n_plan = 0;
 };
 
-// workgroups per wgrad job in proportion to the bytes the job streams per sample tile (the kernel is HBM-bound),
-// about one workgroup per CU in total
+// Workgroups per wgrad job in proportion to the job's measured cost per sample tile (cycles per loop iteration from the
+// s_memtime stamps of a -DKNERF_WGRAD_STAMPS build, tools/kbench.py): the streaming jobs are HBM-bound, the small ones
+// (sigma, rgb heads) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
 std::vector<int32_t> build_wgrad_plan(int n_wg) {
-    int bytes[kWgradJobs], total = 0;
-    for (int j = 0; j < kWgradJobs; ++j) { WgradJob J = wgrad_job(j); bytes[j] = J.layer < 0 ? 0 : 2 * (J.n_it + J.n_ot); total += bytes[j]; }
+    int cost[kWgradJobs], total = 0;
+    for (int j = 0; j < kWgradJobs; ++j) {
+        WgradJob J = wgrad_job(j);
+        int c = 0;
+        if (J.layer >= 0) {
+            if (j == 0) c = 109; else if (j == 5) c = 248; else if (j == 9) c = 106; else if (j == 10) c = 162; else if (j == 11) c = 73;
+            else c = 204;
+        }
+        cost[j] = c; total += c;
+    }
     std::vector<int32_t> plan;
     for (int j = 0; j < kWgradJobs; ++j) {
-        if (!bytes[j]) continue;
-        int ns = bytes[j] * n_wg / total; if (ns < 1) ns = 1;
+        if (!cost[j]) continue;
+        int ns = (cost[j] * (n_wg - 4) + total / 2) / total; if (ns < 1) ns = 1;
         for (int s = 0; s < ns; ++s) { plan.push_back(j); plan.push_back(s); plan.push_back(ns); plan.push_back(0); }
     }
     return plan;
@@ -136,7 +145,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
     HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
     if (train) {
         const size_t tiles = tiles_for((long long)ns);
-        ctx->act_bytes = tiles * kActBlocks * 1024; ctx->mask_bytes = tiles * kMaskBlocks * 1024; ctx->dz_bytes = tiles * kDzBlocks * 1024;
+        ctx->act_bytes = tiles * kActTileBytes; ctx->mask_bytes = tiles * kMaskTileBytes; ctx->dz_bytes = tiles * kDzTileBytes;
         HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));

@@ -16,6 +16,7 @@
 // k order permuted: element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3).  The packed weights carry the
 // same permutation, so no lane ever moves data.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -199,6 +200,15 @@ constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, 
 constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
 constexpr int kDzFeat = 128, kDzSig = 144, kDzF2 = 146, kDzRgb = 154, kDzBlocks = 156;
 constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
+// Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
+// own tile at about the same time, so a stride that is a large power of two times a small odd number (156 KiB =
+// 2^12 * 39) concentrates those writes on a few memory channels; an odd number of 256-B units spreads them.
+#ifndef KNERF_TILE_SKEW
+#define KNERF_TILE_SKEW 256
+#endif
+constexpr size_t kActTileBytes = (size_t)kActBlocks * 1024 + KNERF_TILE_SKEW;
+constexpr size_t kDzTileBytes = (size_t)kDzBlocks * 1024 + KNERF_TILE_SKEW;
+constexpr size_t kMaskTileBytes = (size_t)kMaskBlocks * 1024 + KNERF_TILE_SKEW;
 
 // wgrad jobs: dW[in_row][out_col] += sum_s act[s][in] * dz[s][out], db[out_col] += sum_s dz[s][out]
 struct WgradJob {

@@ -48,11 +48,22 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
 }
 
+// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile, one mask block per trunk layer,
+// the 2 dir blocks after the features stage
+constexpr StoreSched<11> kFwdStores = {{{0, 4, 8, 2, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
+                                        {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 1, 0},
+                                        {960, 16, 9, 2, 2, 1}, {1104, 18, 4, 2, 0, 0}, {1176, 8, 1, 0, 0, 0}}, 4};
+constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
+struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<11, kFwdBlocks>(kFwdStores); };
+struct FwdWaitPlain { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<1, kFwdBlocks>(kNoStores); };
+
 template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_lds = reinterpret_cast<float*>(smem + kRingBytes);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the per-tile base pointers stay in SGPRs
+    const int grp = wave >> 2;                                    // stagger group (chain.h): 0 = waves 0-3, 1 = waves 4-7
     const int col = lane & 31, h = lane >> 5;
 
     // biases -> LDS (plain loads, before any LDS-DMA is in flight)
@@ -70,43 +81,46 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     const float px = __fadd_rn(ox, __fmul_rn(dx, t)), py = __fadd_rn(oy, __fmul_rn(dy, t)), pz = __fadd_rn(oz, __fmul_rn(dz, t));
     __syncthreads();
 
-    Ring ring{a.stream, smem, tid};
+    Ring ring{a.stream, smem, tid, wave};
     ring.prologue_issue();
+    asm volatile("" ::: "memory");            // every store below stays behind the prologue's LDS-DMA (StoreSched counts on it)
 
-    bf16x8 enc[4], dirc[2];
+    // the encodings are recomputed where they are consumed (layer_0 and layer_5; rgb_features) instead of pinning 24
+    // VGPRs across the trunk: 42 v_sin per re-encode vs ~1200 MFMAs per tile
+    bf16x8 enc[4];
     encode<kLx, 4>(px, py, pz, h, enc);
-    encode<kLd, 2>(dx, dy, dz, h, dirc);
 
     char* act = nullptr; char* maskp = nullptr;
     if (SAVE) {
-        act = a.act + (size_t)tile * kActBlocks * 1024;
-        maskp = a.mask + (size_t)tile * kMaskBlocks * 1024;
+        act = a.act + (size_t)tile * kActTileBytes;
+        maskp = a.mask + (size_t)tile * kMaskTileBytes;
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_block(act, kActEnc + q, lane, enc[q]);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
     }
 
     ring.prologue_wait();
     Prefetch pf;
     pf.start<kFwdBlocks>(ring, lane);
+#ifdef KNERF_CONSERVATIVE_WAIT
+    FwdWaitPlain waits;
+#else
+    std::conditional_t<SAVE, FwdWaitSave, FwdWaitPlain> waits;
+#endif
 
     bf16x8 x[16], y[16];
     // relu epilogue of a trunk layer: out -> y (or x), activations + mask saved in training
     auto relu_epi = [&](bf16x8 (&out)[16], int layer, unsigned (&mbits)[4]) {
         return [&, layer](int ot, f32x16 acc) {
-            unsigned m = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (SAVE) m |= (acc[i] > 0.f ? 1u : 0u) << i;
-                acc[i] = __builtin_amdgcn_fmed3f(acc[i], 0.f, __builtin_inff());
-            }
             pack_acc(acc, out[2 * ot], out[2 * ot + 1]);
+            out[2 * ot] = relu_packed(out[2 * ot]);
+            out[2 * ot + 1] = relu_packed(out[2 * ot + 1]);
             if (SAVE) {
                 store_block(act, act_h(layer) + 2 * ot, lane, out[2 * ot]);
                 store_block(act, act_h(layer) + 2 * ot + 1, lane, out[2 * ot + 1]);
-                if (ot & 1) mbits[ot >> 1] |= m << 16; else mbits[ot >> 1] = m;
-                if (ot == 7) *reinterpret_cast<u32x4*>(maskp + layer * 1024 + lane * 16) = u32x4{mbits[0], mbits[1], mbits[2], mbits[3]};
+                // mask word of tile ot in byte lanes: even tile -> bits 0-7 / 16-23, odd tile -> bits 8-15 / 24-31
+                const unsigned m = relu_mask_bits(out[2 * ot], out[2 * ot + 1]);
+                if (ot & 1) mbits[ot >> 1] |= m << 8; else mbits[ot >> 1] = m;
+                if (ot == 7) store16_wt(maskp, (unsigned)(layer * 1024 + lane * 16), u32x4{mbits[0], mbits[1], mbits[2], mbits[3]});
             }
         };
     };
@@ -115,21 +129,23 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     auto bias_init = [&](int base) { return [&, base](int ot) { return bias_acc(bias_lds, base + ot, h); }; };
 
     // layer_0: 63 -> 256
-    dense_stage<0, 4, 8, kFwdBlocks>(ring, pf, lane, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
+    dense_stage<0, 4, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
     // layer_1..4
-    dense_stage<32, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(8), [&](int ks) { return x[ks]; }, relu_epi(y, 1, mb));
-    dense_stage<160, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(16), [&](int ks) { return y[ks]; }, relu_epi(x, 2, mb));
-    dense_stage<288, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(24), [&](int ks) { return x[ks]; }, relu_epi(y, 3, mb));
-    dense_stage<416, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(32), [&](int ks) { return y[ks]; }, relu_epi(x, 4, mb));
+    dense_stage<32, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8), [&](int ks) { return x[ks]; }, relu_epi(y, 1, mb));
+    dense_stage<160, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(16), [&](int ks) { return y[ks]; }, relu_epi(x, 2, mb));
+    dense_stage<288, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(24), [&](int ks) { return x[ks]; }, relu_epi(y, 3, mb));
+    dense_stage<416, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(32), [&](int ks) { return y[ks]; }, relu_epi(x, 4, mb));
     // layer_5: [h4, xyz_enc] -> 256   (skip concat: h first, input second; mlp.py:36-38)
-    dense_stage<544, 20, 8, kFwdBlocks>(ring, pf, lane, bias_init(40), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : enc[ks >= 16 ? ks - 16 : 0]; },
+    bf16x8 enc5[4];
+    encode<kLx, 4>(px, py, pz, h, enc5);
+    dense_stage<544, 20, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(40), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : enc5[ks >= 16 ? ks - 16 : 0]; },
                             relu_epi(y, 5, mb));
-    dense_stage<704, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(48), [&](int ks) { return y[ks]; }, relu_epi(x, 6, mb));
-    dense_stage<832, 16, 8, kFwdBlocks>(ring, pf, lane, bias_init(56), [&](int ks) { return x[ks]; }, relu_epi(y, 7, mb));
+    dense_stage<704, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(48), [&](int ks) { return y[ks]; }, relu_epi(x, 6, mb));
+    dense_stage<832, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(56), [&](int ks) { return x[ks]; }, relu_epi(y, 7, mb));
     (void)btile;
     // features (linear, 8 tiles) + sigma (relu, 9th tile row 0)
     float sigma = 0.f;
-    dense_stage<960, 16, 9, kFwdBlocks>(ring, pf, lane, bias_init(64), [&](int ks) { return y[ks]; }, [&](int ot, f32x16 acc) {
+    dense_stage<960, 16, 9, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(64), [&](int ks) { return y[ks]; }, [&](int ot, f32x16 acc) {
         if (ot < 8) {
             pack_acc(acc, x[2 * (ot < 8 ? ot : 0)], x[2 * (ot < 8 ? ot : 0) + 1]);
             if (SAVE) {
@@ -141,8 +157,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         }
     });
     // rgb_features: [features, dir_enc] -> 128, LINEAR in this reference (mlp.py:23-24,46)
-    bf16x8 f2[8];
-    dense_stage<1104, 18, 4, kFwdBlocks>(ring, pf, lane, bias_init(73), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
+    bf16x8 f2[8], dirc[2];
+    encode<kLd, 2>(dx, dy, dz, h, dirc);
+    if (SAVE) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
+    }
+    dense_stage<1104, 18, 4, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(73), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
                              [&](int ot, f32x16 acc) {
                                  pack_acc(acc, f2[2 * ot], f2[2 * ot + 1]);
                                  if (SAVE) {
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
                                  }
                              });
     // rgb: 128 -> 3, sigmoid
-    dense_stage<1176, 8, 1, kFwdBlocks>(ring, pf, lane, bias_init(77), [&](int ks) { return f2[ks]; }, [&](int, f32x16 acc) {
+    dense_stage<1176, 8, 1, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(77), [&](int ks) { return f2[ks]; }, [&](int, f32x16 acc) {
         if (valid && h == 0) {
             f32x4 r;
             r[0] = 1.f / (1.f + expf(-acc[0]));
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
             reinterpret_cast<f32x4*>(a.raw)[g] = r;
         }
     });
-    ring.drain();
+    ring_finish<kFwdBlocks>(ring, grp);
 }
 
 hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {

@@ -28,12 +28,29 @@ constexpr int kWgScratch = kWgWaves * 1024;   // landing zone of padding LDS-DMA
 // every transposed LDS read).  lds_dst = wave-uniform LDS byte address; completion is counted by hand (vmcnt).
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#ifndef KNERF_WGRAD_LOAD_POLICY
+#define KNERF_WGRAD_LOAD_POLICY "nt"     // once-read streams (measured -2.5 %)
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
+
+#ifdef KNERF_WGRAD_STAMPS   // diagnostic build only (tools/kbench.py --stamps): per-workgroup cycle totals of the loop phases
+__device__ unsigned long long g_wgrad_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp()
+#else
+#define STAMP(var)
+#endif
 
 struct WgradPlan {          // one entry per workgroup, built on the host (knerf_api.hip)
     int job, split, nsplit, pad;
@@ -80,22 +97,38 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             lane_off[r] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8;
     }
 
-    auto issue = [&](long long t, int slot) {
-        if (t >= t1) t = t1 - 1;                              // tail: harmless re-read keeps the vmcnt arithmetic uniform
-        const char* src_in = a.act + ((size_t)t * kActBlocks + act_blk) * 1024 + lane * 16;
-        const char* src_dz = a.dz + ((size_t)t * kDzBlocks + dz_blk) * 1024 + lane * 16;
+    // per-wave source pointers of the next tile to stage (one per LDS-DMA round) and the matching LDS offsets; issue()
+    // stages tiles strictly in order, so the pointers simply advance by one tile stride per call
+    const char* p_in[G_IN]; const char* p_dz[G_DZ];
+    unsigned o_in[G_IN], o_dz[G_DZ];
+#pragma unroll
+    for (int r = 0; r < G_IN; ++r) {
+        const int b = r * kWgWaves + wave;
+        const bool ok = b < BLK_IN;
+        p_in[r] = a.act + (size_t)t0 * kActTileBytes + (size_t)(act_blk + (ok ? b : 0)) * 1024 + lane * 16;
+        o_in[r] = ok ? (unsigned)(b * 1024) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < G_DZ; ++r) {
+        const int b = r * kWgWaves + wave;
+        const bool ok = b < BLK_DZ;
+        p_dz[r] = a.dz + (size_t)t0 * kDzTileBytes + (size_t)(dz_blk + (ok ? b : 0)) * 1024 + lane * 16;
+        o_dz[r] = ok ? (unsigned)((BLK_IN + b) * 1024) : 0xFFFFFFFFu;
+    }
+    long long t_next = t0;
+    auto issue = [&](int slot) {
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
-        for (int r = 0; r < G_IN; ++r) {
-            const int b = r * kWgWaves + wave;
-            const bool ok = b < BLK_IN;
-            glds16(src_in + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch));
-        }
+        for (int r = 0; r < G_IN; ++r)
+            glds16(p_in[r], __builtin_amdgcn_readfirstlane(o_in[r] != 0xFFFFFFFFu ? dst + o_in[r] : scratch));
 #pragma unroll
-        for (int r = 0; r < G_DZ; ++r) {
-            const int b = r * kWgWaves + wave;
-            const bool ok = b < BLK_DZ;
-            glds16(src_dz + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch));
+        for (int r = 0; r < G_DZ; ++r)
+            glds16(p_dz[r], __builtin_amdgcn_readfirstlane(o_dz[r] != 0xFFFFFFFFu ? dst + o_dz[r] : scratch));
+        if (++t_next < t1) {             // tail: harmless re-read of the last tile keeps the vmcnt arithmetic uniform
+#pragma unroll
+            for (int r = 0; r < G_IN; ++r) p_in[r] += kActTileBytes;
+#pragma unroll
+            for (int r = 0; r < G_DZ; ++r) p_dz[r] += kDzTileBytes;
         }
     };
 
@@ -107,27 +140,53 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(t0 + s, s);
+    for (int s = 0; s < NS - 1; ++s) issue(s);
     int slot = 0;
+#ifdef KNERF_WGRAD_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+#endif
     for (long long t = t0; t < t1; ++t) {
+        STAMP(s0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile t landed (mine) ...
+        STAMP(s1);
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile t-1 is free
+        STAMP(s2);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
-        issue(t + NS - 1, nslot);
+        issue(nslot);
+        STAMP(s3);
         const char* in_reg = smem + slot * TILE_BYTES;
         const char* dz_reg = in_reg + BLK_IN * 1024;
+#ifdef KNERF_WGRAD_ABLATE_COMPUTE     // timing experiment only: pure streaming
+        if (t0 < 0)
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
+            // branch-free rows: a wave whose row index is the bias row (it == NI) swaps in the all-ones tile, rows past
+            // it compute on a clamped (valid) tile and are dropped at the flush -- no control flow between the
+            // transposed reads, so they issue back to back
+            bf16x8 afr[NACC];
 #pragma unroll
             for (int n = 0; n < NACC; ++n) {
                 const int it = wi + n * WI;
-                if (it < NI) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(in_reg, it, kk, lane_off), b, acc[n], 0, 0, 0);
-                else if (it == NI) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b, acc[n], 0, 0, 0);
+                afr[n] = tr_frag(in_reg, it < NI ? it : NI - 1, kk, lane_off);
+                if (WI * NACC > NI && it >= NI) afr[n] = ones;
             }
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
+#ifdef KNERF_WGRAD_STAMPS
+        STAMP(s4);
+        c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
+#endif
     }
+#ifdef KNERF_WGRAD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_wgrad_stamps + blockIdx.x * 8;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = (unsigned long long)(t1 - t0); o[5] = job;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // nobody may restage LDS for the next job while a wave still reads this one
 
@@ -173,6 +232,12 @@ __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
         default: break;
     }
 }
+
+#ifdef KNERF_WGRAD_STAMPS
+extern "C" int knerf_debug_wgrad_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wgrad_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     const size_t lds = 160 * 1024;

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at a bench configuration (HIP events via knerf_profile_*).  Usage on the GPU box:
+    python tools/kbench.py [--rays 4096] [--iters 6] [--lib path/to/variant.so]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--iters", type=int, default=6)
+ap.add_argument("--lib", default=None)
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+if args.lib:
+    os.environ["KNERF_LIB"] = os.path.abspath(args.lib)
+
+import numpy as np
+import torch
+from keras_nerf_amd.runtime import KnerfContext
+from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+
+ctx = KnerfContext(white_background=True)
+for net in (0, 1):
+    m = NeRFMLP(seed=net); m.build(); ctx.set_weights(net, m.get_flat_weights())
+wh = 128
+o, d, t = ctx.generate_rays(pose_spherical(20.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, 64, None, seed=1)
+R = args.rays
+o, d, t = o.reshape(-1, 3)[:R].contiguous(), d.reshape(-1, 3)[:R].contiguous(), t.reshape(-1, 64)[:R].contiguous()
+tgt = torch.rand((R, 3), device="cuda")
+loss = torch.zeros(2, device="cuda")
+FWD, DG, WG = 2 * 593408, 2 * (128 * 3 + 256 * 128 + 256 * 257 + 7 * 256 * 256), 2 * 593408
+for _ in range(2):
+    ctx.train_chunk(o, d, t, tgt, None, seed=1, loss=loss); ctx.render_chunk(o, d, t, None, seed=1)
+torch.cuda.synchronize()
+res = {}
+ctx.profile_enable(True); ctx.profile_read()
+for _ in range(args.iters):
+    ctx.render_chunk(o, d, t, None, seed=1)
+pr = ctx.profile_read()
+res["infer_fwd_coarse"] = pr["mlp_fwd_coarse"]; res["infer_fwd_fine"] = pr["mlp_fwd_fine"]
+for _ in range(args.iters):
+    ctx.train_chunk(o, d, t, tgt, None, seed=1, loss=loss)
+pt = ctx.profile_read()
+for k, v in pt.items():
+    res["train_" + k] = v
+ctx.apply_adam()
+if hasattr(ctx.lib, "knerf_debug_wgrad_stamps"):
+    import ctypes as C
+    buf = (C.c_ulonglong * (1024 * 8))()
+    ctx.lib.knerf_debug_wgrad_stamps(buf, 1024 * 8)
+    a = np.array(buf[:]).reshape(1024, 8)
+    a = a[a[:, 4] > 0]
+    per = {}
+    for j in sorted(set(a[:, 5])):
+        r = a[a[:, 5] == j]
+        tiles = r[:, 4].astype(float)
+        per[int(j)] = {k: round(float((r[:, i] / tiles).mean()), 1) for i, k in enumerate(["wait", "barrier", "issue", "compute"])}
+        per[int(j)]["tiles_per_wg"] = float(tiles.mean())
+    print(json.dumps({"wgrad_cycles_per_tile_by_job": per}))
+out = {}
+for k, (ms, n) in res.items():
+    if not n:
+        continue
+    avg = ms / n
+    S = R * (64 if k.endswith("coarse") else 192)
+    fl = FWD if "fwd" in k else DG if "bwd" in k else WG if "wgrad" in k else 0
+    out[k] = {"ms": round(avg, 4), "TFLOPs": round(fl * S / (avg * 1e-3) / 1e12, 1) if fl else None}
+    if "wgrad" in k:
+        out[k]["TBs"] = round(S / 32 * 334 * 1024 / (avg * 1e-3) / 1e12, 2)
+tot = sum(v["ms"] for k, v in out.items() if k.startswith("train_"))
+print(json.dumps({"tag": args.tag, "rays": R, "train_chunk_ms": round(tot, 3), "Mrs_per_s": round(R * 256 / tot / 1e3, 1), "kernels": out}))

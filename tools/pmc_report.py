@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Aggregates rocprofv3 --pmc CSVs (tools/pmc.sh) per kernel: mean counter value per dispatch."""
+import csv, glob, json, sys, collections
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("knerf::", "")
+        if not any(x in k for x in ("mlp_", "wgrad", "composite", "sample")):
+            continue
+        grid = int(r.get("Grid_Size", 0) or 0)
+        agg[(k, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+rep = {}
+for (k, grid), cs in sorted(agg.items()):
+    rep[f"{k} grid={grid}"] = {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())}
+    rep[f"{k} grid={grid}"]["dispatches"] = len(next(iter(cs.values())))
+print(json.dumps(rep, indent=1))
