@@ -22,9 +22,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <int C>
 __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= a.R) return;   // whole wave leaves together
+    __shared__ float s_loss[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    const bool training = a.draw != nullptr;
+    if (training && lane == 0) s_loss[wv] = 0.f;
+    if (ray >= a.R) {         // whole wave leaves together; in training it still joins the block's loss reduction
+        if (training) { __syncthreads(); }
+        return;
+    }
     const int S = a.S;
     const float eps = 1e-10f;
     const f32x4* raw = reinterpret_cast<const f32x4*>(a.raw) + (size_t)ray * S;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) { const int i = lane * C + c; if (i < S) a.weights[(size_t)ray * S + i] = w[c]; }
     }
-    if (!a.draw) return;
+    if (!training) return;
 
     // ---- loss + backward
     float gi[3], l2 = 0.f;
@@ -86,7 +92,10 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
         l2 += df * df;
         gi[k] = (pre[k] >= 0.f && pre[k] <= 1.f) ? a.grad_scale * df : 0.f;
     }
-    if (lane == 0) atomicAdd(a.loss, l2 * a.loss_scale);
+    // one atomic per block (4 rays) instead of one per ray: 4096 same-address atomics cost more than the kernel's work
+    if (lane == 0) s_loss[wv] = l2 * a.loss_scale;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.loss, (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
     const float gsum = a.white ? (gi[0] + gi[1] + gi[2]) : 0.f;
     float dw[C], pr[C];
     float suffix = 0.f;            // lane-local exclusive suffix sums of dw*w, built right to left
