@@ -170,3 +170,33 @@ def test_rccl_all_reduce_on_library_owned_gradient_buffer():
         ctx.zero_grads(); ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_loader_monitor_fit_end_to_end(tmp_path):
+    """f-2 / f-3: nerf_synthetic-layout directory -> DatasetLoader -> NeRF.fit with NeRFTrainMonitor: CSV schema, PNG names,
+    checkpoint cadence and the resume epoch of the reference's callback."""
+    import csv
+    import os
+    from keras_nerf_amd.data.loader import DatasetLoader
+    from keras_nerf_amd.model.nerf.callback import NeRFTrainMonitor
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    from tests.synthetic_scene import write
+    root = write(str(tmp_path / "scene"), n=(4, 2, 3), wh=24)
+    tr, va, te = DatasetLoader(root, white_background=True).load_dataset(1, 16, 16, 2.0, 6.0, 64)
+    imgs, (o, d, t) = next(iter(tr))
+    assert imgs.shape == (1, 16, 16, 4) and o.shape == (1, 16, 16, 3) and t.shape == (1, 16, 16, 64)   # reference test_loader.py:13-49
+    log_dir = str(tmp_path / "logs" / "run")
+    mon = NeRFTrainMonitor(te, log_dir, batch_size=1, update_freq=2)
+    assert mon.last_epoch == 0
+    nerf = NeRF()
+    nerf.compile("adam", "mse", batch_size=1, image_height=16, image_width=16, ray_chunks=128, white_background=True)
+    nerf.fit(tr, epochs=3, validation_data=va, callbacks=[mon], initial_epoch=mon.last_epoch, verbose=0)
+    files = set(os.listdir(log_dir))
+    assert {"log.csv", "model", "test_0_0.png", "test_0_2.png", "test_sample_0_0.png", "test_sample_0_2.png"} <= files
+    assert "test_0_1.png" not in files
+    assert sorted(os.listdir(os.path.join(log_dir, "model"))) == ["coarse.h5", "fine.h5", "model_config.json"]
+    rows = list(csv.DictReader(open(os.path.join(log_dir, "log.csv"))))
+    assert [r["epoch"] for r in rows] == ["0", "2"]
+    assert list(rows[0].keys()) == ["epoch", "coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim",
+                                    "val_coarse_loss", "val_coarse_psnr", "val_coarse_ssim", "val_fine_loss", "val_fine_psnr", "val_fine_ssim"]
+    assert NeRFTrainMonitor(te, log_dir, batch_size=1, update_freq=2).last_epoch == 3        # resume: last CSV epoch + 1

@@ -81,3 +81,29 @@ def test_metrics_against_definitions():
     m = Mean("x"); m.update_state(torch.tensor([1.0, 3.0])); m.update_state(5.0)
     assert m.result() == 3.0
     m.reset_state(); assert m.result() == 0.0
+
+
+def test_image_loader_composites_and_resizes(tmp_path):
+    from PIL import Image
+    from keras_nerf_amd.data.image import ImageLoader
+    rgba = np.zeros((8, 8, 4), np.uint8); rgba[2:6, 2:6] = (255, 0, 0, 255); rgba[0, 0] = (0, 255, 0, 128)
+    p = str(tmp_path / "a.png"); Image.fromarray(rgba, "RGBA").save(p)
+    w = ImageLoader(8, 8, white_background=True)(p); b = ImageLoader(8, 8, white_background=False)(p)
+    assert w.shape == (8, 8, 4) and w.dtype == np.float32 and w.min() >= 0 and w.max() <= 1      # reference tests/data/test_image.py:12-20
+    np.testing.assert_allclose(w[7, 7], [1, 1, 1, 0]); np.testing.assert_allclose(b[7, 7], [0, 0, 0, 0])    # transparent -> background
+    np.testing.assert_allclose(w[3, 3], [1, 0, 0, 1]); np.testing.assert_allclose(b[3, 3], [1, 0, 0, 1])
+    np.testing.assert_allclose(w[0, 0, :3], 128 / 255 * np.array([0, 1, 0]) + (1 - 128 / 255), atol=1e-6)   # alpha blend
+    assert ImageLoader(4, 4)(p).shape == (4, 4, 4)
+
+
+def test_dataset_loader_json_and_shuffle_semantics(tmp_path):
+    from keras_nerf_amd.data.loader import DatasetLoader
+    from tests.synthetic_scene import write
+    root = write(str(tmp_path / "scene"), n=(5, 2, 3))
+    tr, va, te = DatasetLoader(root, white_background=True).load_dataset(2, 24, 24, 2.0, 6.0, 64)
+    assert len(tr.image_paths) == 5 and len(va.image_paths) == 2 and len(te.image_paths) == 3
+    assert len(tr) == 2 and len(te) == 1                          # batch 2, drop_remainder
+    assert tr.image_paths[0].endswith("train/r_0.png") and tr.camera_params[0].shape == (4, 4)
+    order = tr._order()
+    assert sorted(order) == list(range(5))
+    assert all(order[k] <= k + 2 for k in range(5))                # a buffer of batch_size can pull an element at most that far forward
