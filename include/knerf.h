@@ -84,6 +84,12 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
                       const float* target, const float* u, uint64_t seed, uint64_t ray_offset, int n_rays,
                       float inv_chunks, float* loss, float* c_image, float* f_image);
 
+/* The whole chunk loop of train_step (nerf.py:351-421) in one call: n_rays must be a multiple of ray_chunks (the
+ * reference's assert, nerf.py:100); chunk i covers rays [i*ray_chunks, (i+1)*ray_chunks) with weight 1/C.  Same arguments
+ * as knerf_train_chunk, arrays sized for all n_rays. */
+int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
+                      const float* u, uint64_t seed, int n_rays, int ray_chunks, float* loss, float* c_image, float* f_image);
+
 /* coarse_optimizer.apply_gradients + fine_optimizer.apply_gradients + accumulator reset (nerf.py:455-471).
  * Call after the optional all-reduce of knerf_grads_device().  Returns KNERF_ERR_NONFINITE (weights untouched)
  * when a gradient is not finite (nerf.py:381-382).  Synchronises the stream. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "knerf_sample_fine": (C.c_int, [_P, _P, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _F]),
     "knerf_render_chunk": (C.c_int, [_P, _P, _F, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_int, _F, _F, _F, _F, _F, _F, _F]),
     "knerf_train_chunk": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_float, _F, _F, _F]),
+    "knerf_train_batch": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_int, C.c_int, _F, _F, _F]),
     "knerf_apply_adam": (C.c_int, [_P, _P]),
     "knerf_zero_grads": (C.c_int, [_P, _P]),
     "knerf_step_count": (C.c_int, [_P]),

@@ -409,6 +409,22 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
     return run_pass(ctx, s, KNERF_FINE, o, d, ctx->t_f, n_rays, Na, fi, nullptr, nullptr, target, inv_chunks, ls + 1);
 }
 
+int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
+                      const float* u, uint64_t seed, int n_rays, int ray_chunks, float* loss, float* c_image, float* f_image) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
+        return fail(ctx, KNERF_ERR_INVALID, "train_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
+    const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
+    for (int i = 0; i < C; ++i) {
+        const size_t r0 = (size_t)i * ray_chunks;
+        if (int r = knerf_train_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, target + r0 * 3, u ? u + r0 * Nf : nullptr, seed,
+                                      (uint64_t)r0, ray_chunks, 1.0f / (float)C, loss, c_image ? c_image + r0 * 3 : nullptr,
+                                      f_image ? f_image + r0 * 3 : nullptr))
+            return r;
+    }
+    return KNERF_OK;
+}
+
 int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     if (!ctx) return KNERF_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;

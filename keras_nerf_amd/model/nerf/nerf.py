@@ -235,10 +235,9 @@ class NeRF:
         ci = torch.empty((N, 3), device=self.device); fi = torch.empty((N, 3), device=self.device)
         self._loss_acc.zero_()
         seed = self._next_seed()
-        for i in range(C):                                                        # nerf.py:351-421
-            sl = slice(i * R, (i + 1) * R)
-            self._ctx.train_chunk(o[sl], d[sl], t[sl], tgt[sl], None if uf is None else uf[sl], seed, i * R, 1.0 / C,
-                                  self._loss_acc, ci[sl], fi[sl])
+        # the chunk loop of nerf.py:351-421 (C chunks of R rays, gradients and losses accumulated with weight 1/C) runs
+        # inside the library: one host call per step
+        self._ctx.train_batch(o, d, t, tgt, uf, seed, R, self._loss_acc, ci, fi)
         if self._dist:                                                            # nerf.py:455-458 under MirroredStrategy
             parallel.all_reduce_gradients(self._ctx.grads_view(), self.all_reduce)
         self._ctx.apply_adam()            # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471)

@@ -152,6 +152,14 @@ class KnerfContext:
                                                seed, ray_offset, t.shape[0], float(inv_chunks), _ptr(loss), _ptr(c_image),
                                                _ptr(f_image)))
 
+    def train_batch(self, o, d, t, target, u=None, seed=0, ray_chunks=None, loss=None, c_image=None, f_image=None):
+        """the whole chunk loop of one train step (all arrays [N,...]; N % ray_chunks == 0)"""
+        o, d, t, target = self.f32(o), self.f32(d), self.f32(t), self.f32(target)
+        u = None if u is None else self.f32(u)
+        n = t.shape[0]
+        self._check(self.lib.knerf_train_batch(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(target), _ptr(u), seed, n,
+                                               int(ray_chunks or n), _ptr(loss), _ptr(c_image), _ptr(f_image)))
+
     def apply_adam(self):
         self._check(self.lib.knerf_apply_adam(self._ctx, self._stream()))
 

@@ -166,3 +166,33 @@ def test_ragged_chunk_training_matches_oracle():
     assert ec[0] < 4e-2, ec
     assert abs(float(loss[0]) - float(lc)) < 2e-3
     ctx.close()
+
+
+@pytest.mark.parametrize("n_coarse,n_fine,white,oob", [(32, 64, False, "zero"), (48, 80, True, "clamp"), (64, 0, False, "zero")])
+def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
+    """sample counts other than 64+128 (the reference's own tests use 32), black background, clamp mode, and n_fine = 0"""
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = O.NerfConfig(n_coarse=n_coarse, n_fine=n_fine)
+    P = make_problem(n_images=1, wh=8, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    N = P["N"]
+    o, d, t, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["img"].reshape(N, 3)
+    u = P["u"].reshape(N, -1) if n_fine else None
+    ctx = KnerfContext(n_coarse=n_coarse, n_fine=n_fine, white_background=white, oob=oob)
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    ci, cd, cw = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
+    rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, white, emulate_bf16=True)
+    np.testing.assert_allclose(ci, rc["image"], atol=1e-2); np.testing.assert_allclose(cw, rc["weights"], atol=1e-2)
+    if n_fine == 0:
+        ctx.close(); return
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, u, loss=loss)
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:N * (n_coarse + n_fine)].reshape(N, n_coarse + n_fine)
+    np.testing.assert_array_equal(t_fine, O.fine_points(t, ctx.debug_buffer(6).view(torch.float32).cpu().numpy()[:N * n_coarse].reshape(N, n_coarse), u, oob))
+    _, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, white, emulate_bf16=True)
+    _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, white, emulate_bf16=True)
+    ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+    log_stats(f"config_{n_coarse}_{n_fine}_{white}_{oob}", coarse_worst=ec[0], fine_worst=ef[0])
+    assert ec[0] < 5e-2 and ef[0] < 5e-2, (ec, ef)
+    assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    ctx.close()
