@@ -1,0 +1,47 @@
+"""Race screen for the hand-synchronised kernels (LDS-DMA ring with counted vmcnt, staggered wave groups, inline-asm stores):
+the chain kernels contain no atomics, so at bench size their outputs and every saved block must be bit-identical from
+launch to launch; the sampler likewise.  Only the fp32-atomic gradient flush may differ in the last bits."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(t):
+    return hashlib.sha1(t.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()
+
+
+def test_chain_kernels_are_bit_reproducible_at_bench_size():
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    from keras_nerf_amd.runtime import KnerfContext
+    ctx = KnerfContext(white_background=True)
+    for net in (0, 1):
+        m = NeRFMLP(seed=net); m.build(); ctx.set_weights(net, m.get_flat_weights() * 1.5)
+    o, d, t = ctx.generate_rays(pose_spherical(33.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, 64), 64, 64, 2.0, 6.0,
+                                64, None, seed=3)
+    o, d, t = o.reshape(-1, 3), d.reshape(-1, 3), t.reshape(-1, 64)          # 4096 rays = one bench chunk
+    tgt = torch.rand((4096, 3), device="cuda")
+    u = torch.rand((4096, 128), device="cuda")
+    ref = None
+    for rep in range(6):
+        out = ctx.render_chunk(o, d, t, u)
+        dig = {k: _digest(v) for k, v in out.items()}
+        ctx.zero_grads()
+        ctx.train_chunk(o, d, t, tgt, u)
+        torch.cuda.synchronize()
+        n_tiles = 4096 * 192 // 32
+        for name, which, stride in (("act", 0, 158 * 1024 + 256), ("mask", 1, 8 * 1024 + 256), ("dz", 2, 156 * 1024 + 256)):
+            dig[name] = _digest(ctx.debug_buffer(which)[:n_tiles * stride])
+        dig["raw"] = _digest(ctx.debug_buffer(3)[:4096 * 192 * 16]); dig["draw"] = _digest(ctx.debug_buffer(4)[:4096 * 192 * 16])
+        g = ctx.grads_view().clone()
+        if ref is None:
+            ref, gref = dig, g
+        else:
+            assert dig == ref, [k for k in dig if dig[k] != ref[k]]
+            assert float((g - gref).abs().max()) <= 1e-5 * float(gref.abs().max())     # atomics: order only
+    assert float(gref.abs().max()) > 0
+    ctx.close()
