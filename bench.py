@@ -58,7 +58,7 @@ def make_batch(nerf, wh, batch, rank, seed=42):
     return images, (o, d, t)
 
 
-def cpu_baseline(n_rays=1024, chunk=512, repeats=3):
+def cpu_baseline(n_rays=512, chunk=256, repeats=3):
     """op-for-op torch-CPU restatement of the reference train step (oracle/torch_ref.py) on a bounded sample"""
     from oracle import nerf_oracle as O
     from oracle import torch_ref as T

@@ -27,7 +27,10 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 constexpr int kWaves = 8;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kTile = 32;                 // samples per wave
-constexpr int kPageBlocks = 16;           // 1 KiB blocks per ring page
+#ifndef KNERF_PAGE_BLOCKS
+#define KNERF_PAGE_BLOCKS 16
+#endif
+constexpr int kPageBlocks = KNERF_PAGE_BLOCKS;   // 1 KiB blocks per ring page
 constexpr int kPageBytes = kPageBlocks * 1024;
 #ifndef KNERF_SLOTS
 #define KNERF_SLOTS 6
@@ -225,8 +228,9 @@ struct Prefetch {
 };
 
 // number of ring barriers each group takes over a stream of NBLOCKS blocks (A: b = 8, 24, ...; B: b = 16, 32, ...)
-constexpr int barriers_a(int nblocks) { return nblocks > 8 ? (nblocks - 9) / kPageBlocks + 1 : 0; }
-constexpr int barriers_b(int nblocks) { return nblocks > 16 ? (nblocks - 17) / kPageBlocks + 1 : 0; }
+constexpr int barriers_a(int nblocks) { return nblocks > kPageBlocks / 2 ? (nblocks - kPageBlocks / 2 - 1) / kPageBlocks + 1 : 0; }
+constexpr int barriers_b(int nblocks) { return nblocks > kPageBlocks ? (nblocks - kPageBlocks - 1) / kPageBlocks + 1 : 0; }
+static_assert(kPrefetch <= kPageBlocks / 2 && kSlots >= 4 && kPageBlocks % 16 == 0, "ring geometry");
 // after its last block group B takes the barriers group A still has (the counts differ by at most one)
 template <int NBLOCKS>
 __device__ __forceinline__ void ring_finish(const Ring& ring, int grp) {
