@@ -120,6 +120,12 @@ int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weight
  * Classes: 0 mlp_fwd coarse, 1 mlp_fwd fine, 2 composite, 3 sample_fine, 4 mlp_bwd coarse, 5 mlp_bwd fine,
  * 6 wgrad coarse, 7 wgrad fine, 8 adam+repack.  read() synchronises the device, returns summed milliseconds and launch
  * counts since enable/the previous read (n >= 9). */
+/* Backward schedule.  producers = 0 (default): dgrad and wgrad are separate launches.  producers = P > 0: one launch of
+ * P persistent dgrad workgroups + (CUs - P) wgrad workgroups that consume dZ as it is published (fused_bwd.hip).  Results
+ * are the same up to fp32 summation order.  A poll time-out inside the fused launch is reported by knerf_apply_adam
+ * (KNERF_ERR_HIP); it cannot hang.  No reference counterpart (scheduling only). */
+int knerf_set_fused_backward(knerf_ctx* ctx, int producers);
+
 int knerf_profile_enable(knerf_ctx* ctx, int on);
 int knerf_profile_read(knerf_ctx* ctx, double* total_ms, int64_t* launches, int n);
 

@@ -41,6 +41,19 @@ struct WgradArgs {
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
 
+// dgrad + wgrad in one launch (fused_bwd.hip)
+struct FusedArgs {
+    BwdArgs bwd;
+    WgradArgs wgrad;          // plan = consumer workgroups only
+    unsigned* flags;          // one word per 256-sample workgroup tile; == epoch when that tile's dZ is published
+    int* abort_flag;          // raised by a consumer whose bounded poll timed out
+    long long n_wg_tiles;
+    unsigned epoch;           // launch counter (flags are never cleared)
+    int n_producers;
+    int debug;                // KNERF_FUSED_DEBUG bits: 1 consumers idle, 2 producers idle, 4 consumers ignore flags
+};
+hipError_t launch_bwd_wgrad(const FusedArgs& f, hipStream_t stream);
+
 struct CompositeArgs {
     const float* raw;       // [R,S,4]
     const float* t;         // [R,S]

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -65,7 +66,12 @@ struct knerf_ctx {
     float* grads = nullptr;
     Tables tab;
     int step = 0;
-    int* d_flag = nullptr;
+    int* d_flag = nullptr;             // [0] non-finite gradient, [1] fused backward poll time-out
+    // fused dgrad+wgrad launch (fused_bwd.hip): 0 = separate kernels
+    int fused_producers = 0, n_cu = 256;
+    int* d_fplan = nullptr; int n_fplan = 0;
+    unsigned* d_ready = nullptr; size_t ready_cap = 0;
+    unsigned epoch = 0;
     // workspaces (grow-only)
     int ws_rays = 0; bool ws_train = false;
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
@@ -152,6 +158,10 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
         HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
         HIPCHK(hipMemset(ctx->dz, 0, ctx->dz_bytes));     // blocks kDzSig+1 / kDzRgb+1 are never written and must read 0
         HIPCHK(hipMemset(ctx->act, 0, ctx->act_bytes));
+        free_dev(ctx->d_ready);
+        ctx->ready_cap = tiles / kWaves;
+        HIPCHK(hipMalloc(&ctx->d_ready, ctx->ready_cap * sizeof(unsigned)));
+        HIPCHK(hipMemset(ctx->d_ready, 0, ctx->ready_cap * sizeof(unsigned)));   // epochs start at 1
     }
     ctx->ws_rays = R; ctx->ws_train = train;
     return KNERF_OK;
@@ -197,13 +207,24 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
         ba.n_samples = fa.n_samples;
-        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
         wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
-        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F); HIPCHK(launch_wgrad(wa, s)); }
+        if (ctx->fused_producers > 0) {
+            FusedArgs f{};
+            f.bwd = ba; f.wgrad = wa; f.wgrad.plan = ctx->d_fplan; f.wgrad.n_plan = ctx->n_fplan;
+            f.flags = ctx->d_ready; f.abort_flag = ctx->d_flag + 1; f.n_wg_tiles = wa.n_tiles / kWaves;
+            f.epoch = ++ctx->epoch; f.n_producers = ctx->fused_producers;
+            if (const char* e = std::getenv("KNERF_FUSED_DEBUG")) f.debug = std::atoi(e);
+            if ((size_t)f.n_wg_tiles > ctx->ready_cap) return fail(ctx, KNERF_ERR_INVALID, "ready-flag buffer too small");
+            ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
+            HIPCHK(launch_bwd_wgrad(f, s));
+        } else {
+            { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
+            { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F); HIPCHK(launch_wgrad(wa, s)); }
+        }
     }
     return KNERF_OK;
 }
@@ -282,8 +303,9 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     }
     CREATECHK(hipMalloc(&ctx->grads, 2 * (size_t)kParamCount * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float)));
-    CREATECHK(hipMalloc(&ctx->d_flag, sizeof(int)));
-    CREATECHK(hipMemset(ctx->d_flag, 0, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->d_flag, 2 * sizeof(int)));
+    CREATECHK(hipMemset(ctx->d_flag, 0, 2 * sizeof(int)));
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
     for (int n = 0; n < 2; ++n) {
         Net& N = ctx->net[n];
@@ -302,6 +324,9 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         CREATECHK(hipMemset(N.bias, 0, kFwdBiasTiles * 32 * sizeof(float)));
     }
 #undef CREATECHK
+    if (const char* e = std::getenv("KNERF_FUSED_BWD")) {       // tuning override; the schedule is otherwise set by the host API
+        if (int r = knerf_set_fused_backward(ctx, std::atoi(e))) { g_create_error = ctx->err; knerf_destroy(ctx); return r; }
+    }
     *out = ctx;
     return KNERF_OK;
 }
@@ -312,7 +337,7 @@ int knerf_destroy(knerf_ctx* ctx) {
         Net& N = ctx->net[n];
         free_dev(N.w); free_dev(N.m); free_dev(N.v); free_dev(N.fwd_stream); free_dev(N.bwd_stream); free_dev(N.bias);
     }
-    free_dev(ctx->grads); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp);
+    free_dev(ctx->grads); free_dev(ctx->d_flag); free_dev(ctx->d_fplan); free_dev(ctx->d_ready); free_dev(ctx->loss_tmp);
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
@@ -431,10 +456,14 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     // finite check first so that a bad step leaves the weights untouched (reference aborts fit at nerf.py:381-382)
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
     HIPCHK(launch_check_finite(ctx->grads, 2 * kParamCount, ctx->d_flag, s));
-    int flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    int flag[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(flag, ctx->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (flag) return fail(ctx, KNERF_ERR_NONFINITE, "Gradient is not finite");
+    if (flag[1]) {
+        HIPCHK(hipMemsetAsync(ctx->d_flag + 1, 0, sizeof(int), s));
+        return fail(ctx, KNERF_ERR_HIP, "fused backward: a consumer timed out waiting for dZ (workgroups not co-resident?); gradients are invalid");
+    }
+    if (flag[0]) return fail(ctx, KNERF_ERR_NONFINITE, "Gradient is not finite");
     ctx->step += 1;
     const double b1 = ctx->cfg.beta1, b2 = ctx->cfg.beta2;
     const float lr_t = (float)((double)ctx->cfg.lr * std::sqrt(1.0 - std::pow(b2, ctx->step)) / (1.0 - std::pow(b1, ctx->step)));
@@ -446,6 +475,25 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         HIPCHK(launch_adam(a, s));
         if (int r = repack(ctx, n, s)) return r;
     }
+    return KNERF_OK;
+}
+
+int knerf_set_fused_backward(knerf_ctx* ctx, int producers) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (producers <= 0) { ctx->fused_producers = 0; return KNERF_OK; }
+    if (producers > ctx->n_cu - kWgradJobs) return fail(ctx, KNERF_ERR_INVALID, "producers must leave one workgroup per wgrad job");
+    // producers + consumers must all be resident at once: one 160 KiB-LDS workgroup per CU
+    std::vector<int32_t> plan;
+    for (int n_wg = ctx->n_cu - producers + 4; n_wg > 0; --n_wg) {
+        plan = build_wgrad_plan(n_wg);
+        if ((int)plan.size() / 4 <= ctx->n_cu - producers) break;
+    }
+    if (plan.empty() || (int)plan.size() / 4 > ctx->n_cu - producers) return fail(ctx, KNERF_ERR_INVALID, "no consumer plan fits");
+    free_dev(ctx->d_fplan);
+    HIPCHK(hipMalloc(&ctx->d_fplan, plan.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(ctx->d_fplan, plan.data(), plan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->n_fplan = (int)plan.size() / 4;
+    ctx->fused_producers = producers;
     return KNERF_OK;
 }
 

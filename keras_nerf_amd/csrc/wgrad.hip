@@ -1,236 +1,13 @@
-// wgrad.hip -- weight and bias gradients of one NeRF MLP from the saved activations and dZ blocks (gfx950).
-//
-// dW_l[in][out] += sum_samples act_l[s][in] * dz_l[s][out],  db_l[out] += sum_samples dz_l[s][out]
-// i.e. what tape.gradient(...) returns for the 24 trainable tensors at reference keras_nerf/model/nerf/nerf.py:376-377 /
-// 405-406, accumulated straight into the flat fp32 accumulator that nerf.py:383-384 / 412-413 maintain (the 1/C chunk
-// factor is already folded into dL/dimage by the compositing kernel).
-//
-// The contraction runs over SAMPLES, which the chain kernels keep on the lane axis, so both MFMA operands need the
-// transposed view.  The saved 1 KiB blocks are copied verbatim into LDS (LDS-DMA) and read back with
-// ds_read_b64_tr_b16: each lane ends up holding 8 consecutive samples of one feature.  HBM-bound by construction
-// (128 FLOP per byte at width 256): a workgroup owns one layer ("job") and a contiguous range of sample tiles, keeps
-// the layer's gradient in registers (one 32-column strip per wave) and adds it to global memory with fp32 atomics
-// once at the end.
-#include <hip/hip_runtime.h>
-#include "chain.h"
-#include "kernels.h"
-#include "layout.h"
+// wgrad.hip -- stand-alone launch of the weight-gradient jobs (wgrad_body.h): one workgroup per (job, contiguous tile range).
+#include "wgrad_body.h"
 
 namespace knerf {
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-constexpr int kWgThreads = 512, kWgWaves = 8;
-constexpr int kWgScratch = kWgWaves * 1024;   // landing zone of padding LDS-DMA copies (never read)
-
-// LDS-DMA of 16 B per lane, invisible to hipcc's wait-count pass (the builtin form makes it drain vmcnt(0) before
-// every transposed LDS read).  lds_dst = wave-uniform LDS byte address; completion is counted by hand (vmcnt).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-#ifndef KNERF_WGRAD_LOAD_POLICY
-#define KNERF_WGRAD_LOAD_POLICY "nt"     // once-read streams (measured -2.5 %)
-#endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
-
-#ifdef KNERF_WGRAD_STAMPS   // diagnostic build only (tools/kbench.py --stamps): per-workgroup cycle totals of the loop phases
-__device__ unsigned long long g_wgrad_stamps[1024 * 8];
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define STAMP(var) const unsigned long long var = stamp()
-#else
-#define STAMP(var)
-#endif
-
-struct WgradPlan {          // one entry per workgroup, built on the host (knerf_api.hip)
-    int job, split, nsplit, pad;
-};
-
-// 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
-// region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
-__device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, const int (&lane_off)[2]) {
-    const char* base = region + pair * 2048 + kk * 512;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[0]));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[1]));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-template <int NI, int NO>
-__device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
-                                               long long t0, long long t1, char* smem) {
-    constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
-    constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
-    constexpr int ROWS = NI + 1;
-    constexpr int NACC = (ROWS + WI - 1) / WI;
-    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO;
-    constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
-    constexpr int G_IN = (BLK_IN + kWgWaves - 1) / kWgWaves, G_DZ = (BLK_DZ + kWgWaves - 1) / kWgWaves;
-    constexpr int G = G_IN + G_DZ;                           // LDS-DMA instructions per wave per tile (uniform)
-    constexpr int NS = (160 * 1024 - kWgScratch) / TILE_BYTES >= 4 ? 4 : 3;
-    static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
-    static_assert(NO == WO, "one output tile per wave column");
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the per-wave tile branches uniform
-    const int wo = WO == 1 ? 0 : wave % WO, wi = WI == 1 ? 0 : wave / WO;
-    const unsigned smem_base = lds_addr(smem);
-    const unsigned scratch = smem_base + NS * TILE_BYTES + wave * 1024;
-
-    // per-lane offsets of the two transposed reads (see layout.h saved_off and the header of this file)
-    int lane_off[2];
-    {
-        const int grp = lane >> 4, par = grp & 1, h = grp >> 1, il = lane & 15, q = il >> 2, p = il & 3;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            lane_off[r] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8;
-    }
-
-    // per-wave source pointers of the next tile to stage (one per LDS-DMA round) and the matching LDS offsets; issue()
-    // stages tiles strictly in order, so the pointers simply advance by one tile stride per call
-    const char* p_in[G_IN]; const char* p_dz[G_DZ];
-    unsigned o_in[G_IN], o_dz[G_DZ];
-#pragma unroll
-    for (int r = 0; r < G_IN; ++r) {
-        const int b = r * kWgWaves + wave;
-        const bool ok = b < BLK_IN;
-        p_in[r] = a.act + (size_t)t0 * kActTileBytes + (size_t)(act_blk + (ok ? b : 0)) * 1024 + lane * 16;
-        o_in[r] = ok ? (unsigned)(b * 1024) : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int r = 0; r < G_DZ; ++r) {
-        const int b = r * kWgWaves + wave;
-        const bool ok = b < BLK_DZ;
-        p_dz[r] = a.dz + (size_t)t0 * kDzTileBytes + (size_t)(dz_blk + (ok ? b : 0)) * 1024 + lane * 16;
-        o_dz[r] = ok ? (unsigned)((BLK_IN + b) * 1024) : 0xFFFFFFFFu;
-    }
-    long long t_next = t0;
-    auto issue = [&](int slot) {
-        const unsigned dst = smem_base + slot * TILE_BYTES;
-#pragma unroll
-        for (int r = 0; r < G_IN; ++r)
-            glds16(p_in[r], __builtin_amdgcn_readfirstlane(o_in[r] != 0xFFFFFFFFu ? dst + o_in[r] : scratch));
-#pragma unroll
-        for (int r = 0; r < G_DZ; ++r)
-            glds16(p_dz[r], __builtin_amdgcn_readfirstlane(o_dz[r] != 0xFFFFFFFFu ? dst + o_dz[r] : scratch));
-        if (++t_next < t1) {             // tail: harmless re-read of the last tile keeps the vmcnt arithmetic uniform
-#pragma unroll
-            for (int r = 0; r < G_IN; ++r) p_in[r] += kActTileBytes;
-#pragma unroll
-            for (int r = 0; r < G_DZ; ++r) p_dz[r] += kDzTileBytes;
-        }
-    };
-
-    f32x16 acc[NACC];
-#pragma unroll
-    for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s);
-    int slot = 0;
-#ifdef KNERF_WGRAD_STAMPS
-    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
-#endif
-    for (long long t = t0; t < t1; ++t) {
-        STAMP(s0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile t landed (mine) ...
-        STAMP(s1);
-        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile t-1 is free
-        STAMP(s2);
-        int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
-        issue(nslot);
-        STAMP(s3);
-        const char* in_reg = smem + slot * TILE_BYTES;
-        const char* dz_reg = in_reg + BLK_IN * 1024;
-#ifdef KNERF_WGRAD_ABLATE_COMPUTE     // timing experiment only: pure streaming
-        if (t0 < 0)
-#endif
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
-            // branch-free rows: a wave whose row index is the bias row (it == NI) swaps in the all-ones tile, rows past
-            // it compute on a clamped (valid) tile and are dropped at the flush -- no control flow between the
-            // transposed reads, so they issue back to back
-            bf16x8 afr[NACC];
-#pragma unroll
-            for (int n = 0; n < NACC; ++n) {
-                const int it = wi + n * WI;
-                afr[n] = tr_frag(in_reg, it < NI ? it : NI - 1, kk, lane_off);
-                if (WI * NACC > NI && it >= NI) afr[n] = ones;
-            }
-#pragma unroll
-            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
-        }
-        slot = slot + 1 == NS ? 0 : slot + 1;
-#ifdef KNERF_WGRAD_STAMPS
-        STAMP(s4);
-        c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
-#endif
-    }
-#ifdef KNERF_WGRAD_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {
-        unsigned long long* o = g_wgrad_stamps + blockIdx.x * 8;
-        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = (unsigned long long)(t1 - t0); o[5] = job;
-    }
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // nobody may restage LDS for the next job while a wave still reads this one
-
-    // flush: acc[n] reg i of lane (c, hh) is dW[row 32*it + (i&3) + 8(i>>2) + 4hh][col 32*wo + c]
-    const int* dst = a.dst + a.job_off[job];
-    constexpr int NCOLS = NO * 32;
-    const int c = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int n = 0; n < NACC; ++n) {
-        const int it = wi + n * WI;
-        if (it < NI) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const int d = dst[row * NCOLS + 32 * wo + c];
-                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
-            }
-        } else if (it == NI) {
-            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
-            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
-        }
-    }
-}
 
 __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradPlan pl = reinterpret_cast<const WgradPlan*>(a.plan)[blockIdx.x];
-    const long long t0 = a.n_tiles * pl.split / pl.nsplit, t1 = a.n_tiles * (pl.split + 1) / pl.nsplit;
-    if (t0 >= t1) return;
-    switch (pl.job) {
-        case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, t0, t1, smem); break;
-        case 1: wgrad_job_body<8, 8>(a, 1, act_h(0), 16 * 1, t0, t1, smem); break;
-        case 2: wgrad_job_body<8, 8>(a, 2, act_h(1), 16 * 2, t0, t1, smem); break;
-        case 3: wgrad_job_body<8, 8>(a, 3, act_h(2), 16 * 3, t0, t1, smem); break;
-        case 4: wgrad_job_body<8, 8>(a, 4, act_h(3), 16 * 4, t0, t1, smem); break;
-        case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, t0, t1, smem); break;
-        case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, t0, t1, smem); break;
-        case 7: wgrad_job_body<8, 8>(a, 7, act_h(6), 16 * 7, t0, t1, smem); break;
-        case 8: wgrad_job_body<8, 8>(a, 8, kActH7, kDzFeat, t0, t1, smem); break;
-        case 9: wgrad_job_body<8, 1>(a, 9, kActH7, kDzSig, t0, t1, smem); break;
-        case 10: wgrad_job_body<9, 4>(a, 10, kActFeat, kDzF2, t0, t1, smem); break;
-        case 11: wgrad_job_body<4, 1>(a, 11, kActF2, kDzRgb, t0, t1, smem); break;
-        default: break;
-    }
+    const ContigSeq seq{a.n_tiles * pl.split / pl.nsplit, a.n_tiles * (pl.split + 1) / pl.nsplit};
+    wgrad_dispatch(a, pl.job, seq, smem);
 }
 
 #ifdef KNERF_WGRAD_STAMPS

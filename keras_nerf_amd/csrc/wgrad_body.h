@@ -1,0 +1,299 @@
+// wgrad_body.h -- weight and bias gradients of one NeRF MLP from the saved activations and dZ blocks (gfx950).
+//
+// dW_l[in][out] += sum_samples act_l[s][in] * dz_l[s][out],  db_l[out] += sum_samples dz_l[s][out]
+// i.e. what tape.gradient(...) returns for the 24 trainable tensors at reference keras_nerf/model/nerf/nerf.py:376-377 /
+// 405-406, accumulated straight into the flat fp32 accumulator that nerf.py:383-384 / 412-413 maintain (the 1/C chunk
+// factor is already folded into dL/dimage by the compositing kernel).
+//
+// The contraction runs over SAMPLES, which the chain kernels keep on the lane axis, so both MFMA operands need the
+// transposed view.  The saved 1 KiB blocks are copied verbatim into LDS (LDS-DMA) and read back with
+// ds_read_b64_tr_b16: each lane ends up holding 8 consecutive samples of one feature.  HBM-bound by construction
+// (128 FLOP per byte at width 256): a workgroup owns one layer ("job") and a contiguous range of sample tiles, keeps
+// the layer's gradient in registers (one 32-column strip per wave) and adds it to global memory with fp32 atomics
+// once at the end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "chain.h"
+#include "kernels.h"
+#include "layout.h"
+
+namespace knerf {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int kWgThreads = 512, kWgWaves = 8;
+constexpr int kWgScratch = kWgWaves * 1024;   // landing zone of padding LDS-DMA copies (never read)
+
+// LDS-DMA of 16 B per lane, invisible to hipcc's wait-count pass (the builtin form makes it drain vmcnt(0) before
+// every transposed LDS read).  lds_dst = wave-uniform LDS byte address; completion is counted by hand (vmcnt).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+#ifndef KNERF_WGRAD_LOAD_POLICY
+#define KNERF_WGRAD_LOAD_POLICY "nt"     // once-read streams (measured -2.5 %)
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// agent-scope coherent variant for data another workgroup of the SAME launch published (fused_bwd.hip): sc1 re-validates
+// the line past this XCD's L2, which may still hold the previous pass's copy of the same dZ address
+__device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+#ifdef KNERF_WGRAD_STAMPS   // diagnostic build only (tools/kbench.py --stamps): per-workgroup cycle totals of the loop phases
+__device__ unsigned long long g_wgrad_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp()
+#else
+#define STAMP(var)
+#endif
+
+struct WgradPlan {          // one entry per workgroup, built on the host (knerf_api.hip)
+    int job, split, nsplit, pad;
+};
+
+// 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
+// region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
+__device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, const int (&lane_off)[2]) {
+    const char* base = region + pair * 2048 + kk * 512;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[0]));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[1]));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- tile sequences -------------------------------------------------------------------------------------------------
+// The job body walks `count()` sample tiles; tile(i) is the global sample-tile index of the i-th one.
+struct ContigSeq {                       // stand-alone wgrad kernel: a contiguous range [t0, t1)
+    static constexpr bool kFlags = false;
+    long long t0, t1;
+    __device__ __forceinline__ long long count() const { return t1 - t0; }
+    __device__ __forceinline__ long long tile(long long i) const { return t0 + i; }
+    __device__ __forceinline__ const unsigned* flag(long long) const { return nullptr; }
+};
+struct FusedSeq {                        // fused dgrad+wgrad launch: every nsplit-th workgroup tile (8 sample tiles each),
+    static constexpr bool kFlags = true; // so that all consumers follow the producers' frontier; one ready flag per workgroup tile
+    int split, nsplit;
+    long long n_wg_tiles;
+    const unsigned* flags;
+    unsigned epoch;
+    int* abort_flag;
+    int ignore_flags;                    // timing experiments only (KNERF_FUSED_DEBUG): results are then undefined
+    __device__ __forceinline__ long long count() const {
+        return split < n_wg_tiles ? ((n_wg_tiles - split + nsplit - 1) / nsplit) * kWaves : 0;
+    }
+    __device__ __forceinline__ long long wg_tile(long long i) const { return split + (i >> 3) * nsplit; }
+    __device__ __forceinline__ long long tile(long long i) const { return wg_tile(i) * kWaves + (i & 7); }
+    __device__ __forceinline__ const unsigned* flag(long long i) const { return flags + wg_tile(i); }
+};
+
+// 4-byte LDS-DMA of a flag word (every lane copies the same word): rides the tile DMA's vmcnt queue
+__device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// blocking poll (slow path, drains this wave's DMA queue): bounded, never hangs -- on time-out the abort flag is raised
+// and the caller proceeds (the host reports the launch as failed)
+__device__ __forceinline__ void poll_flag_blocking(const unsigned* f, unsigned epoch, int* abort_flag) {
+    for (int n = 0; n < (1 << 18); ++n) {            // ~0.5 s at 2 us per poll
+        unsigned v, ab;
+        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v), "=&v"(ab) : "v"(f), "v"(abort_flag) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) == epoch) return;
+        if (__builtin_amdgcn_readfirstlane(ab) != 0) return;     // somebody timed out: the launch has failed, just finish
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if ((threadIdx.x & 63) == 0) atomicExch(abort_flag, 1);
+}
+
+template <int NI, int NO, class Seq>
+__device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
+                                               const Seq seq, char* smem) {
+    constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
+    constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
+    constexpr int ROWS = NI + 1;
+    constexpr int NACC = (ROWS + WI - 1) / WI;
+    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO;
+    constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
+    constexpr int G_IN = (BLK_IN + kWgWaves - 1) / kWgWaves, G_DZ = (BLK_DZ + kWgWaves - 1) / kWgWaves;
+    constexpr int G = G_IN + G_DZ + (Seq::kFlags ? 1 : 0);   // LDS-DMA instructions per wave per iteration (uniform)
+    constexpr int kFlagLds = Seq::kFlags ? kWgWaves * 4 * 256 : 0;   // per wave 4 slots of 64 lanes x 4 B
+    constexpr int NS = (160 * 1024 - kWgScratch - kFlagLds) / TILE_BYTES >= 4 ? 4 : 3;
+    static_assert(NS * TILE_BYTES + kWgScratch + kFlagLds <= 160 * 1024, "LDS budget");
+    static_assert(NO == WO, "one output tile per wave column");
+
+    const long long cnt = seq.count();
+    if (cnt <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the per-wave tile branches uniform
+    const int wo = WO == 1 ? 0 : wave % WO, wi = WI == 1 ? 0 : wave / WO;
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned scratch = smem_base + NS * TILE_BYTES + wave * 1024;
+    const unsigned flag_lds = smem_base + NS * TILE_BYTES + kWgScratch + wave * 1024;   // 4 slots x 256 B
+    const char* flag_lds_ptr = smem + NS * TILE_BYTES + kWgScratch + wave * 1024;
+
+    // per-lane offsets of the two transposed reads (see layout.h saved_off and the header of this file)
+    int lane_off[2];
+    {
+        const int grp = lane >> 4, par = grp & 1, h = grp >> 1, il = lane & 15, q = il >> 2, p = il & 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            lane_off[r] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8;
+    }
+
+    // stage sample tile number i (clamped at the end: a harmless re-read keeps the vmcnt arithmetic uniform) into `slot`
+    auto issue = [&](long long i, int slot) {
+        const long long t = seq.tile(i < cnt ? i : cnt - 1);
+        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)act_blk * 1024 + lane * 16;
+        const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)dz_blk * 1024 + lane * 16;
+        const unsigned dst = smem_base + slot * TILE_BYTES;
+#pragma unroll
+        for (int r = 0; r < G_IN; ++r) {
+            const int b = r * kWgWaves + wave;
+            const bool ok = b < BLK_IN;
+            glds16(src_in + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch));
+        }
+#pragma unroll
+        for (int r = 0; r < G_DZ; ++r) {
+            const int b = r * kWgWaves + wave;
+            const bool ok = b < BLK_DZ;
+            const unsigned to = __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch);
+            if constexpr (Seq::kFlags) glds16_sc1(src_dz + (ok ? b : 0) * 1024, to);
+            else glds16(src_dz + (ok ? b : 0) * 1024, to);
+        }
+    };
+    // pre-load the ready flag of the workgroup tile that sample tile i belongs to (checked 3 iterations later)
+    auto preload_flag = [&](long long i) {
+        if constexpr (Seq::kFlags) glds4_sc1(seq.flag(i < cnt ? i : cnt - 1), flag_lds + (unsigned)((i & 3) * 256));
+    };
+    auto check_flag = [&](long long i) {
+        if constexpr (Seq::kFlags) {
+            // one flag per workgroup tile = 8 consecutive sample tiles of this sequence: look only at its first one (an
+            // LDS read in front of the DMA issue costs ~1000 cycles per iteration under this kernel's LDS load)
+            if ((i & (kWaves - 1)) == 0) {
+                const unsigned v = *reinterpret_cast<const volatile unsigned*>(flag_lds_ptr + (i & 3) * 256 + lane * 4);
+                if (__builtin_amdgcn_readfirstlane(v) != seq.epoch && !seq.ignore_flags) poll_flag_blocking(seq.flag(i < cnt ? i : cnt - 1), seq.epoch, seq.abort_flag);
+            }
+        }
+    };
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    // prologue: tiles 0..NS-2 (their flags are polled the slow way), flag pre-loads for tiles NS-1..NS+1
+    if constexpr (Seq::kFlags) {
+        if (!seq.ignore_flags) poll_flag_blocking(seq.flag(0), seq.epoch, seq.abort_flag);
+    }
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) { issue(s, s); preload_flag(s + NS - 1); }
+    int slot = 0;
+#ifdef KNERF_WGRAD_STAMPS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
+#endif
+    for (long long i = 0; i < cnt; ++i) {
+        STAMP(s0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile i landed (mine) ...
+        STAMP(s1);
+        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
+        STAMP(s2);
+        int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
+        check_flag(i + NS - 1);                 // pre-loaded NS-1 iterations ago, retired by the wait above
+        issue(i + NS - 1, nslot);
+        preload_flag(i + 2 * (NS - 1));
+        STAMP(s3);
+        const char* in_reg = smem + slot * TILE_BYTES;
+        const char* dz_reg = in_reg + BLK_IN * 1024;
+#ifdef KNERF_WGRAD_ABLATE_COMPUTE     // timing experiment only: pure streaming
+        if (cnt < 0)
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
+            // branch-free rows: a wave whose row index is the bias row (it == NI) swaps in the all-ones tile, rows past
+            // it compute on a clamped (valid) tile and are dropped at the flush -- no control flow between the
+            // transposed reads, so they issue back to back
+            bf16x8 afr[NACC];
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) {
+                const int it = wi + n * WI;
+                afr[n] = tr_frag(in_reg, it < NI ? it : NI - 1, kk, lane_off);
+                if (WI * NACC > NI && it >= NI) afr[n] = ones;
+            }
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+#ifdef KNERF_WGRAD_STAMPS
+        STAMP(s4);
+        c_wait += s1 - s0; c_bar += s2 - s1; c_issue += s3 - s2; c_comp += s4 - s3;
+#endif
+    }
+#ifdef KNERF_WGRAD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_wgrad_stamps + blockIdx.x * 8;
+        o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = (unsigned long long)cnt; o[5] = job;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // nobody may restage LDS for the next job while a wave still reads this one
+
+    // flush: acc[n] reg i of lane (c, hh) is dW[row 32*it + (i&3) + 8(i>>2) + 4hh][col 32*wo + c]
+    const int* dst = a.dst + a.job_off[job];
+    constexpr int NCOLS = NO * 32;
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        const int it = wi + n * WI;
+        if (it < NI) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int d = dst[row * NCOLS + 32 * wo + c];
+                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
+            }
+        } else if (it == NI) {
+            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
+            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
+        }
+    }
+}
+
+// one job of the plan over the given tile sequence
+template <class Seq>
+__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const Seq& seq, char* smem) {
+    switch (job) {
+        case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, seq, smem); break;
+        case 1: wgrad_job_body<8, 8>(a, 1, act_h(0), 16 * 1, seq, smem); break;
+        case 2: wgrad_job_body<8, 8>(a, 2, act_h(1), 16 * 2, seq, smem); break;
+        case 3: wgrad_job_body<8, 8>(a, 3, act_h(2), 16 * 3, seq, smem); break;
+        case 4: wgrad_job_body<8, 8>(a, 4, act_h(3), 16 * 4, seq, smem); break;
+        case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, seq, smem); break;
+        case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, seq, smem); break;
+        case 7: wgrad_job_body<8, 8>(a, 7, act_h(6), 16 * 7, seq, smem); break;
+        case 8: wgrad_job_body<8, 8>(a, 8, kActH7, kDzFeat, seq, smem); break;
+        case 9: wgrad_job_body<8, 1>(a, 9, kActH7, kDzSig, seq, smem); break;
+        case 10: wgrad_job_body<9, 4>(a, 10, kActFeat, kDzF2, seq, smem); break;
+        case 11: wgrad_job_body<4, 1>(a, 11, kActF2, kDzRgb, seq, smem); break;
+        default: break;
+    }
+}
+
+}  // namespace knerf

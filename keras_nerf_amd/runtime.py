@@ -163,6 +163,10 @@ class KnerfContext:
     def apply_adam(self):
         self._check(self.lib.knerf_apply_adam(self._ctx, self._stream()))
 
+    def set_fused_backward(self, producers: int):
+        """0: dgrad and wgrad as separate launches; P>0: one launch, P persistent dgrad workgroups feeding the wgrad ones."""
+        self._check(self.lib.knerf_set_fused_backward(self._ctx, int(producers)))
+
     def zero_grads(self):
         self._check(self.lib.knerf_zero_grads(self._ctx, self._stream()))
 

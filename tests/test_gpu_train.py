@@ -196,3 +196,27 @@ def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
     assert ec[0] < 5e-2 and ef[0] < 5e-2, (ec, ef)
     assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
     ctx.close()
+
+
+@pytest.mark.parametrize("producers,rays", [(96, 256), (200, 256), (16, 101)])
+def test_fused_backward_schedule_matches_separate_kernels(producers, rays):
+    """knerf_set_fused_backward: one launch of persistent dgrad producers + wgrad consumers.  Same products, only the fp32
+    atomic summation order differs; a poll time-out would surface as an error from apply_adam."""
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+    ctx = new_ctx(P)
+    o, d, t, u, img = (x[:rays] for x in flat(P))
+    loss = torch.zeros(2, device="cuda")
+    grads = []
+    for p in (0, producers, producers):          # run the fused launch twice: ready flags carry epochs across launches
+        ctx.set_fused_backward(p)
+        ctx.zero_grads(); loss.zero_()
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss)
+        torch.cuda.synchronize()
+        grads.append(ctx.grads_view().cpu().numpy().copy())
+    scale = np.abs(grads[0]).max()
+    for g in grads[1:]:
+        assert np.abs(g - grads[0]).max() / scale < 1e-5
+    ctx.apply_adam()                             # raises KnerfError if a consumer timed out
+    with pytest.raises(Exception):
+        ctx.set_fused_backward(1000)             # must leave one workgroup per wgrad job
+    ctx.close()
