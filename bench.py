@@ -85,6 +85,21 @@ def cpu_baseline(n_rays=512, chunk=256, repeats=3):
             "s_per_step": med}
 
 
+def sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(elapsed, world):
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    return elapsed
+
+
 def bench_render(args, world, rank, wh, chunks, desc):
     """cfg5: frames/s of the 360-degree render loop of the reference's inference.py:62-114 (theta sweep at phi=-30,
     radius 4; rays generated on the device; fine image + depth copied to the host per frame as the reference does)."""
@@ -104,12 +119,12 @@ def bench_render(args, world, rank, wh, chunks, desc):
         return fine["image"].cpu().numpy(), fine["depth"].cpu().numpy()
     for i in range(args.warmup):
         frame(i)
-    torch.cuda.synchronize()
+    sync(world)
     t0 = time.perf_counter()
     for i in range(n_frames):
         img, dep = frame(args.warmup + i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
     fps = world * n_frames / elapsed
     rs = fps * wh * wh * 256
     roofline = None
@@ -167,15 +182,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible (RCCL needs one GPU per rank)")
+    device_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            torch.distributed.init_process_group(backend)
 
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
     if args.config == "cfg5":
-        return bench_render(args, world, rank, wh, chunks, desc)
+        bench_render(args, world, rank, wh, chunks, desc)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     nerf = NeRF(seed=0)
     nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
                  white_background=True)
@@ -183,32 +210,26 @@ def main():
     n_rays = batch * wh * wh
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         nerf.train_step(data, with_metrics=False)
-    sync()
+    sync(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nerf.train_step(data, with_metrics=False)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
+    sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
     value = world * n_rays * samples_per_ray * args.steps / elapsed
 
     roofline = None
-    if rank == 0 and not args.no_profile:
-        nerf._ctx.profile_enable(True)
-        nerf._ctx.profile_read()
+    if not args.no_profile:
+        # every rank takes the two extra steps (train_step all-reduces); only rank 0 records HIP events around its kernels
+        if rank == 0:
+            nerf._ctx.profile_enable(True)
+            nerf._ctx.profile_read()
         for _ in range(2):
             nerf.train_step(data, with_metrics=False)
+        sync(world)
+    if rank == 0 and not args.no_profile:
         prof = nerf._ctx.profile_read()
         nerf._ctx.profile_enable(False)
         total = sum(ms for ms, _ in prof.values())
