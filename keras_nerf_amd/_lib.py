@@ -24,6 +24,7 @@ _F = C.c_void_p  # device float* passed as integers (tensor.data_ptr())
 # name -> (restype, argtypes): exactly the declarations of include/knerf.h
 SIGNATURES = {
     "knerf_param_count": (C.c_size_t, []),
+    "knerf_param_count_for": (C.c_size_t, [_P]),
     "knerf_create": (C.c_int, [C.POINTER(KnerfConfig), C.POINTER(_P)]),
     "knerf_destroy": (C.c_int, [_P]),
     "knerf_last_error": (C.c_char_p, [_P]),

@@ -8,9 +8,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libknerf_hip.so")
-SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "fused_bwd.hip", "composite.hip", "sampler.hip", "optim.hip",
+SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "fused_bwd.hip", "generic.hip", "composite.hip", "sampler.hip", "optim.hip",
            "raygen.hip", "probe.hip", "utils_ops.hip"]
-HEADERS = ["chain.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", os.path.join("..", "..", "include", "knerf.h")]
+HEADERS = ["chain.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h")]
 # -ffp-contract=off: the parity-critical fp32 arithmetic (ray points, sampler, compositing) must round like the
 # reference's separate mul/add ops; fused multiply-adds are written explicitly (__builtin_fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]

@@ -1,0 +1,74 @@
+// generic.h -- the general-shape MLP path (any n_layers / dense_units / skip_layer / pos_emb_*), gfx950.
+//
+// The fused chain kernels (mlp_fwd/mlp_bwd/wgrad) are specialised for the reference's default NeRFMLP (8 x 256, skip 4,
+// L = 10/4; reference mlp.py:4-50 with the constructor defaults of nerf.py:11-14).  Every other shape the reference's
+// constructor and CLI accept (train_single.py:30-36) runs here: one MFMA GEMM launch per Dense layer over row-major bf16
+// activations in HBM, same numerics contract as the fused path (bf16 matmul operands, fp32 accumulate, fp32 bias and
+// activation), same compositing / sampling / Adam kernels around it.  This path is about coverage, not peak speed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace knerf {
+namespace gen {
+
+struct Seg { int col0, width, wrow0; };      // input-buffer columns [col0, col0+width) <- Keras kernel rows [wrow0, ...)
+
+struct Layer {
+    int w_off, b_off;          // offsets of kernel / bias in the net's flat fp32 parameter vector (Keras order)
+    int k_real, n_real;        // Keras kernel shape
+    int n_seg; Seg seg[2];     // where the kernel's rows sit in the (padded, possibly concatenated) input buffer
+    int in_buf;                // activation buffer read by this layer; its ld is the GEMM K
+    int out_buf, out_col0;     // bf16 output buffer (+ first column), or out_buf < 0: fp32 head output `head`
+    int head;                  // 0 sigma, 1 rgb (fp32 [M,32] outputs), -1 otherwise
+    int np;                    // n_real rounded up to 32
+    int relu;
+    size_t wt_off;             // packed Wt [np][K]      (forward:  out = in . Wt^T)
+    size_t wd_off; int wd_ld, wd_col0;   // packed Wd [K][wd_ld] (dgrad: d_in = d_out . Wd^T), this layer's columns at wd_col0
+    int dz_buf, dz_col0;       // where this layer's dZ lives
+};
+
+struct Plan {
+    int n_layers, units, skip, lx, ld;
+    int xyz_dim, dir_dim, kxp, kdp, up, u2p;
+    int n_params;
+    std::vector<Layer> layers;           // Keras order: layer_0..n-1, sigma, features, rgb_features, rgb
+    std::vector<int> buf_ld;             // activation buffers (bf16, [Mp][ld])
+    std::vector<int> dz_ld;              // dZ buffers (bf16, [Mp][ld])
+    std::vector<int> concat_after;       // per trunk layer: 1 if [h ; xyz_enc] follows it
+    int buf_encx, buf_encd, buf_fcat, buf_f2, buf_trunk;
+    int dz_c, dz_head, dz_r;
+    size_t packed_elems;                 // bf16 elements of the packed-weight arena
+    size_t act_elems_per_row, dz_elems_per_row;
+};
+
+bool is_default_shape(int n_layers, int units, int skip, int lx, int ld);
+int param_count(int n_layers, int units, int skip, int lx, int ld);
+Plan build_plan(int n_layers, int units, int skip, int lx, int ld);
+
+struct Workspace {             // per context, grow-only; Mp = padded sample count
+    size_t mp = 0;
+    unsigned short* act = nullptr;     // all activation buffers, buffer b at act + off_b * mp
+    unsigned short* dz = nullptr;
+    float* zs = nullptr;               // [Mp][32] sigma pre-activation
+    float* zc = nullptr;               // [Mp][32] rgb pre-activation
+};
+
+struct NetDev {                // per net
+    unsigned short* packed = nullptr;  // packed bf16 weights (Wt and Wd of every layer)
+};
+
+// All functions enqueue on `s` and return the first HIP error.
+hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* packed, hipStream_t s);
+// forward over n = R*S samples: fills raw [n][4] (rgb after sigmoid, sigma after relu); keeps activations for backward
+hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
+                   const float* t, long long n, int S, float* raw, hipStream_t s);
+// backward from draw [n][4] (dL/d rgb, dL/d sigma): accumulates into grad_flat (fp32 atomics)
+hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
+                    float* grad_flat, hipStream_t s);
+size_t padded_rows(long long n);
+
+}  // namespace gen
+}  // namespace knerf

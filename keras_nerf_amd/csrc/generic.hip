@@ -1,0 +1,497 @@
+// generic.hip -- general-shape NeRFMLP forward / backward on gfx950 (see generic.h).
+//
+// Reference semantics restated: NeRFMLP.call (mlp.py:29-50): relu Dense x n_layers with [h ; xyz_enc] concatenated after
+// layer i when i % skip == 0 and i > 0; sigma = relu(Dense(1)); features = Dense(units); [features ; dir_enc];
+// rgb_features = Dense(units/2) (linear); rgb = sigmoid(Dense(3)).  Inputs: NeRFUtils.encode_position_and_directions
+// (utils.py:188-210).  Backward is the chain rule of that graph (tape.gradient at nerf.py:370-377).
+//
+// Layout: every activation is a row-major bf16 matrix [Mp][ld] (one row per ray sample, Mp = samples rounded up to 128,
+// every segment padded to a multiple of 32 columns with zeros), so that both MFMA operands of `out = in . W` are
+// K-contiguous 16-byte loads: A fragment = 8 consecutive features of a sample, B fragment = 8 consecutive input weights
+// of an output unit (weights are packed transposed, Wt[out][in]).  dgrad uses the same kernel with Wd[in][out].
+// wgrad contracts over samples (the row index of both operands): each 32x32 block is transposed in registers by two MFMAs
+// against identity fragments -- D = A.[I|0] + A'.[0|I] leaves lane = feature, registers = samples, which is an MFMA
+// operand with a fixed sample permutation shared by both factors -- so no LDS and no workgroup barrier is involved.
+#include "generic.h"
+
+#include <cmath>
+
+namespace knerf {
+namespace gen {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short u16;
+
+namespace {
+
+constexpr int r32(int v) { return (v + 31) / 32 * 32; }
+
+__device__ __forceinline__ u16 to_bf16(float v) {
+    const __bf16 b = (__bf16)v;                       // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---- positional encoding (utils.py:176-210): rows [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] --------
+__global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ t,
+                                                    long long n, long long mp, int S, int lx, int ld, u16* __restrict__ ex, int kxp,
+                                                    u16* __restrict__ ed, int kdp) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= mp) return;
+    u16* rx = ex + (size_t)m * kxp;
+    u16* rd = ed + (size_t)m * kdp;
+    if (m >= n) {
+        for (int c = 0; c < kxp; ++c) rx[c] = 0;
+        for (int c = 0; c < kdp; ++c) rd[c] = 0;
+        return;
+    }
+    const long long ray = m / S;
+    const float tv = t[m];
+    float p[3], dv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dv[c] = d[ray * 3 + c];
+        p[c] = __fadd_rn(o[ray * 3 + c], __fmul_rn(dv[c], tv));       // o + d*t, separate mul and add like the reference
+    }
+    int col = 0;
+    for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(p[c]);
+    float f = 1.f;
+    for (int l = 0; l < lx; ++l, f *= 2.f) {
+        for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(sinf(f * p[c]));
+        for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(cosf(f * p[c]));
+    }
+    for (; col < kxp; ++col) rx[col] = 0;
+    col = 0;
+    for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(dv[c]);
+    f = 1.f;
+    for (int l = 0; l < ld; ++l, f *= 2.f) {
+        for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(sinf(f * dv[c]));
+        for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(cosf(f * dv[c]));
+    }
+    for (; col < kdp; ++col) rd[col] = 0;
+}
+
+// dst[:, 0:cols) = src[:, 0:cols)   (cols multiple of 8, 16-byte granules): the concat halves
+__global__ __launch_bounds__(256) void copy_cols_kernel(const u16* __restrict__ src, int lds, u16* __restrict__ dst, int ldd, long long rows, int cols) {
+    const int per_row = cols / 8;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const long long r = i / per_row;
+    const int c = (int)(i % per_row) * 8;
+    *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + c) = *reinterpret_cast<const uint4*>(src + (size_t)r * lds + c);
+}
+
+// ---- C[M][N] = A[M][K] . Bt[N][K]^T (+bias) (relu) (* [aux > 0]) -----------------------------------------------------
+struct GemmArgs {
+    const u16* A; int lda;
+    const u16* Bt; int ldb;
+    long long M; int N, K;
+    const float* bias; int n_real;       // bias[col] for col < n_real (fp32 master weights), else 0
+    int relu;
+    const u16* aux; int ldaux;           // optional relu mask source (the saved post-relu activation)
+    u16* Cb; int ldc;                    // bf16 output (may be null)
+    float* Cf; int ldcf;                 // fp32 output (may be null)
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= g.M) return;
+    const int n0 = blockIdx.y * NT * 32;
+    const u16* A = g.A + (size_t)(m0 + r) * g.lda + 8 * h;
+    const u16* B = g.Bt + (size_t)(n0 + r) * g.ldb + 8 * h;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16();
+    for (int k = 0; k < g.K; k += 16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + (size_t)t * 32 * g.ldb + k);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 32 * t + r;
+        const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long long row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float v = acc[t][i] + b;
+            if (g.relu) v = fmaxf(v, 0.f);
+            if (g.aux) { const short a = (short)g.aux[(size_t)row * g.ldaux + col]; v = a > 0 ? v : 0.f; }
+            if (g.Cb) g.Cb[(size_t)row * g.ldc + col] = to_bf16(v);
+            if (g.Cf) g.Cf[(size_t)row * g.ldcf + col] = v;
+        }
+    }
+}
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+    const int nt = g.N / 32;
+    const dim3 block(256);
+    const unsigned gx = (unsigned)((g.M + 127) / 128);
+    if (nt % 8 == 0) hipLaunchKernelGGL(gemm_kernel<8>, dim3(gx, nt / 8), block, 0, s, g);
+    else if (nt % 4 == 0) hipLaunchKernelGGL(gemm_kernel<4>, dim3(gx, nt / 4), block, 0, s, g);
+    else if (nt % 2 == 0) hipLaunchKernelGGL(gemm_kernel<2>, dim3(gx, nt / 2), block, 0, s, g);
+    else hipLaunchKernelGGL(gemm_kernel<1>, dim3(gx, nt), block, 0, s, g);
+    return hipGetLastError();
+}
+
+// ---- heads ----------------------------------------------------------------------------------------------------------
+// raw[m] = (sigmoid(zc[m][0..2]), relu(zs[m][0]))   (mlp.py:44-49)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ zc, long long n, float* __restrict__ raw) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n) return;
+    float4 v;
+    v.x = 1.f / (1.f + expf(-zc[m * 32 + 0]));
+    v.y = 1.f / (1.f + expf(-zc[m * 32 + 1]));
+    v.z = 1.f / (1.f + expf(-zc[m * 32 + 2]));
+    v.w = fmaxf(zs[m * 32], 0.f);
+    reinterpret_cast<float4*>(raw)[m] = v;
+}
+// dZ_rgb = d_rgb * y (1 - y) (sigmoid), dZ_sigma = d_sigma * [sigma > 0] (relu); rows >= n and padding columns are zero
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ draw, long long n, long long mp,
+                                                      u16* __restrict__ dzc, u16* __restrict__ dzs, int ld_s) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= mp) return;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < n) {
+        const float4 y = reinterpret_cast<const float4*>(raw)[m];
+        const float4 dy = reinterpret_cast<const float4*>(draw)[m];
+        g[0] = dy.x * y.x * (1.f - y.x);
+        g[1] = dy.y * y.y * (1.f - y.y);
+        g[2] = dy.z * y.z * (1.f - y.z);
+        g[3] = y.w > 0.f ? dy.w : 0.f;
+    }
+    u16* rc = dzc + (size_t)m * 32;
+    u16* rs = dzs + (size_t)m * ld_s;
+    for (int c = 0; c < 32; ++c) { rc[c] = c < 3 ? to_bf16(g[c]) : 0; rs[c] = c == 0 ? to_bf16(g[3]) : 0; }
+}
+
+// ---- weight packing -------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w;             // flat fp32 parameters of the net
+    u16* dst;
+    int w_off, n_real;          // kernel[k][n] = w[w_off + k * n_real + n]
+    int K, np;                  // padded input width (buffer ld), padded output width
+    int n_seg; Seg seg[2];
+    int transpose;              // 0: dst[n][k] (ld K)   1: dst[k][col0 + n] (ld ldd)
+    int ldd, col0;
+};
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.K * a.np) return;
+    const int n = (int)(i / a.K), kc = (int)(i % a.K);
+    int wrow = -1;
+    for (int s = 0; s < a.n_seg; ++s)
+        if (kc >= a.seg[s].col0 && kc < a.seg[s].col0 + a.seg[s].width) wrow = a.seg[s].wrow0 + kc - a.seg[s].col0;
+    const float v = (wrow >= 0 && n < a.n_real) ? a.w[a.w_off + (size_t)wrow * a.n_real + n] : 0.f;
+    if (a.transpose) a.dst[(size_t)kc * a.ldd + a.col0 + n] = to_bf16(v);
+    else a.dst[(size_t)n * a.K + kc] = to_bf16(v);
+}
+
+// ---- wgrad: dW[k][n] += sum_m X[m][k] dZ[m][n], db[n] += sum_m dZ[m][n] -----------------------------------------------
+struct WgradArgs {
+    const u16* X; int ldx;
+    const u16* Z; int ldz;
+    long long steps;            // Mp / 32
+    float* grad;                // flat fp32 gradient of the net
+    int w_off, b_off, n_real;
+    int n_seg; Seg seg[2];
+};
+
+// 32 samples x 32 features at P (row-major, ld) -> two operand fragments with lane = feature:
+// f[0] = samples sigma(hh, j) (first 16), f[1] = 16 + sigma(hh, j), sigma(hh, j) = (j&3) + 8(j>>2) + 4hh.
+__device__ __forceinline__ void transpose_tile(const u16* P, int ld, int r, int h, const bf16x8& ilo, const bf16x8& ihi, bf16x8 (&f)[2], float* colsum) {
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 8 * h);
+    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 16 + 8 * h);
+    f32x16 T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ilo, zero16(), 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ihi, T, 0, 0, 0);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float lo = T[j], hi = T[8 + j];
+        f[0][j] = (__bf16)lo;              // exact: the values are bf16 times one
+        f[1][j] = (__bf16)hi;
+        s += lo + hi;
+    }
+    if (colsum) *colsum += s;
+}
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * KT * 32, n0 = blockIdx.y * NT * 32;
+    bf16x8 ilo, ihi;          // B[k][c] = [k == c] for c < 16 / [k == c - 16] for c >= 16, k = 8h + j
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ilo[j] = (__bf16)((8 * h + j == r) ? 1.f : 0.f);
+        ihi[j] = (__bf16)((8 * h + j == r - 16) ? 1.f : 0.f);
+    }
+    f32x16 acc[KT][NT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = zero16();
+    float bsum[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bsum[b] = 0.f;
+    const bool do_bias = blockIdx.x == 0;
+    for (long long s = (long long)blockIdx.z * 4 + wave; s < g.steps; s += (long long)gridDim.z * 4) {
+        const u16* X = g.X + (size_t)s * 32 * g.ldx + k0;
+        const u16* Z = g.Z + (size_t)s * 32 * g.ldz + n0;
+        bf16x8 xa[KT][2], zb[NT][2];
+#pragma unroll
+        for (int a = 0; a < KT; ++a) transpose_tile(X + 32 * a, g.ldx, r, h, ilo, ihi, xa[a], nullptr);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) transpose_tile(Z + 32 * b, g.ldz, r, h, ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][0], zb[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][1], zb[b][1], acc[a][b], 0, 0, 0);
+            }
+    }
+    // flush: lane (col = r, hh = h), register i -> input column k0 + 32a + (i&3) + 8(i>>2) + 4hh
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int col = n0 + 32 * b + r;
+        if (col >= g.n_real) continue;
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = k0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+                int wrow = -1;
+                for (int sg = 0; sg < g.n_seg; ++sg)
+                    if (kc >= g.seg[sg].col0 && kc < g.seg[sg].col0 + g.seg[sg].width) wrow = g.seg[sg].wrow0 + kc - g.seg[sg].col0;
+                if (wrow >= 0) atomicAdd(g.grad + g.w_off + (size_t)wrow * g.n_real + col, acc[a][b][i]);
+            }
+        if (do_bias) atomicAdd(g.grad + g.b_off + col, bsum[b]);     // both lane halves hold different samples
+    }
+}
+
+hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
+    const int kt = K / 32, nt = N / 32;
+    const int KT = kt % 2 == 0 ? 2 : 1, NT = nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);
+    const int gx = kt / KT, gy = nt / NT;
+    long long gz = 1024 / ((long long)gx * gy);
+    const long long max_z = (g.steps + 3) / 4;
+    if (gz > max_z) gz = max_z;
+    if (gz < 1) gz = 1;
+    const dim3 grid(gx, gy, (unsigned)gz), block(256);
+#define KNERF_GEN_WG(KT_, NT_) hipLaunchKernelGGL((wgrad_kernel<KT_, NT_>), grid, block, 0, s, g)
+    if (KT == 2 && NT == 4) KNERF_GEN_WG(2, 4);
+    else if (KT == 2 && NT == 2) KNERF_GEN_WG(2, 2);
+    else if (KT == 2 && NT == 1) KNERF_GEN_WG(2, 1);
+    else if (KT == 1 && NT == 4) KNERF_GEN_WG(1, 4);
+    else if (KT == 1 && NT == 2) KNERF_GEN_WG(1, 2);
+    else KNERF_GEN_WG(1, 1);
+#undef KNERF_GEN_WG
+    return hipGetLastError();
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ---- host: plan -----------------------------------------------------------------------------------------------------
+bool is_default_shape(int n_layers, int units, int skip, int lx, int ld) {
+    return n_layers == 8 && units == 256 && skip == 4 && lx == 10 && ld == 4;
+}
+
+int param_count(int n_layers, int units, int skip, int lx, int ld) {
+    return build_plan(n_layers, units, skip, lx, ld).n_params;
+}
+
+Plan build_plan(int n_layers, int units, int skip, int lx, int ld) {
+    Plan p{};
+    p.n_layers = n_layers; p.units = units; p.skip = skip; p.lx = lx; p.ld = ld;
+    p.xyz_dim = 3 + 6 * lx; p.dir_dim = 3 + 6 * ld;
+    p.kxp = r32(p.xyz_dim); p.kdp = r32(p.dir_dim); p.up = r32(units);
+    const int u2 = units / 2;
+    p.u2p = r32(u2);
+    auto new_buf = [&](int ldv) { p.buf_ld.push_back(ldv); return (int)p.buf_ld.size() - 1; };
+    auto new_dz = [&](int ldv) { p.dz_ld.push_back(ldv); return (int)p.dz_ld.size() - 1; };
+    p.buf_encx = new_buf(p.kxp);
+    p.buf_encd = new_buf(p.kdp);
+    int off = 0;
+    size_t packed = 0;
+    int prev = p.buf_encx, fan_in = p.xyz_dim, n_seg = 1;
+    Seg segs[2] = {{0, p.xyz_dim, 0}, {0, 0, 0}};
+    auto add_layer = [&](int n_real, int out_buf, int out_col0, int head, int relu, int dz_buf, int dz_col0) -> Layer& {
+        Layer L{};
+        L.k_real = fan_in; L.n_real = n_real;
+        L.w_off = off; L.b_off = off + fan_in * n_real; off += fan_in * n_real + n_real;
+        L.n_seg = n_seg; L.seg[0] = segs[0]; L.seg[1] = segs[1];
+        L.in_buf = prev; L.out_buf = out_buf; L.out_col0 = out_col0; L.head = head; L.relu = relu;
+        L.np = r32(n_real);
+        L.dz_buf = dz_buf; L.dz_col0 = dz_col0;
+        const int K = p.buf_ld[prev];
+        L.wt_off = packed; packed += (size_t)L.np * K;
+        L.wd_off = packed; L.wd_ld = L.np; L.wd_col0 = 0; packed += (size_t)K * L.np;
+        p.layers.push_back(L);
+        return p.layers.back();
+    };
+    for (int i = 0; i < n_layers; ++i) {
+        const bool cat = (i % skip == 0) && i > 0;                 // mlp.py:36-38
+        const int out = new_buf(p.up + (cat ? p.kxp : 0));
+        add_layer(units, out, 0, -1, 1, new_dz(p.up), 0);
+        p.concat_after.push_back(cat ? 1 : 0);
+        prev = out;
+        segs[0] = {0, units, 0};
+        if (cat) { segs[1] = {p.up, p.xyz_dim, units}; n_seg = 2; fan_in = units + p.xyz_dim; }
+        else { n_seg = 1; fan_in = units; }
+    }
+    p.buf_trunk = prev;
+    p.dz_head = new_dz(p.up + 32);
+    p.dz_r = new_dz(p.u2p);
+    p.dz_c = new_dz(32);
+    // sigma and features read the trunk; their dgrad weights share one matrix Wd_head [trunk_ld][up + 32] = [features | sigma]
+    const int Ktr = p.buf_ld[p.buf_trunk];
+    {
+        Layer& Ls = add_layer(1, -1, 0, 0, 0, p.dz_head, p.up);
+        packed -= (size_t)Ktr * Ls.np;                 // give back the private Wd, use the shared one
+        const size_t shared = packed; packed += (size_t)Ktr * (p.up + 32);
+        Ls.wd_off = shared; Ls.wd_ld = p.up + 32; Ls.wd_col0 = p.up;
+        p.buf_fcat = new_buf(p.up + p.kdp);
+        Layer& Lf = add_layer(units, p.buf_fcat, 0, -1, 0, p.dz_head, 0);
+        packed -= (size_t)Ktr * Lf.np;
+        Lf.wd_off = shared; Lf.wd_ld = p.up + 32; Lf.wd_col0 = 0;
+    }
+    prev = p.buf_fcat; fan_in = units + p.dir_dim; n_seg = 2;
+    segs[0] = {0, units, 0}; segs[1] = {p.up, p.dir_dim, units};
+    p.buf_f2 = new_buf(p.u2p);
+    add_layer(u2, p.buf_f2, 0, -1, 0, p.dz_r, 0);
+    prev = p.buf_f2; fan_in = u2; n_seg = 1; segs[0] = {0, u2, 0};
+    add_layer(3, -1, 0, 1, 0, p.dz_c, 0);
+    p.n_params = off;
+    p.packed_elems = packed;
+    p.act_elems_per_row = 0; for (int v : p.buf_ld) p.act_elems_per_row += v;
+    p.dz_elems_per_row = 0; for (int v : p.dz_ld) p.dz_elems_per_row += v;
+    return p;
+}
+
+size_t padded_rows(long long n) { return (size_t)((n + 127) / 128 * 128); }
+
+namespace {
+u16* act_buf(const Plan& p, const Workspace& ws, int b) {
+    size_t o = 0;
+    for (int i = 0; i < b; ++i) o += p.buf_ld[i];
+    return ws.act + o * ws.mp;
+}
+u16* dz_buf(const Plan& p, const Workspace& ws, int b) {
+    size_t o = 0;
+    for (int i = 0; i < b; ++i) o += p.dz_ld[i];
+    return ws.dz + o * ws.mp;
+}
+#define GENCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+}  // namespace
+
+hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* packed, hipStream_t s) {
+    for (const Layer& L : p.layers) {
+        PackArgs a{};
+        a.w = w_flat; a.w_off = L.w_off; a.n_real = L.n_real; a.K = p.buf_ld[L.in_buf]; a.np = L.np;
+        a.n_seg = L.n_seg; a.seg[0] = L.seg[0]; a.seg[1] = L.seg[1];
+        a.dst = packed + L.wt_off; a.transpose = 0; a.ldd = a.K; a.col0 = 0;
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long long)a.K * a.np)), dim3(256), 0, s, a);
+        a.dst = packed + L.wd_off; a.transpose = 1; a.ldd = L.wd_ld; a.col0 = L.wd_col0;
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long long)a.K * a.np)), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
+                   const float* t, long long n, int S, float* raw, hipStream_t s) {
+    const long long mp = (long long)padded_rows(n);
+    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+    u16* ex = act_buf(p, ws, p.buf_encx);
+    u16* ed = act_buf(p, ws, p.buf_encd);
+    hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld, ex, p.kxp, ed, p.kdp);
+    GENCHK(hipGetLastError());
+    for (size_t li = 0; li < p.layers.size(); ++li) {
+        const Layer& L = p.layers[li];
+        GemmArgs g{};
+        g.A = act_buf(p, ws, L.in_buf); g.lda = p.buf_ld[L.in_buf];
+        g.Bt = net.packed + L.wt_off; g.ldb = g.lda;
+        g.M = mp; g.N = L.np; g.K = g.lda;
+        g.bias = w_flat + L.b_off; g.n_real = L.n_real; g.relu = L.relu;
+        if (L.out_buf >= 0) { g.Cb = act_buf(p, ws, L.out_buf) + L.out_col0; g.ldc = p.buf_ld[L.out_buf]; }
+        else { g.Cf = L.head == 0 ? ws.zs : ws.zc; g.ldcf = 32; }
+        GENCHK(launch_gemm(g, s));
+        if ((int)li < p.n_layers && p.concat_after[li]) {
+            hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kxp / 8))), dim3(256), 0, s, ex, p.kxp,
+                               act_buf(p, ws, L.out_buf) + p.up, p.buf_ld[L.out_buf], mp, p.kxp);
+            GENCHK(hipGetLastError());
+        }
+        if (L.out_buf == p.buf_fcat) {
+            hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kdp / 8))), dim3(256), 0, s, ed, p.kdp,
+                               act_buf(p, ws, p.buf_fcat) + p.up, p.buf_ld[p.buf_fcat], mp, p.kdp);
+            GENCHK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ws.zs, ws.zc, n, raw);
+    return hipGetLastError();
+}
+
+hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
+                    float* grad_flat, hipStream_t s) {
+    const long long mp = (long long)padded_rows(n);
+    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+    const int nl = p.n_layers;
+    const Layer& Lsig = p.layers[nl];
+    const Layer& Lrf = p.layers[nl + 2];
+    const Layer& Lrgb = p.layers[nl + 3];
+    u16* dzc = dz_buf(p, ws, p.dz_c);
+    u16* dzh = dz_buf(p, ws, p.dz_head);
+    u16* dzr = dz_buf(p, ws, p.dz_r);
+    const int ldh = p.up + 32;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, raw, draw, n, mp, dzc, dzh + p.up, ldh);
+    GENCHK(hipGetLastError());
+    auto dgrad = [&](const u16* A, int lda, int K, const u16* Wd, int ldb, int N, const u16* aux, int ldaux, u16* C, int ldc) {
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.Bt = Wd; g.ldb = ldb; g.M = mp; g.N = N; g.K = K;
+        g.aux = aux; g.ldaux = ldaux; g.Cb = C; g.ldc = ldc;
+        return launch_gemm(g, s);
+    };
+    // d f2 = dZ_rgb . W_rgb^T (rgb_features is linear: dZ_rf = d f2)
+    GENCHK(dgrad(dzc, 32, 32, net.packed + Lrgb.wd_off, Lrgb.wd_ld, p.u2p, nullptr, 0, dzr, p.u2p));
+    // d features = (dZ_rf . W_rf^T)[:, :units]   (features is linear; dir_enc is a constant)
+    GENCHK(dgrad(dzr, p.u2p, p.u2p, net.packed + Lrf.wd_off, Lrf.wd_ld, p.up, nullptr, 0, dzh, ldh));
+    // d trunk = [dZ_features | dZ_sigma] . [W_features | W_sigma]^T, masked by the last trunk layer's relu
+    {
+        const Layer& Ll = p.layers[nl - 1];
+        GENCHK(dgrad(dzh, ldh, ldh, net.packed + Lsig.wd_off, Lsig.wd_ld, p.up, act_buf(p, ws, Ll.out_buf), p.buf_ld[Ll.out_buf],
+                     dz_buf(p, ws, Ll.dz_buf), p.up));
+    }
+    for (int i = nl - 2; i >= 0; --i) {
+        const Layer& Ln = p.layers[i + 1];
+        const Layer& Li = p.layers[i];
+        GENCHK(dgrad(dz_buf(p, ws, Ln.dz_buf), p.up, p.up, net.packed + Ln.wd_off, Ln.wd_ld, p.up, act_buf(p, ws, Li.out_buf),
+                     p.buf_ld[Li.out_buf], dz_buf(p, ws, Li.dz_buf), p.up));
+    }
+    for (const Layer& L : p.layers) {
+        WgradArgs w{};
+        w.X = act_buf(p, ws, L.in_buf); w.ldx = p.buf_ld[L.in_buf];
+        w.Z = dz_buf(p, ws, L.dz_buf) + L.dz_col0; w.ldz = p.dz_ld[L.dz_buf];
+        w.steps = mp / 32; w.grad = grad_flat; w.w_off = L.w_off; w.b_off = L.b_off; w.n_real = L.n_real;
+        w.n_seg = L.n_seg; w.seg[0] = L.seg[0]; w.seg[1] = L.seg[1];
+        GENCHK(launch_wgrad(w, w.ldx, L.np, s));
+    }
+    return hipSuccess;
+}
+
+}  // namespace gen
+}  // namespace knerf

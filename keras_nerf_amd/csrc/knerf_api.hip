@@ -12,6 +12,7 @@
 #include "../../include/knerf.h"
 #include "chain.h"
 #include "kernels.h"
+#include "generic.h"
 #include "layout.h"
 
 using namespace knerf;
@@ -72,6 +73,12 @@ struct knerf_ctx {
     int* d_fplan = nullptr; int n_fplan = 0;
     unsigned* d_ready = nullptr; size_t ready_cap = 0;
     unsigned epoch = 0;
+    // general-shape MLP path (generic.h): used when the config is not the default NeRFMLP shape
+    bool generic = false;
+    int n_params = kParamCount;
+    gen::Plan gplan;
+    gen::Workspace gws;
+    gen::NetDev gnet[2];
     // workspaces (grow-only)
     int ws_rays = 0; bool ws_train = false;
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
@@ -122,6 +129,10 @@ constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPa
 
 int repack(knerf_ctx* ctx, int n, hipStream_t s) {
     Net& N = ctx->net[n];
+    if (ctx->generic) {
+        HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n].packed, s));
+        return KNERF_OK;
+    }
     HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)kFwdBlocks * 512, s));
     HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)kBwdBlocks * 512, s));
     HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)kFwdBiasTiles * 32, s));
@@ -149,7 +160,21 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
     HIPCHK(hipMalloc(&ctx->w_c, (size_t)R * ctx->cfg.n_coarse * sizeof(float)));
     HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
     HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
-    if (train) {
+    if (ctx->generic) {
+        gen::Workspace& g = ctx->gws;
+        free_dev(g.act); free_dev(g.dz); free_dev(g.zs); free_dev(g.zc);
+        g.mp = gen::padded_rows((long long)ns);
+        const size_t ab = ctx->gplan.act_elems_per_row * g.mp * sizeof(unsigned short), zb = ctx->gplan.dz_elems_per_row * g.mp * sizeof(unsigned short);
+        HIPCHK(hipMalloc(&g.act, ab));
+        HIPCHK(hipMemset(g.act, 0, ab));
+        HIPCHK(hipMalloc(&g.zs, g.mp * 32 * sizeof(float)));
+        HIPCHK(hipMalloc(&g.zc, g.mp * 32 * sizeof(float)));
+        if (train) {
+            HIPCHK(hipMalloc(&g.dz, zb));
+            HIPCHK(hipMemset(g.dz, 0, zb));
+            HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
+        }
+    } else if (train) {
         const size_t tiles = tiles_for((long long)ns);
         ctx->act_bytes = tiles * kActTileBytes; ctx->mask_bytes = tiles * kMaskTileBytes; ctx->dz_bytes = tiles * kDzTileBytes;
         HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
@@ -196,14 +221,23 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
     fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw; fa.act = ctx->act; fa.mask = ctx->mask;
     fa.n_samples = (long long)R * S; fa.S = S;
-    { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F); HIPCHK(launch_mlp_fwd(fa, train, s)); }
+    if (ctx->generic) {
+        ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F);
+        HIPCHK(gen::forward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->net[net].w, o, d, t, fa.n_samples, S, ctx->raw, s));
+    } else {
+        ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F);
+        HIPCHK(launch_mlp_fwd(fa, train, s));
+    }
     CompositeArgs ca{};
     ca.raw = ctx->raw; ca.t = t; ca.target = target; ca.image = image; ca.depth = depth; ca.weights = weights;
     ca.draw = train ? ctx->draw : nullptr; ca.loss = loss; ca.R = R; ca.S = S; ca.white = ctx->cfg.white_background;
     ca.grad_scale = 2.0f / (3.0f * (float)R) * inv_chunks;
     ca.loss_scale = inv_chunks / (3.0f * (float)R);
     { ProfScope ps(ctx, s, P_COMPOSITE); HIPCHK(launch_composite(ca, s)); }
-    if (train) {
+    if (train && ctx->generic) {
+        ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
+        HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s));
+    } else if (train) {
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
         ba.n_samples = fa.n_samples;
@@ -235,6 +269,11 @@ extern "C" {
 
 size_t knerf_param_count(void) { return (size_t)kParamCount; }
 
+size_t knerf_param_count_for(const knerf_config* cfg) {
+    if (!cfg || cfg->n_layers < 1 || cfg->dense_units < 2 || cfg->skip_layer < 1 || cfg->pos_emb_xyz < 0 || cfg->pos_emb_dir < 0) return 0;
+    return (size_t)gen::param_count(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
+}
+
 const char* knerf_last_error(const knerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int knerf_debug_table(int kind, int32_t* out, size_t* n) {
@@ -261,9 +300,9 @@ int knerf_debug_table(int kind, int32_t* out, size_t* n) {
 int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     knerf_ctx* ctx = nullptr;
     if (!cfg || !out) return fail(nullptr, KNERF_ERR_INVALID, "null argument");
-    if (cfg->n_layers != 8 || cfg->dense_units != 256 || cfg->skip_layer != 4 || cfg->pos_emb_xyz != kLx || cfg->pos_emb_dir != kLd)
-        return fail(nullptr, KNERF_ERR_INVALID,
-                    "the fused gfx950 kernels implement NeRFMLP(n_layers=8, dense_units=256, skip_layer=4) with pos_emb_xyz=10, pos_emb_dir=4 only");
+    if (cfg->n_layers < 1 || cfg->n_layers > 64 || cfg->dense_units < 2 || cfg->dense_units > 4096 || cfg->skip_layer < 1 ||
+        cfg->pos_emb_xyz < 0 || cfg->pos_emb_xyz > 32 || cfg->pos_emb_dir < 0 || cfg->pos_emb_dir > 32)
+        return fail(nullptr, KNERF_ERR_INVALID, "need 1 <= n_layers <= 64, 2 <= dense_units <= 4096, skip_layer >= 1, 0 <= pos_emb_* <= 32");
     if (cfg->n_coarse < 2 || cfg->n_coarse > 256 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 512)
         return fail(nullptr, KNERF_ERR_INVALID, "need 2 <= n_coarse <= 256 and n_coarse + n_fine <= 512");
     int ndev = 0;
@@ -276,6 +315,13 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         return fail(nullptr, KNERF_ERR_NODEVICE, std::string("libknerf_hip is built for gfx950 only; device is ") + prop.gcnArchName);
     ctx = new knerf_ctx();
     ctx->cfg = *cfg;
+    ctx->generic = !gen::is_default_shape(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir) ||
+                   std::getenv("KNERF_FORCE_GENERIC") != nullptr;      // the override lets tests run the default shape through both paths
+    if (ctx->generic) {
+        ctx->gplan = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
+        ctx->n_params = ctx->gplan.n_params;
+    }
+    const size_t NP = (size_t)ctx->n_params;
     const Tables& ht = host_tables();
     ctx->tab.host = ht.host; ctx->tab.wgrad = ht.wgrad; ctx->tab.wgrad_off = ht.wgrad_off;
     auto up = [&](int*& dptr, const std::vector<int32_t>& v) -> hipError_t {
@@ -301,21 +347,25 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         ctx->tab.n_plan = (int)plan.size() / 4;
         CREATECHK(up(ctx->tab.d_plan, plan));
     }
-    CREATECHK(hipMalloc(&ctx->grads, 2 * (size_t)kParamCount * sizeof(float)));
-    CREATECHK(hipMemset(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float)));
+    CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
+    CREATECHK(hipMemset(ctx->grads, 0, 2 * NP * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->d_flag, 2 * sizeof(int)));
     CREATECHK(hipMemset(ctx->d_flag, 0, 2 * sizeof(int)));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
     for (int n = 0; n < 2; ++n) {
         Net& N = ctx->net[n];
-        CREATECHK(hipMalloc(&N.w, kParamCount * sizeof(float)));
-        CREATECHK(hipMalloc(&N.m, kParamCount * sizeof(float)));
-        CREATECHK(hipMalloc(&N.v, kParamCount * sizeof(float)));
-        CREATECHK(hipMemset(N.w, 0, kParamCount * sizeof(float)));
-        CREATECHK(hipMemset(N.m, 0, kParamCount * sizeof(float)));
-        CREATECHK(hipMemset(N.v, 0, kParamCount * sizeof(float)));
-        N.g = ctx->grads + (size_t)n * kParamCount;
+        CREATECHK(hipMalloc(&N.w, NP * sizeof(float)));
+        CREATECHK(hipMalloc(&N.m, NP * sizeof(float)));
+        CREATECHK(hipMalloc(&N.v, NP * sizeof(float)));
+        CREATECHK(hipMemset(N.w, 0, NP * sizeof(float)));
+        CREATECHK(hipMemset(N.m, 0, NP * sizeof(float)));
+        CREATECHK(hipMemset(N.v, 0, NP * sizeof(float)));
+        N.g = ctx->grads + (size_t)n * NP;
+        if (ctx->generic) {
+            CREATECHK(hipMalloc(&ctx->gnet[n].packed, ctx->gplan.packed_elems * sizeof(unsigned short)));
+            CREATECHK(hipMemset(ctx->gnet[n].packed, 0, ctx->gplan.packed_elems * sizeof(unsigned short)));
+        }
         CREATECHK(hipMalloc(&N.fwd_stream, kFwdStreamBytes));
         CREATECHK(hipMalloc(&N.bwd_stream, kBwdStreamBytes));
         CREATECHK(hipMemset(N.fwd_stream, 0, kFwdStreamBytes));
@@ -341,13 +391,15 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
+    free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
+    free_dev(ctx->gnet[0].packed); free_dev(ctx->gnet[1].packed);
     delete ctx;
     return KNERF_OK;
 }
 
 int knerf_set_weights(knerf_ctx* ctx, int net, const float* host_flat, size_t n) {
     if (int r = check_net(ctx, net)) return r;
-    if (!host_flat || n != (size_t)kParamCount) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(kParamCount) + " floats");
+    if (!host_flat || n != (size_t)ctx->n_params) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(ctx->n_params) + " floats");
     HIPCHK(hipMemcpy(ctx->net[net].w, host_flat, n * sizeof(float), hipMemcpyHostToDevice));
     if (int r = repack(ctx, net, nullptr)) return r;
     HIPCHK(hipStreamSynchronize(nullptr));
@@ -356,7 +408,7 @@ int knerf_set_weights(knerf_ctx* ctx, int net, const float* host_flat, size_t n)
 
 int knerf_get_weights(knerf_ctx* ctx, int net, float* host_flat, size_t n) {
     if (int r = check_net(ctx, net)) return r;
-    if (!host_flat || n != (size_t)kParamCount) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(kParamCount) + " floats");
+    if (!host_flat || n != (size_t)ctx->n_params) return fail(ctx, KNERF_ERR_INVALID, "weights: expected " + std::to_string(ctx->n_params) + " floats");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(host_flat, ctx->net[net].w, n * sizeof(float), hipMemcpyDeviceToHost));
     return KNERF_OK;
@@ -365,14 +417,14 @@ int knerf_get_weights(knerf_ctx* ctx, int net, float* host_flat, size_t n) {
 int knerf_weights_device(knerf_ctx* ctx, int net, float** dev, size_t* n) {
     if (int r = check_net(ctx, net)) return r;
     if (dev) *dev = ctx->net[net].w;
-    if (n) *n = (size_t)kParamCount;
+    if (n) *n = (size_t)ctx->n_params;
     return KNERF_OK;
 }
 
 int knerf_grads_device(knerf_ctx* ctx, float** dev, size_t* n) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (dev) *dev = ctx->grads;
-    if (n) *n = 2 * (size_t)kParamCount;
+    if (n) *n = 2 * (size_t)ctx->n_params;
     return KNERF_OK;
 }
 
@@ -455,7 +507,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // finite check first so that a bad step leaves the weights untouched (reference aborts fit at nerf.py:381-382)
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
-    HIPCHK(launch_check_finite(ctx->grads, 2 * kParamCount, ctx->d_flag, s));
+    HIPCHK(launch_check_finite(ctx->grads, 2 * ctx->n_params, ctx->d_flag, s));
     int flag[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(flag, ctx->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -470,7 +522,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     ProfScope ps(ctx, s, P_ADAM);
     for (int n = 0; n < 2; ++n) {
         AdamArgs a{};
-        a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = kParamCount;
+        a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = ctx->n_params;
         a.lr_t = lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
         if (int r = repack(ctx, n, s)) return r;
@@ -499,7 +551,7 @@ int knerf_set_fused_backward(knerf_ctx* ctx, int producers) {
 
 int knerf_zero_grads(knerf_ctx* ctx, void* stream) {
     if (!ctx) return KNERF_ERR_INVALID;
-    HIPCHK(hipMemsetAsync(ctx->grads, 0, 2 * (size_t)kParamCount * sizeof(float), (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(ctx->grads, 0, 2 * (size_t)ctx->n_params * sizeof(float), (hipStream_t)stream));
     return KNERF_OK;
 }
 

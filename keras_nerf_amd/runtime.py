@@ -51,7 +51,7 @@ class KnerfContext:
             msg = self.lib.knerf_last_error(None).decode()
             self._ctx = C.c_void_p()
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
-        self.param_count = int(self.lib.knerf_param_count())
+        self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -40,12 +40,26 @@ def test_no_cpu_fallback_create_fails_loudly_without_gpu():
         KnerfContext()
 
 
-def test_unsupported_shape_rejected_before_any_device_work():
+def test_invalid_shapes_rejected_before_any_device_work():
     lib = _lib.load()
-    cfg = _lib.KnerfConfig(64, 128, 10, 4, 8, 128, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
-    p = C.c_void_p()
-    assert lib.knerf_create(C.byref(cfg), C.byref(p)) == _lib.KNERF_ERR_INVALID
-    assert b"dense_units=256" in lib.knerf_last_error(None)
+    for bad in ((64, 128, 10, 4, 0, 256, 4), (64, 128, 10, 4, 8, 1, 4), (64, 128, 10, 4, 8, 256, 0), (64, 128, -1, 4, 8, 256, 4),
+                (1, 128, 10, 4, 8, 256, 4), (300, 300, 10, 4, 8, 256, 4)):
+        cfg = _lib.KnerfConfig(*bad, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
+        p = C.c_void_p()
+        assert lib.knerf_create(C.byref(cfg), C.byref(p)) == _lib.KNERF_ERR_INVALID, bad
+        assert lib.knerf_last_error(None)
+        assert lib.knerf_param_count_for(C.byref(cfg)) == 0 or bad[0] in (1, 300)
+
+
+def test_param_count_for_any_shape_matches_the_layer_list():
+    """mlp.py:11-27: the general-shape path sizes its buffers from this count (no device needed)"""
+    from keras_nerf_amd.model.nerf.mlp import layer_shapes
+    lib = _lib.load()
+    for nl, u, sk, lx, ld in ((8, 256, 4, 10, 4), (4, 128, 2, 6, 2), (3, 64, 1, 4, 1), (2, 96, 4, 10, 4), (5, 160, 3, 12, 5), (1, 2, 1, 0, 0)):
+        cfg = _lib.KnerfConfig(64, 128, lx, ld, nl, u, sk, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
+        want = sum(i * o + o for _, i, o in layer_shapes(nl, u, sk, 3 + 6 * lx, 3 + 6 * ld))
+        assert lib.knerf_param_count_for(C.byref(cfg)) == want
+    assert lib.knerf_param_count() == lib.knerf_param_count_for(C.byref(_lib.KnerfConfig(64, 128, 10, 4, 8, 256, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-7)))
 
 
 def test_product_code_never_imports_the_oracle():

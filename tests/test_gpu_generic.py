@@ -1,0 +1,173 @@
+"""General-shape MLP path (csrc/generic.hip) against the oracle: every NeRF(...) shape argument the reference's
+constructor and CLI accept (nerf.py:11-14, train_single.py:30-36), not only the default 8 x 256 / skip 4 / L 10,4 that the
+fused kernels implement.  Tolerances are the ones of tests/test_gpu_train.py (bf16 matmul operands, fp32 accumulate)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from tests.problem import make_problem
+from tests.test_gpu_forward import log_stats
+from tests.test_gpu_train import flat, per_tensor_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir)
+    "small_skip2": (4, 128, 2, 6, 2),          # concat after layers 2 (and the trunk output stays plain)
+    "skip1_every_layer": (3, 64, 1, 4, 1),     # concat after layers 1 and 2: the trunk output itself is concatenated
+    "odd_units": (2, 96, 4, 10, 4),            # units not a power of two, units/2 = 48 (padded to 64), no concat at all
+    "wide_enc": (5, 160, 3, 12, 5),            # xyz_dim 75 -> padded 96, concat after layer 3
+}
+
+
+def shape_cfg(name, n_coarse=64, n_fine=128):
+    nl, u, sk, lx, ld = SHAPES[name]
+    return O.NerfConfig(n_coarse=n_coarse, n_fine=n_fine, pos_emb_xyz=lx, pos_emb_dir=ld, n_layers=nl, dense_units=u, skip_layer=sk)
+
+
+def ctx_for(P, **kw):
+    from keras_nerf_amd.runtime import KnerfContext
+    c = P["cfg"]
+    ctx = KnerfContext(n_coarse=c.n_coarse, n_fine=c.n_fine, pos_emb_xyz=c.pos_emb_xyz, pos_emb_dir=c.pos_emb_dir,
+                       n_layers=c.n_layers, dense_units=c.dense_units, skip_layer=c.skip_layer, white_background=True, **kw)
+    assert ctx.param_count == O.param_count(c)
+    ctx.set_weights(0, O.flatten_params(P["cp"]))
+    ctx.set_weights(1, O.flatten_params(P["fp"]))
+    return ctx
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_generic_shape_images_losses_and_gradients(name):
+    cfg = shape_cfg(name)
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    ctx = ctx_for(P)
+    o, d, t, u, img = flat(P)
+    loss = torch.zeros(2, device="cuda")
+    ci = torch.empty((P["N"], 3), device="cuda"); fi = torch.empty_like(ci)
+    ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
+    torch.cuda.synchronize()
+    g = ctx.grads_view().cpu().numpy()
+    n = ctx.param_count
+    S = cfg.n_coarse + cfg.n_fine
+    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:P["N"] * S].reshape(P["N"], S)
+    # against the bf16-emulating oracle this path agrees to <1e-2 (it rounds exactly where the oracle does); against pure
+    # fp32 the gap is bf16's own: L=12 encodings (wide_enc) push the sparse sigma-bias gradient to 0.18 of its max
+    fp32_tol = 0.25 if name == "wide_enc" else 0.1
+    for emu, tol in ((True, 1e-2), (False, fp32_tol)):
+        rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=emu)
+        rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=emu)
+        ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
+        ef = per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+        log_stats(f"generic_{name}_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0],
+                  loss_c=abs(float(loss[0]) - float(lc)), loss_f=abs(float(loss[1]) - float(lf)))
+        assert ec[0] < tol, ec
+        assert ef[0] < tol, ef
+        assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+        if emu:
+            np.testing.assert_allclose(ci.cpu().numpy(), rc["image"], atol=1e-2)
+            np.testing.assert_allclose(fi.cpu().numpy(), rf["image"], atol=1e-2)
+    assert np.abs(g[:n]).max() > 1e-6 and np.abs(g[n:]).max() > 1e-6
+    ctx.close()
+
+
+def test_generic_ragged_chunk_and_stale_workspace():
+    cfg = shape_cfg("small_skip2", n_coarse=32, n_fine=48)
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    ctx = ctx_for(P)
+    big = flat(P)
+    ctx.train_chunk(big[0], big[1], big[2], big[4], big[3])       # stale rows of a larger chunk stay in the workspaces
+    ctx.zero_grads()
+    o, d, t, u, img = [x[:37].copy() for x in big]
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, u, loss=loss)
+    g = ctx.grads_view().cpu().numpy()
+    n = ctx.param_count
+    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=True)
+    ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
+    log_stats("generic_ragged", coarse_worst=ec[0])
+    assert ec[0] < 4e-2, ec
+    assert abs(float(loss[0]) - float(lc)) < 2e-3
+    ctx.close()
+
+
+def test_generic_adam_steps_follow_oracle():
+    cfg = shape_cfg("small_skip2")
+    P = make_problem(n_images=1, wh=16, weight_scale=1.0, bias_std=0.0, cfg=cfg)
+    ctx = ctx_for(P)
+    o, d, t, u, img = flat(P)
+    cp = [p.copy() for p in P["cp"]]; fp = [p.copy() for p in P["fp"]]
+    oc, of_ = O.KerasAdam(cp), O.KerasAdam(fp)
+    R = 128
+    loss = torch.zeros(2, device="cuda")
+    for step in range(3):
+        loss.zero_()
+        for c in range(P["N"] // R):
+            sl = slice(c * R, (c + 1) * R)
+            ctx.train_chunk(o[sl], d[sl], t[sl], img[sl], u[sl], inv_chunks=R / P["N"], loss=loss, ray_offset=c * R)
+        ctx.apply_adam()
+        m, _, _, _ = O.train_step(cp, fp, oc, of_, P["img"], P["o"], P["d"], P["t"], P["u"], cfg, R, True, "zero", emulate_bf16=True)
+        lg = loss.cpu().numpy()
+        assert abs(lg[0] - m["coarse_loss"]) < 3e-3 and abs(lg[1] - m["fine_loss"]) < 3e-3
+    for w, ref, init in ((ctx.get_weights(0), O.flatten_params(cp), O.flatten_params(P["cp"])),
+                         (ctx.get_weights(1), O.flatten_params(fp), O.flatten_params(P["fp"]))):
+        moved = np.abs(ref - init) > 1e-4
+        agree = np.mean(np.sign(w - init)[moved] == np.sign(ref - init)[moved])
+        log_stats("generic_adam_direction_agreement", agree=agree)
+        assert agree > 0.97
+        assert np.abs(w - ref).mean() < 0.1 * np.abs(ref - init).mean()
+    ctx.close()
+
+
+def test_default_shape_through_both_paths_agrees():
+    """KNERF_FORCE_GENERIC routes the default 8 x 256 shape through the general kernels: fused and general path must agree
+    with each other as closely as each agrees with the oracle."""
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+    o, d, t, u, img = flat(P)
+    res = []
+    for force in (False, True):
+        if force:
+            os.environ["KNERF_FORCE_GENERIC"] = "1"
+        try:
+            ctx = ctx_for(P)
+        finally:
+            os.environ.pop("KNERF_FORCE_GENERIC", None)
+        loss = torch.zeros(2, device="cuda")
+        fi = torch.empty((P["N"], 3), device="cuda")
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, f_image=fi)
+        torch.cuda.synchronize()
+        res.append((ctx.grads_view().cpu().numpy().copy(), loss.cpu().numpy().copy(), fi.cpu().numpy().copy()))
+        ctx.close()
+    (g0, l0, i0), (g1, l1, i1) = res
+    n = g0.size // 2
+    ec = per_tensor_err(g1[:n], g0[:n], P["cfg"])[0]
+    ef = per_tensor_err(g1[n:], g0[n:], P["cfg"])[0]
+    log_stats("generic_vs_fused_default_shape", coarse_worst=ec, fine_worst=ef, dloss=float(np.abs(l0 - l1).max()),
+              dimg_mean=float(np.abs(i0 - i1).mean()))
+    assert ec < 4e-2
+    # the fine net sees each path's own importance samples: percent-level differences in the coarse weights move
+    # individual samples across bins (oob="zero" is discontinuous), so single pixels and sparse gradients differ more
+    assert ef < 0.3
+    assert np.abs(l0 - l1).max() < 2e-3
+    assert np.abs(i0 - i1).mean() < 3e-3
+
+
+def test_generic_nerf_class_trains_and_renders():
+    """the NeRF class surface (nerf.py:11-14, 78, 332, 229) with non-default shape arguments"""
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    cfg = shape_cfg("small_skip2", n_coarse=32, n_fine=32)
+    P = make_problem(n_images=2, wh=16, cfg=cfg)
+    nerf = NeRF(n_coarse=32, n_fine=32, pos_emb_xyz=cfg.pos_emb_xyz, pos_emb_dir=cfg.pos_emb_dir, n_layers=cfg.n_layers,
+                dense_units=cfg.dense_units, skip_layer=cfg.skip_layer, seed=3)
+    nerf.compile(optimizer="adam", loss="mse", batch_size=2, image_height=16, image_width=16, ray_chunks=128, white_background=True)
+    rgba = np.concatenate([P["img"], np.ones(P["img"].shape[:-1] + (1,), np.float32)], -1)
+    data = (rgba, (P["o"], P["d"], P["t"]))
+    first = nerf.train_step(data)
+    for _ in range(30):
+        logs = nerf.train_step(data)
+    assert np.isfinite(logs["fine_loss"]) and logs["fine_loss"] < first["fine_loss"]
+    coarse, fine = nerf.predict_and_render_images((P["o"], P["d"], P["t"]))
+    assert tuple(fine["image"].shape) == (2, 16, 16, 3) and tuple(fine["weights"].shape) == (2, 16, 16, 64)
+    assert torch.isfinite(fine["image"]).all()

@@ -14,6 +14,7 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=6)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--shape", default="8,256,4,10,4", help="n_layers,dense_units,skip_layer,pos_emb_xyz,pos_emb_dir (non-default: general-shape path)")
 args = ap.parse_args()
 if args.lib:
     os.environ["KNERF_LIB"] = os.path.abspath(args.lib)
@@ -24,9 +25,10 @@ from keras_nerf_amd.runtime import KnerfContext
 from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
 from keras_nerf_amd.model.nerf.mlp import NeRFMLP
 
-ctx = KnerfContext(white_background=True)
+NL, NU, SK, LX, LD = (int(v) for v in args.shape.split(","))
+ctx = KnerfContext(white_background=True, n_layers=NL, dense_units=NU, skip_layer=SK, pos_emb_xyz=LX, pos_emb_dir=LD)
 for net in (0, 1):
-    m = NeRFMLP(seed=net); m.build(); ctx.set_weights(net, m.get_flat_weights())
+    m = NeRFMLP(NL, NU, SK, seed=net, xyz_dim=3 + 6 * LX, dir_dim=3 + 6 * LD); m.build(); ctx.set_weights(net, m.get_flat_weights())
 wh = 128
 o, d, t = ctx.generate_rays(pose_spherical(20.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, 64, None, seed=1)
 R = args.rays
@@ -34,6 +36,10 @@ o, d, t = o.reshape(-1, 3)[:R].contiguous(), d.reshape(-1, 3)[:R].contiguous(), 
 tgt = torch.rand((R, 3), device="cuda")
 loss = torch.zeros(2, device="cuda")
 FWD, DG, WG = 2 * 593408, 2 * (128 * 3 + 256 * 128 + 256 * 257 + 7 * 256 * 256), 2 * 593408
+if args.shape != "8,256,4,10,4":       # FLOP per sample of an arbitrary shape: 2 x MACs of every Dense layer
+    from keras_nerf_amd.model.nerf.mlp import layer_shapes
+    macs = sum(i * o for _, i, o in layer_shapes(NL, NU, SK, 3 + 6 * LX, 3 + 6 * LD))
+    FWD, DG, WG = 2 * macs, 2 * macs, 2 * macs
 for _ in range(2):
     ctx.train_chunk(o, d, t, tgt, None, seed=1, loss=loss); ctx.render_chunk(o, d, t, None, seed=1)
 torch.cuda.synchronize()
