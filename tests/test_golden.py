@@ -80,3 +80,49 @@ def test_hip_path_against_fullsize_golden():
             l2.append(np.linalg.norm(g[off:off + n].astype(np.float64))); off += n
     np.testing.assert_allclose(l2, z["bf16_grad_c_l2_per_tensor"], rtol=5e-2)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_general_shape_path_against_small_golden():
+    """small_r16.npz is an 8 x 32 / L = 4,2 / 8+16-sample case: it runs on the general-shape kernels (csrc/generic.hip).
+    Compared with the fp32 golden vectors (coarse image, losses, coarse gradient, two Adam steps) at bf16 tolerances."""
+    from keras_nerf_amd.runtime import KnerfContext
+    import torch
+    z = np.load(os.path.join(G, "small_r16.npz"))
+    cfg = O.NerfConfig(n_coarse=8, n_fine=16, pos_emb_xyz=4, pos_emb_dir=2, n_layers=8, dense_units=32, skip_layer=4)
+    cp = [(p * 3).astype(np.float32) for p in O.init_params(cfg, 1)]
+    fp = [(p * 3).astype(np.float32) for p in O.init_params(cfg, 2)]
+    o, d, t, u, img = (z[k].reshape(16, -1).astype(np.float32) for k in ("o", "d", "t", "u", "img"))
+    for oob in ("zero", "clamp"):
+        ctx = KnerfContext(n_coarse=8, n_fine=16, pos_emb_xyz=4, pos_emb_dir=2, n_layers=8, dense_units=32, skip_layer=4,
+                           white_background=True, oob=oob)
+        assert ctx.param_count == O.param_count(cfg)
+        ctx.set_weights(0, O.flatten_params(cp)); ctx.set_weights(1, O.flatten_params(fp))
+        out = {k: v.cpu().numpy() for k, v in ctx.render_chunk(o, d, t, u).items()}
+        np.testing.assert_allclose(out["c_image"], z[f"f32_{oob}_c_image"].reshape(16, 3), atol=2e-2)
+        # x3 weights saturate alpha (weights are mostly 0 or 1): bf16 operands move two of the 128 by 0.03
+        np.testing.assert_allclose(out["c_weights"], z[f"f32_{oob}_c_weights"].reshape(16, 8), atol=5e-2)
+        if oob == "zero":
+            # x3 weights saturate this case (weights of 0 or 1, gradients ~1e-4 carried by a few samples), so the fp32
+            # gradient is not a meaningful target for bf16 operands: losses are checked against the fixture, gradients
+            # against the oracle run with the kernels' operand rounding on the fixture's inputs
+            cpe, fpe = [p.copy() for p in cp], [p.copy() for p in fp]
+            oc, of_ = O.KerasAdam(cpe), O.KerasAdam(fpe)
+            a5 = [x[None] for x in (z["img"], z["o"], z["d"], z["t"], z["u"])]
+            loss = torch.zeros(2, device="cuda")
+            for step in range(2):
+                loss.zero_()
+                for c in range(2):                       # ray_chunks = 8 as in the fixture
+                    sl = slice(8 * c, 8 * c + 8)
+                    ctx.train_chunk(o[sl], d[sl], t[sl], img[sl], u[sl], inv_chunks=0.5, loss=loss, ray_offset=8 * c)
+                g = ctx.grads_view().cpu().numpy()[:ctx.param_count].copy()
+                ctx.apply_adam()
+                m, _, _, (gc, _gf) = O.train_step(cpe, fpe, oc, of_, a5[0].astype(np.float32), a5[1], a5[2], a5[3], a5[4], cfg, 8, True,
+                                                  "zero", emulate_bf16=True)
+                assert abs(float(loss[0]) - float(z[f"f32_step{step}_losses"][0])) < 3e-2      # fp32 fixture, bf16 operands
+                assert abs(float(loss[0]) - m["coarse_loss"]) < 1e-3                            # same rounding: tight
+                if step == 0:
+                    ref = O.flatten_params(gc)
+                    err = np.abs(g - ref).max() / np.abs(ref).max()
+                    assert err < 5e-2, (err, float(np.abs(ref).max()), float(np.abs(g).max()))
+        ctx.close()

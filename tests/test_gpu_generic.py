@@ -20,6 +20,7 @@ SHAPES = {
     "skip1_every_layer": (3, 64, 1, 4, 1),     # concat after layers 1 and 2: the trunk output itself is concatenated
     "odd_units": (2, 96, 4, 10, 4),            # units not a power of two, units/2 = 48 (padded to 64), no concat at all
     "wide_enc": (5, 160, 3, 12, 5),            # xyz_dim 75 -> padded 96, concat after layer 3
+    "tiny32": (8, 32, 4, 4, 2),                # the shape of tests/golden/small_r16.npz: single 32-wide tiles everywhere
 }
 
 
@@ -55,7 +56,8 @@ def test_generic_shape_images_losses_and_gradients(name):
     t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:P["N"] * S].reshape(P["N"], S)
     # against the bf16-emulating oracle this path agrees to <1e-2 (it rounds exactly where the oracle does); against pure
     # fp32 the gap is bf16's own: L=12 encodings (wide_enc) push the sparse sigma-bias gradient to 0.18 of its max
-    fp32_tol = 0.25 if name == "wide_enc" else 0.1
+    # and a 32-unit net (tiny32) has so few active paths that single bf16 roundings move whole gradient tensors
+    fp32_tol = {"wide_enc": 0.25, "tiny32": 1.0}.get(name, 0.1)
     for emu, tol in ((True, 1e-2), (False, fp32_tol)):
         rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=emu)
         rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=emu)
