@@ -158,7 +158,11 @@ def test_generate_rays(ctx_and_problem):
     assert t2.min() >= 2.0 and t2.max() <= 6.0 and np.all(np.diff(t2, axis=-1) >= 0) and t2.std() > 0.5
 
 
-def test_unsupported_architecture_fails_loudly():
+def test_invalid_architecture_fails_loudly():
     from keras_nerf_amd.runtime import KnerfContext
-    with pytest.raises(ValueError):
-        KnerfContext(dense_units=128)
+    for bad in (dict(dense_units=1), dict(n_layers=0), dict(skip_layer=0), dict(pos_emb_xyz=-1), dict(n_coarse=1), dict(n_coarse=300, n_fine=300)):
+        with pytest.raises(ValueError):
+            KnerfContext(**bad)
+    ctx = KnerfContext(dense_units=128)          # non-default shapes run on the general-shape kernels (test_gpu_generic.py)
+    assert ctx.param_count != KnerfContext().param_count
+    ctx.close()
