@@ -99,26 +99,82 @@ struct GemmArgs {
     float* Cf; int ldcf;                 // fp32 output (may be null)
 };
 
+// Workgroup = 8 waves x 32 rows; the Bt slab of the current 64-wide K chunk ([32 NT][64] bf16) is staged in LDS once per
+// workgroup (rows padded to 144 B: the 16-byte fragment reads of 16 lanes then cover all 64 banks exactly once) and
+// double-buffered, so the weights cross L2 once per 256 rows instead of once per 32; A fragments come straight from
+// global memory (each wave owns its rows) and are fetched one chunk ahead.
+constexpr int kGemmWaves = 8, kGemmKC = 64, kGemmRowB = 144;
+
 template <int NT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    constexpr int NB = NT * 32;                       // staged Bt rows
+    constexpr int BUF = NB * kGemmRowB;               // bytes per buffer
+    constexpr int PER_T = (NB * 8 + kGemmWaves * 64 - 1) / (kGemmWaves * 64);   // 16-byte granules per thread per chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
-    if (m0 >= g.M) return;
-    const int n0 = blockIdx.y * NT * 32;
+    long long m0 = ((long long)blockIdx.x * kGemmWaves + wave) * 32;
+    const bool live = m0 < g.M;                       // M is a multiple of 128, the workgroup covers 256 rows
+    if (!live) m0 = 0;                                // idle waves still help staging and hit the barriers
+    const int n0 = blockIdx.y * NB;
     const u16* A = g.A + (size_t)(m0 + r) * g.lda + 8 * h;
-    const u16* B = g.Bt + (size_t)(n0 + r) * g.ldb + 8 * h;
+    const int nchunks = (g.K + kGemmKC - 1) / kGemmKC;
+
+    uint4 stage[PER_T];
+    auto fetch_b = [&](int kc) {                      // global -> registers: granule q = (row, 16-byte column chunk)
+#pragma unroll
+        for (int p = 0; p < PER_T; ++p) {
+            const int q = p * kGemmWaves * 64 + tid;
+            const int row = q >> 3, cc = q & 7;
+            const int k = kc * kGemmKC + cc * 8;
+            stage[p] = (row < NB && k < g.K) ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + row) * g.ldb + k) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto put_b = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PER_T; ++p) {
+            const int q = p * kGemmWaves * 64 + tid;
+            const int row = q >> 3, cc = q & 7;
+            if (row < NB) *reinterpret_cast<uint4*>(gsm + buf * BUF + row * kGemmRowB + cc * 16) = stage[p];
+        }
+    };
+    bf16x8 a_cur[4], a_nxt[4];
+    auto fetch_a = [&](int kc, bf16x8 (&a)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = kc * kGemmKC + ks * 16;
+            if (k < g.K) a[ks] = *reinterpret_cast<const bf16x8*>(A + k);
+        }
+    };
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16();
-    for (int k = 0; k < g.K; k += 16) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + k);
+    fetch_b(0); fetch_a(0, a_cur);
+    put_b(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        const bool more = kc + 1 < nchunks;
+        if (more) { fetch_b(kc + 1); fetch_a(kc + 1, a_nxt); }
+        const char* B = gsm + buf * BUF + r * kGemmRowB + h * 16;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + (size_t)t * 32 * g.ldb + k);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+            if (kc * kGemmKC + ks * 16 < g.K) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + t * 32 * kGemmRowB + ks * 32);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[ks], b, acc[t], 0, 0, 0);
+                }
+            }
         }
+        if (more) {
+            put_b(buf ^ 1);                           // the other buffer was last read before the previous barrier
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a_cur[ks] = a_nxt[ks];
+        }
+        __syncthreads();
     }
+    if (!live) return;
     // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -136,15 +192,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+template <int NT>
+hipError_t launch_gemm_nt(const GemmArgs& g, int gy, hipStream_t s) {
+    const size_t lds = 2 * (size_t)NT * 32 * kGemmRowB;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const unsigned gx = (unsigned)((g.M + kGemmWaves * 32 - 1) / (kGemmWaves * 32));
+    hipLaunchKernelGGL(gemm_kernel<NT>, dim3(gx, gy), dim3(kGemmWaves * 64), lds, s, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int nt = g.N / 32;
-    const dim3 block(256);
-    const unsigned gx = (unsigned)((g.M + 127) / 128);
-    if (nt % 8 == 0) hipLaunchKernelGGL(gemm_kernel<8>, dim3(gx, nt / 8), block, 0, s, g);
-    else if (nt % 4 == 0) hipLaunchKernelGGL(gemm_kernel<4>, dim3(gx, nt / 4), block, 0, s, g);
-    else if (nt % 2 == 0) hipLaunchKernelGGL(gemm_kernel<2>, dim3(gx, nt / 2), block, 0, s, g);
-    else hipLaunchKernelGGL(gemm_kernel<1>, dim3(gx, nt), block, 0, s, g);
-    return hipGetLastError();
+    if (nt % 8 == 0) return launch_gemm_nt<8>(g, nt / 8, s);
+    if (nt % 4 == 0) return launch_gemm_nt<4>(g, nt / 4, s);
+    if (nt % 2 == 0) return launch_gemm_nt<2>(g, nt / 2, s);
+    return launch_gemm_nt<1>(g, nt, s);
 }
 
 // ---- heads ----------------------------------------------------------------------------------------------------------
@@ -210,13 +277,18 @@ struct WgradArgs {
     int n_seg; Seg seg[2];
 };
 
-// 32 samples x 32 features at P (row-major, ld) -> two operand fragments with lane = feature:
-// f[0] = samples sigma(hh, j) (first 16), f[1] = 16 + sigma(hh, j), sigma(hh, j) = (j&3) + 8(j>>2) + 4hh.
-__device__ __forceinline__ void transpose_tile(const u16* P, int ld, int r, int h, const bf16x8& ilo, const bf16x8& ihi, bf16x8 (&f)[2], float* colsum) {
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 8 * h);
-    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 16 + 8 * h);
-    f32x16 T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ilo, zero16(), 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ihi, T, 0, 0, 0);
+// 32 samples x 32 features (row-major; raw = the two 16-byte row pieces each lane loaded) -> two operand fragments with
+// lane = feature: f[0] = samples sigma(hh, j) (first 16), f[1] = 16 + sigma(hh, j), sigma(hh, j) = (j&3) + 8(j>>2) + 4hh.
+struct RawTile { bf16x8 a1, a2; };
+__device__ __forceinline__ RawTile load_tile(const u16* P, int ld, int r, int h) {
+    RawTile t;
+    t.a1 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 8 * h);
+    t.a2 = *reinterpret_cast<const bf16x8*>(P + (size_t)r * ld + 16 + 8 * h);
+    return t;
+}
+__device__ __forceinline__ void transpose_tile(const RawTile& t, const bf16x8& ilo, const bf16x8& ihi, bf16x8 (&f)[2], float* colsum) {
+    f32x16 T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.a1, ilo, zero16(), 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.a2, ihi, T, 0, 0, 0);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -248,14 +320,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) bsum[b] = 0.f;
     const bool do_bias = blockIdx.x == 0;
-    for (long long s = (long long)blockIdx.z * 4 + wave; s < g.steps; s += (long long)gridDim.z * 4) {
-        const u16* X = g.X + (size_t)s * 32 * g.ldx + k0;
-        const u16* Z = g.Z + (size_t)s * 32 * g.ldz + n0;
+    const long long stride = (long long)gridDim.z * 4;
+    long long s = (long long)blockIdx.z * 4 + wave;
+    RawTile xr[KT], zr[NT];   // one m-step ahead: the loads of step s + stride fly under the MFMAs of step s
+    auto fetch = [&](long long st) {
+        const u16* X = g.X + (size_t)st * 32 * g.ldx + k0;
+        const u16* Z = g.Z + (size_t)st * 32 * g.ldz + n0;
+#pragma unroll
+        for (int a = 0; a < KT; ++a) xr[a] = load_tile(X + 32 * a, g.ldx, r, h);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) zr[b] = load_tile(Z + 32 * b, g.ldz, r, h);
+    };
+    if (s < g.steps) fetch(s);
+    for (; s < g.steps; s += stride) {
         bf16x8 xa[KT][2], zb[NT][2];
 #pragma unroll
-        for (int a = 0; a < KT; ++a) transpose_tile(X + 32 * a, g.ldx, r, h, ilo, ihi, xa[a], nullptr);
+        for (int a = 0; a < KT; ++a) transpose_tile(xr[a], ilo, ihi, xa[a], nullptr);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) transpose_tile(Z + 32 * b, g.ldz, r, h, ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
+        for (int b = 0; b < NT; ++b) transpose_tile(zr[b], ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
+        if (s + stride < g.steps) fetch(s + stride);
 #pragma unroll
         for (int a = 0; a < KT; ++a)
 #pragma unroll
