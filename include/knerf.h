@@ -143,6 +143,9 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
  * fragments, out = [64][16] f32); kind 1 = one ds_read_b64_tr_b16 (in0 = 4 KiB LDS image, in1 = [64] int32 byte
  * offsets, out = [64][4] u16).  All device pointers. */
 int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream);
+/* MFMA-shape rate probe (shape 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16) with the chain kernels' operand
+ * traffic; `blocks` workgroups of 512 threads, 96 * 2^15 * 16 FLOP per wave and iteration.  Diagnostic only. */
+int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,91 @@ __global__ void probe_tr(const unsigned short* in, const int* addr, s16x4* out) 
     auto p = (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)lds + addr[threadIdx.x]);
     out[threadIdx.x] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
 }
+// MFMA-shape rate probes (MI355X_MICROARCH.md, DVFS give-back item 7): the chain kernels' inner loop -- one 1 KiB A fragment
+// read from LDS per 32768 FLOP, B operands in registers, dependent accumulation -- once with v_mfma_f32_32x32x16_bf16
+// and once with v_mfma_f32_16x16x32_bf16 (two 16-sample groups share each A fragment).  in0: >= 96 KiB of random bf16,
+// in1: >= 64 x 128 B of random bf16, out: one float per thread (keeps the results alive).  iters = out-tile sweeps.
+typedef __attribute__((ext_vector_type(4))) float f32x4p;
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void probe_rate(const char* in0, const bf16x8* in1, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 96 * 1024 / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(in0)[i];
+    bf16x8 b[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = in1[k * 64 + lane];
+    __syncthreads();
+    float sink = 0.f;
+    // A fragments are read 4 blocks ahead of their use, as in chain.h (Prefetch)
+    for (int it = 0; it < iters; ++it) {
+        unsigned bo = lane * 16;
+        asm volatile("" : "+v"(bo));            // the image never changes: keep hipcc from hoisting all 96 reads out of the loop
+        const char* base = lds + bo;
+        bf16x8 pf0 = *reinterpret_cast<const bf16x8*>(base), pf1 = *reinterpret_cast<const bf16x8*>(base + 1024),
+               pf2 = *reinterpret_cast<const bf16x8*>(base + 2048), pf3 = *reinterpret_cast<const bf16x8*>(base + 3072);
+        if (SHAPE == 32) {
+#pragma unroll
+            for (int ot = 0; ot < 6; ++ot) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 16; ks += 4) {
+                    const int blk = ot * 16 + ks;
+                    bf16x8 c0 = pf0; pf0 = *reinterpret_cast<const bf16x8*>(base + ((blk + 4) % 96) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b[ks], acc, 0, 0, 0);
+                    bf16x8 c1 = pf1; pf1 = *reinterpret_cast<const bf16x8*>(base + ((blk + 5) % 96) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b[ks + 1], acc, 0, 0, 0);
+                    bf16x8 c2 = pf2; pf2 = *reinterpret_cast<const bf16x8*>(base + ((blk + 6) % 96) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, b[ks + 2], acc, 0, 0, 0);
+                    bf16x8 c3 = pf3; pf3 = *reinterpret_cast<const bf16x8*>(base + ((blk + 7) % 96) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, b[ks + 3], acc, 0, 0, 0);
+                }
+                sink += acc[0] + acc[15];
+            }
+        } else {
+#pragma unroll
+            for (int ot = 0; ot < 12; ++ot) {
+                f32x4p a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ks += 4) {
+                    const int blk = ot * 8 + ks;
+                    bf16x8 c0 = pf0; pf0 = *reinterpret_cast<const bf16x8*>(base + ((blk + 4) % 96) * 1024);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b[ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b[8 + ks], a1, 0, 0, 0);
+                    bf16x8 c1 = pf1; pf1 = *reinterpret_cast<const bf16x8*>(base + ((blk + 5) % 96) * 1024);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b[ks + 1], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b[9 + ks], a1, 0, 0, 0);
+                    bf16x8 c2 = pf2; pf2 = *reinterpret_cast<const bf16x8*>(base + ((blk + 6) % 96) * 1024);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c2, b[ks + 2], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c2, b[10 + ks], a1, 0, 0, 0);
+                    bf16x8 c3 = pf3; pf3 = *reinterpret_cast<const bf16x8*>(base + ((blk + 7) % 96) * 1024);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c3, b[ks + 3], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c3, b[11 + ks], a1, 0, 0, 0);
+                }
+                sink += a0[0] + a1[3];
+            }
+        }
+    }
+    out[blockIdx.x * 512 + tid] = sink;
+}
 }  // namespace knerf
+
+extern "C" int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream) {
+    using namespace knerf;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 96 * 1024;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_rate<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_rate<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
+        done = true;
+    }
+    if (shape == 32) hipLaunchKernelGGL(probe_rate<32>, dim3(blocks), dim3(512), lds, s, (const char*)in0, (const bf16x8*)in1, (float*)out, iters);
+    else if (shape == 16) hipLaunchKernelGGL(probe_rate<16>, dim3(blocks), dim3(512), lds, s, (const char*)in0, (const bf16x8*)in1, (float*)out, iters);
+    else return KNERF_ERR_INVALID;
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
 
 extern "C" int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream) {
     using namespace knerf;
