@@ -168,12 +168,14 @@ def test_ragged_chunk_training_matches_oracle():
     ctx.close()
 
 
-@pytest.mark.parametrize("n_coarse,n_fine,white,oob", [(32, 64, False, "zero"), (48, 80, True, "clamp"), (64, 0, False, "zero")])
+@pytest.mark.parametrize("n_coarse,n_fine,white,oob", [(32, 64, False, "zero"), (48, 80, True, "clamp"), (64, 0, False, "zero"),
+                                                       (256, 256, True, "zero"),      # the largest counts the kernels accept
+                                                       (2, 3, False, "clamp")])       # and the smallest
 def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
     """sample counts other than 64+128 (the reference's own tests use 32), black background, clamp mode, and n_fine = 0"""
     from keras_nerf_amd.runtime import KnerfContext
     cfg = O.NerfConfig(n_coarse=n_coarse, n_fine=n_fine)
-    P = make_problem(n_images=1, wh=8, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    P = make_problem(n_images=1, wh=4 if n_coarse == 256 else 8, weight_scale=1.5, bias_std=0.05, cfg=cfg)
     N = P["N"]
     o, d, t, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["img"].reshape(N, 3)
     u = P["u"].reshape(N, -1) if n_fine else None
@@ -193,7 +195,8 @@ def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
     _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, white, emulate_bf16=True)
     ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
     log_stats(f"config_{n_coarse}_{n_fine}_{white}_{oob}", coarse_worst=ec[0], fine_worst=ef[0])
-    assert ec[0] < 5e-2 and ef[0] < 5e-2, (ec, ef)
+    tol = 8e-2 if n_coarse == 2 else 5e-2       # 128 + 320 samples in all: the bf16 roundings do not average out
+    assert ec[0] < tol and ef[0] < tol, (ec, ef)
     assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
     ctx.close()
 
