@@ -409,7 +409,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 
 hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     const int kt = K / 32, nt = N / 32;
-    const int KT = kt % 2 == 0 ? 2 : 1, NT = nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);
+#ifndef KNERF_GEN_MAXKT
+#define KNERF_GEN_MAXKT 2
+#endif
+#ifndef KNERF_GEN_MAXNT
+#define KNERF_GEN_MAXNT 2      // measured: 2x2 blocks (more waves in flight) 17.6 ms per default-shape chunk, 2x4 19.1, 1x4 18.7
+#endif
+    const int KT = (kt % 2 == 0 && KNERF_GEN_MAXKT >= 2) ? 2 : 1;
+    const int NT = (nt % 4 == 0 && KNERF_GEN_MAXNT >= 4) ? 4 : ((nt % 2 == 0 && KNERF_GEN_MAXNT >= 2) ? 2 : 1);
     const int gx = kt / KT, gy = nt / NT;
     long long gz = 1024 / ((long long)gx * gy);
     const long long max_z = (g.steps + 3) / 4;
