@@ -607,6 +607,7 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
         case 6: *dev = ctx->w_c; *bytes = (size_t)ctx->ws_rays * ctx->cfg.n_coarse * sizeof(float); break;
         default: return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: unknown buffer");
     }
+    if (!*dev) return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: not allocated (no pass has run yet, or the buffer belongs to the fused path and this context runs the general-shape kernels)");
     return KNERF_OK;
 }
 
