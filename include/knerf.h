@@ -68,6 +68,12 @@ int knerf_refresh_weights(knerf_ctx* ctx, void* stream);
 int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, const float* d, const float* t,
                         int n_rays, int n_samples, float* image, float* depth, float* weights);
 
+/* NeRFMLP.__call__((xyz_enc, dir_enc)) (mlp.py:29-50) on inputs that are ALREADY positional encodings:
+ * xyz_enc [n, 3+6*pos_emb_xyz], dir_enc [n, 3+6*pos_emb_dir] fp32 device pointers; raw [n,4] = (rgb after sigmoid, sigma
+ * after relu).  The reference calls its MLPs this way only to create weights and in a shape test; it runs on the
+ * general-shape kernels (bf16 operands, fp32 accumulate) for every shape, including the default one. */
+int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, const float* dir_enc, uint64_t n, float* raw);
+
 /* the fine branch's sampling (nerf.py:182-191, utils.py:60-97): t_out [R, n_coarse+n_fine] sorted.
  * u [R,n_fine] in [0,1) or NULL for the built-in Philox stream keyed by (seed, stream_id, ray_offset + ray). */
 int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const float* w_coarse, const float* u,

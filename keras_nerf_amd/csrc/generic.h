@@ -65,6 +65,9 @@ hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* pack
 // forward over n = R*S samples: fills raw [n][4] (rgb after sigmoid, sigma after relu); keeps activations for backward
 hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
                    const float* t, long long n, int S, float* raw, hipStream_t s);
+// the same on inputs that are already positional encodings: xyz_enc [n][3+6*lx], dir_enc [n][3+6*ld] (fp32)
+hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* xyz_enc,
+                           const float* dir_enc, long long n, float* raw, hipStream_t s);
 // backward from draw [n][4] (dL/d rgb, dL/d sigma): accumulates into grad_flat (fp32 atomics)
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
                     float* grad_flat, hipStream_t s);

@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ o
     for (; col < kdp; ++col) rd[col] = 0;
 }
 
+// already-encoded fp32 rows [n][dim] -> zero-padded bf16 rows [mp][ld]   (NeRFMLP.__call__ on encoded inputs, mlp.py:29-31)
+__global__ __launch_bounds__(256) void convert_rows_kernel(const float* __restrict__ src, int dim, long long n, long long mp, u16* __restrict__ dst, int ld) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mp * ld) return;
+    const long long m = i / ld;
+    const int c = (int)(i % ld);
+    dst[i] = (m < n && c < dim) ? to_bf16(src[m * dim + c]) : (u16)0;
+}
+
 // dst[:, 0:cols) = src[:, 0:cols)   (cols multiple of 8, 16-byte granules): the concat halves
 __global__ __launch_bounds__(256) void copy_cols_kernel(const u16* __restrict__ src, int lds, u16* __restrict__ dst, int ldd, long long rows, int cols) {
     const int per_row = cols / 8;
@@ -544,14 +553,11 @@ hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* pack
     return hipGetLastError();
 }
 
-hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
-                   const float* t, long long n, int S, float* raw, hipStream_t s) {
-    const long long mp = (long long)padded_rows(n);
-    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+namespace {
+// every Dense layer over the encodings already sitting in the enc_x / enc_d buffers, then the heads
+hipError_t run_layers(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, long long n, long long mp, float* raw, hipStream_t s) {
     u16* ex = act_buf(p, ws, p.buf_encx);
     u16* ed = act_buf(p, ws, p.buf_encd);
-    hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld, ex, p.kxp, ed, p.kdp);
-    GENCHK(hipGetLastError());
     for (size_t li = 0; li < p.layers.size(); ++li) {
         const Layer& L = p.layers[li];
         GemmArgs g{};
@@ -575,6 +581,27 @@ hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const 
     }
     hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ws.zs, ws.zc, n, raw);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
+                   const float* t, long long n, int S, float* raw, hipStream_t s) {
+    const long long mp = (long long)padded_rows(n);
+    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld,
+                       act_buf(p, ws, p.buf_encx), p.kxp, act_buf(p, ws, p.buf_encd), p.kdp);
+    GENCHK(hipGetLastError());
+    return run_layers(p, ws, net, w_flat, n, mp, raw, s);
+}
+
+hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* xyz_enc,
+                           const float* dir_enc, long long n, float* raw, hipStream_t s) {
+    const long long mp = (long long)padded_rows(n);
+    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(convert_rows_kernel, dim3(blocks_for(mp * p.kxp)), dim3(256), 0, s, xyz_enc, p.xyz_dim, n, mp, act_buf(p, ws, p.buf_encx), p.kxp);
+    hipLaunchKernelGGL(convert_rows_kernel, dim3(blocks_for(mp * p.kdp)), dim3(256), 0, s, dir_enc, p.dir_dim, n, mp, act_buf(p, ws, p.buf_encd), p.kdp);
+    GENCHK(hipGetLastError());
+    return run_layers(p, ws, net, w_flat, n, mp, raw, s);
 }
 
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,

@@ -79,6 +79,11 @@ struct knerf_ctx {
     gen::Plan gplan;
     gen::Workspace gws;
     gen::NetDev gnet[2];
+    // knerf_mlp_call (NeRFMLP.__call__ on encoded inputs): own plan / packed weights / workspace, also on a fused-path context
+    gen::Plan call_plan; bool call_plan_ok = false;
+    gen::Workspace call_ws;
+    gen::NetDev call_net;
+    float* call_raw = nullptr;
     // workspaces (grow-only)
     int ws_rays = 0; bool ws_train = false;
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
@@ -393,6 +398,7 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
     free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
     free_dev(ctx->gnet[0].packed); free_dev(ctx->gnet[1].packed);
+    free_dev(ctx->call_ws.act); free_dev(ctx->call_ws.zs); free_dev(ctx->call_ws.zc); free_dev(ctx->call_net.packed); free_dev(ctx->call_raw);
     delete ctx;
     return KNERF_OK;
 }
@@ -441,6 +447,34 @@ int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, c
     if (n_samples < 1 || n_samples > ctx->cfg.n_coarse + ctx->cfg.n_fine) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: n_samples out of range");
     if (int r = ensure_ws(ctx, n_rays, false)) return r;
     return run_pass(ctx, (hipStream_t)stream, net, o, d, t, n_rays, n_samples, image, depth, weights, nullptr, 1.f, nullptr);
+}
+
+int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, const float* dir_enc, uint64_t n, float* raw) {
+    if (int r = check_net(ctx, net)) return r;
+    if (!xyz_enc || !dir_enc || !raw || n == 0) return fail(ctx, KNERF_ERR_INVALID, "mlp_call: null/empty argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->call_plan_ok) {
+        const knerf_config& c = ctx->cfg;
+        ctx->call_plan = gen::build_plan(c.n_layers, c.dense_units, c.skip_layer, c.pos_emb_xyz, c.pos_emb_dir);
+        HIPCHK(hipMalloc(&ctx->call_net.packed, ctx->call_plan.packed_elems * sizeof(unsigned short)));
+        ctx->call_plan_ok = true;
+    }
+    const gen::Plan& p = ctx->call_plan;
+    const size_t mp = gen::padded_rows((long long)n);
+    gen::Workspace& w = ctx->call_ws;
+    if (mp > w.mp) {
+        free_dev(w.act); free_dev(w.zs); free_dev(w.zc); free_dev(ctx->call_raw);
+        w.mp = 0;
+        const size_t ab = p.act_elems_per_row * mp * sizeof(unsigned short);
+        HIPCHK(hipMalloc(&w.act, ab));
+        HIPCHK(hipMemset(w.act, 0, ab));
+        HIPCHK(hipMalloc(&w.zs, mp * 32 * sizeof(float)));
+        HIPCHK(hipMalloc(&w.zc, mp * 32 * sizeof(float)));
+        w.mp = mp;
+    }
+    HIPCHK(gen::pack_weights(p, ctx->net[net].w, ctx->call_net.packed, s));       // the weights may have changed since the last call
+    HIPCHK(gen::forward_encoded(p, w, ctx->call_net, ctx->net[net].w, xyz_enc, dir_enc, (long long)n, raw, s));
+    return KNERF_OK;
 }
 
 int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const float* w_coarse, const float* u,

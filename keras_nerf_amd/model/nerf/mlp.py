@@ -123,28 +123,26 @@ class NeRFMLP:
         return self.call(inputs)
 
     def call(self, inputs):
-        """Evaluates the MLP on already encoded inputs [..., xyz_dim] / [..., dir_dim].  The reference's NeRF never
-        calls its MLPs this way outside _build_model (weights creation) and a shape test; the fused kernels start from
-        ray origins/directions instead, so this entry point is served by a plain fp32 torch evaluation of the same
-        layer sequence (bias add, ReLU trunk with skip concat, ReLU sigma, linear features / rgb_features, sigmoid rgb)."""
+        """Evaluates the MLP on already encoded inputs [..., xyz_dim] / [..., dir_dim] (mlp.py:29-50).  The reference's
+        NeRF never calls its MLPs this way outside _build_model (weight creation) and a shape test; the fused kernels
+        start from ray origins/directions instead, so this entry point runs on the general-shape HIP kernels
+        (knerf_mlp_call: bf16 matmul operands, fp32 accumulate/bias/activation) for every shape."""
         xyz, dire = inputs
         if not torch.cuda.is_available():
             from ...runtime import KnerfError
             raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
-        dev = self._ctx.device if self._ctx is not None else "cuda"
-        xyz = torch.as_tensor(np.asarray(xyz, np.float32) if not isinstance(xyz, torch.Tensor) else xyz).to(dev, torch.float32)
-        dire = torch.as_tensor(np.asarray(dire, np.float32) if not isinstance(dire, torch.Tensor) else dire).to(dev, torch.float32)
-        w = [torch.as_tensor(a).to(dev) for a in self.get_weights()]
-        h, p = xyz, 0
-        for i in range(self.n_layers):
-            h = torch.relu(h @ w[p] + w[p + 1]); p += 2
-            if i % self.skip_layer == 0 and i > 0:
-                h = torch.cat([h, xyz], dim=-1)
-        sigma = torch.relu(h @ w[p] + w[p + 1]); p += 2
-        feat = h @ w[p] + w[p + 1]; p += 2
-        f2 = torch.cat([feat, dire], dim=-1) @ w[p] + w[p + 1]; p += 2
-        rgb = torch.sigmoid(f2 @ w[p] + w[p + 1])
-        return rgb, sigma
+        ctx, net = self._ctx, self._net
+        if ctx is None:                      # stand-alone MLP (reference test_nerf_mlp.py): a private context of this shape
+            if getattr(self, "_own_ctx", None) is None:
+                from ...runtime import KnerfContext
+                self._own_ctx = KnerfContext(pos_emb_xyz=(self.xyz_dim - 3) // 6, pos_emb_dir=(self.dir_dim - 3) // 6,
+                                             n_layers=self.n_layers, dense_units=self.dense_units, skip_layer=self.skip_layer)
+            ctx, net = self._own_ctx, 0
+            ctx.set_weights(0, self.get_flat_weights())
+        xyz = ctx.f32(xyz); dire = ctx.f32(dire)
+        lead = tuple(xyz.shape[:-1])
+        raw = ctx.mlp_call(net, xyz.reshape(-1, self.xyz_dim), dire.reshape(-1, self.dir_dim))
+        return raw[:, :3].reshape(lead + (3,)), raw[:, 3:4].reshape(lead + (1,))
 
     def get_config(self):
         return {"name": self.name, "n_layers": self.n_layers, "dense_units": self.dense_units, "skip_layer": self.skip_layer}

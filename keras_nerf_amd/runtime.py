@@ -167,6 +167,14 @@ class KnerfContext:
         """0: dgrad and wgrad as separate launches; P>0: one launch, P persistent dgrad workgroups feeding the wgrad ones."""
         self._check(self.lib.knerf_set_fused_backward(self._ctx, int(producers)))
 
+    def mlp_call(self, net: int, xyz_enc, dir_enc) -> torch.Tensor:
+        """NeRFMLP.__call__ on already encoded inputs [n, xyz_dim] / [n, dir_dim]: raw [n,4] = (rgb, sigma)"""
+        x, dd = self.f32(xyz_enc).contiguous(), self.f32(dir_enc).contiguous()
+        n = x.shape[0]
+        raw = torch.empty((n, 4), device=self.device, dtype=torch.float32)
+        self._check(self.lib.knerf_mlp_call(self._ctx, self._stream(), int(net), _ptr(x), _ptr(dd), n, _ptr(raw)))
+        return raw
+
     def zero_grads(self):
         self._check(self.lib.knerf_zero_grads(self._ctx, self._stream()))
 

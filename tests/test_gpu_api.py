@@ -145,6 +145,22 @@ def test_nerf_mlp_call_shapes():
     rgb, sigma = m((torch.rand(200, 32, 63), torch.rand(200, 32, 27)))                # reference test_nerf_mlp.py:6-33
     assert rgb.shape == (200, 32, 3) and sigma.shape == (200, 32, 1)
     assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 and float(sigma.min()) >= 0
+    # values: the oracle's MLP on the same encoded inputs and weights (bf16 operands on the GPU)
+    from oracle import nerf_oracle as O
+    cfg = O.NerfConfig()
+    x = np.random.default_rng(0).random((64, 63), dtype=np.float32) * 2 - 1
+    dd = np.random.default_rng(1).random((64, 27), dtype=np.float32) * 2 - 1
+    params = m.get_weights()
+    er, es = O.mlp_forward(params, x, dd, cfg, emulate_bf16=True)
+    gr, gs = m((x, dd))
+    np.testing.assert_allclose(gr.cpu().numpy(), er, atol=2e-3)
+    np.testing.assert_allclose(gs.cpu().numpy(), es, atol=2e-3)
+    er32, es32 = O.mlp_forward(params, x, dd, cfg)
+    np.testing.assert_allclose(gr.cpu().numpy(), er32, atol=2e-2)
+    # other shapes (reference test passes arbitrary constructor arguments)
+    m2 = NeRFMLP(3, 64, 2, xyz_dim=27, dir_dim=15)
+    r2, s2 = m2((torch.rand(10, 27), torch.rand(10, 15)))
+    assert r2.shape == (10, 3) and s2.shape == (10, 1)
 
 
 def test_rccl_all_reduce_on_library_owned_gradient_buffer():
