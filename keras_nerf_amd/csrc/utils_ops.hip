@@ -2,6 +2,7 @@
 // utility class directly (reference keras_nerf/model/nerf/utils.py).  The train/render path does not use these: there
 // the same arithmetic is fused into mlp_fwd.hip / sampler.hip.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include "../../include/knerf.h"
 #include "kernels.h"
 
@@ -56,9 +57,67 @@ __global__ void inverse_cdf_kernel(const float* mids, const float* w, const floa
     }
 }
 
+// tf.image.psnr / tf.image.ssim with their defaults as logged by NeRF.update_and_return_metrics (nerf.py:306-330):
+// SSIM = mean over VALID 11x11 Gaussian (sigma 1.5) windows and channels of luminance x contrast-structure, k1 0.01,
+// k2 0.03, max_val 1.  One thread per window position; out[b] = {sum of window-channel SSIM terms, sum of squared
+// differences}; the two divisions and the log10 happen on the host side of the call.
+struct MetricArgs { const float* a; const float* b; float* out; int H, W, C; float g[11]; };
+__global__ __launch_bounds__(256) void image_metrics_kernel(MetricArgs m) {
+    const int img = blockIdx.y;
+    const int wh = m.H - 10, ww = m.W - 10;
+    const float* A = m.a + (size_t)img * m.H * m.W * m.C;
+    const float* B = m.b + (size_t)img * m.H * m.W * m.C;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float ssum = 0.f, sq = 0.f;
+    if (idx < wh * ww) {
+        const int wi = idx / ww, wj = idx % ww;
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        for (int c = 0; c < m.C; ++c) {
+            float mx = 0.f, my = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+            for (int di = 0; di < 11; ++di)
+                for (int dj = 0; dj < 11; ++dj) {
+                    const float w = m.g[di] * m.g[dj];
+                    const size_t p = ((size_t)(wi + di) * m.W + (wj + dj)) * m.C + c;
+                    const float x = A[p], y = B[p];
+                    mx += w * x; my += w * y; xx += w * x * x; yy += w * y * y; xy += w * x * y;
+                }
+            const float sxx = xx - mx * mx, syy = yy - my * my, sxy = xy - mx * my;
+            ssum += (2.f * mx * my + c1) / (mx * mx + my * my + c1) * ((2.f * sxy + c2) / (sxx + syy + c2));
+        }
+    }
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)m.H * m.W * m.C; p += (size_t)gridDim.x * 256) {
+        const float d = A[p] - B[p];
+        sq += d * d;
+    }
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ssum += __shfl_xor(ssum, o, 64); sq += __shfl_xor(sq, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ssum; red[1][threadIdx.x >> 6] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(m.out + 2 * img, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(m.out + 2 * img + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
 }  // namespace knerf
 
 using namespace knerf;
+
+extern "C" int knerf_image_metrics(void* stream, const float* a, const float* b, int n_images, int height, int width, int channels,
+                                   float* sums) {
+    if (!a || !b || !sums || n_images <= 0 || channels <= 0 || height < 11 || width < 11) return KNERF_ERR_INVALID;
+    MetricArgs m{};
+    m.a = a; m.b = b; m.out = sums; m.H = height; m.W = width; m.C = channels;
+    double g[11], tot = 0.0;
+    for (int k = 0; k < 11; ++k) { g[k] = std::exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); tot += g[k]; }
+    for (int k = 0; k < 11; ++k) m.g[k] = (float)(g[k] / tot);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, (size_t)n_images * 2 * sizeof(float), s) != hipSuccess) return KNERF_ERR_HIP;
+    const int windows = (height - 10) * (width - 10);
+    hipLaunchKernelGGL(image_metrics_kernel, dim3((windows + 255) / 256, n_images), dim3(256), 0, s, m);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
 
 extern "C" int knerf_positional_encoding(void* stream, const float* x, long long n_rows, int L, float* out) {
     if (!x || !out || n_rows <= 0 || L < 0 || L > 30) return KNERF_ERR_INVALID;

@@ -1,11 +1,10 @@
 """Keras-style running Mean and the two image metrics the reference logs (nerf.py:306-330): tf.image.psnr and
-tf.image.ssim with their defaults.  Host-side bookkeeping on CUDA tensors; not part of the fused hot path."""
+tf.image.ssim with their defaults, computed by one HIP kernel (knerf_image_metrics); the running means are host-side."""
 from __future__ import annotations
 
 import math
 
 import torch
-import torch.nn.functional as F
 
 
 class Mean:
@@ -28,30 +27,36 @@ class Mean:
         return self.total / self.count if self.count else 0.0
 
 
+def _image_sums(a, b):
+    """[B,H,W,C] CUDA tensors -> per-image (SSIM term sum, squared-difference sum) from the HIP kernel (csrc/utils_ops.hip)"""
+    from ... import _lib
+    if not (isinstance(a, torch.Tensor) and a.is_cuda):
+        from ...runtime import KnerfError
+        raise KnerfError("image metrics run on the MI355X (knerf_image_metrics); there is no CPU path")
+    a = a.to(torch.float32).contiguous(); b = b.to(device=a.device, dtype=torch.float32).contiguous()
+    if a.shape != b.shape or a.dim() != 4:
+        raise ValueError("expected two [B,H,W,C] tensors of the same shape")
+    B, H, W, C = a.shape
+    if H < 11 or W < 11:
+        raise ValueError("ssim needs images of at least 11x11")
+    sums = torch.empty((B, 2), device=a.device, dtype=torch.float32)
+    rc = _lib.load().knerf_image_metrics(torch.cuda.current_stream(a.device).cuda_stream, a.data_ptr(), b.data_ptr(), B, H, W, C,
+                                         sums.data_ptr())
+    if rc != 0:
+        from ...runtime import KnerfError
+        raise KnerfError(f"knerf_image_metrics failed ({rc})")
+    return sums, (H - 10) * (W - 10) * C, H * W * C
+
+
 def psnr(a, b, max_val=1.0):
     """tf.image.psnr: per image over the last three axes"""
-    mse = torch.mean((a - b) ** 2, dim=(-3, -2, -1))
-    return 20.0 * math.log10(max_val) - 10.0 * torch.log10(mse)
+    sums, _, n = _image_sums(a, b)
+    return 20.0 * math.log10(max_val) - 10.0 * torch.log10(sums[:, 1] / n)
 
 
-def _gauss(size=11, sigma=1.5, device="cpu"):
-    x = torch.arange(size, dtype=torch.float32, device=device) - (size - 1) / 2.0
-    g = torch.exp(-(x ** 2) / (2 * sigma ** 2))
-    g = g / g.sum()
-    return torch.outer(g, g)
-
-
-def ssim(a, b, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
-    """tf.image.ssim defaults: 11x11 Gaussian (sigma 1.5), VALID windows, mean over windows and channels; [B,H,W,C]."""
-    x = a.permute(0, 3, 1, 2); y = b.permute(0, 3, 1, 2)
-    C = x.shape[1]
-    if x.shape[-1] < filter_size or x.shape[-2] < filter_size:
-        raise ValueError(f"ssim needs images of at least {filter_size}x{filter_size}")
-    w = _gauss(filter_size, filter_sigma, x.device)[None, None].repeat(C, 1, 1, 1)
-    conv = lambda z: F.conv2d(z, w, groups=C)
-    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
-    mx, my = conv(x), conv(y)
-    sxx, syy, sxy = conv(x * x) - mx * mx, conv(y * y) - my * my, conv(x * y) - mx * my
-    lum = (2 * mx * my + c1) / (mx * mx + my * my + c1)
-    cs = (2 * sxy + c2) / (sxx + syy + c2)
-    return torch.mean(lum * cs, dim=(1, 2, 3))
+def ssim(a, b, max_val=1.0):
+    """tf.image.ssim defaults: 11x11 Gaussian (sigma 1.5), VALID windows, k1 0.01, k2 0.03, mean over windows and channels"""
+    if max_val != 1.0:
+        raise ValueError("the kernel implements max_val = 1 (the reference's call, nerf.py:310-321)")
+    sums, nwin, _ = _image_sums(a, b)
+    return sums[:, 0] / nwin

@@ -505,6 +505,24 @@ def psnr(a, b, max_val=1.0):
     return 20.0 * np.log10(max_val) - 10.0 * np.log10(m)
 
 
+def ssim(a, b, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """tf.image.ssim with its defaults as called at nerf.py:313-321 (TF documentation semantics, not runnable here):
+    Gaussian window 11x11 sigma 1.5, VALID positions, per channel luminance x contrast-structure, mean over windows and
+    channels.  a, b [B,H,W,C]; float64 arithmetic."""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    x = np.arange(filter_size, dtype=np.float64) - (filter_size - 1) / 2.0
+    g = np.exp(-(x ** 2) / (2 * filter_sigma ** 2)); g /= g.sum()
+    w = np.outer(g, g)
+    win = lambda z: np.lib.stride_tricks.sliding_window_view(z, (filter_size, filter_size), axis=(1, 2))   # [B,h,w,C,f,f]
+    conv = lambda z: np.einsum("bhwcij,ij->bhwc", win(z), w)
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    mx, my = conv(a), conv(b)
+    sxx, syy, sxy = conv(a * a) - mx * mx, conv(b * b) - my * my, conv(a * b) - mx * my
+    lum = (2 * mx * my + c1) / (mx * mx + my * my + c1)
+    cs = (2 * sxy + c2) / (sxx + syy + c2)
+    return np.mean(lum * cs, axis=(1, 2, 3))
+
+
 # --------------------------------------------------------------------------------------
 # data side: rays and poses  (keras_nerf/data/rays.py, keras_nerf/data/utils.py)
 # --------------------------------------------------------------------------------------

@@ -139,6 +139,20 @@ def test_rays_generator_like_reference_test():
         last = (o, d, t)
 
 
+def test_image_metrics_kernel_against_oracle_definitions():
+    from keras_nerf_amd.model.nerf.metrics import psnr, ssim
+    rng = np.random.default_rng(0)
+    for shape in ((2, 16, 16, 3), (3, 37, 53, 3), (1, 128, 128, 3), (1, 11, 11, 1)):
+        a = rng.random(shape, dtype=np.float32)
+        b = np.clip(a + 0.1 * rng.standard_normal(shape).astype(np.float32), 0, 1)
+        ta, tb = torch.tensor(a, device="cuda"), torch.tensor(b, device="cuda")
+        np.testing.assert_allclose(psnr(ta, tb).cpu().numpy(), O.psnr(a, b), rtol=1e-5)
+        np.testing.assert_allclose(ssim(ta, tb).cpu().numpy(), O.ssim(a, b), atol=2e-5)
+        assert float(ssim(ta, ta)[0]) == pytest.approx(1.0, abs=1e-5)
+    with pytest.raises(ValueError):
+        ssim(ta[:, :8, :8], tb[:, :8, :8])
+
+
 def test_nerf_mlp_call_shapes():
     from keras_nerf_amd.model.nerf.mlp import NeRFMLP
     m = NeRFMLP(8, 256, 4)
