@@ -120,12 +120,14 @@ int knerf_generate_rays(knerf_ctx* ctx, void* stream, const float* c2w, const fl
  * inverse_cdf = fine_hierarchical_sampling_chunk (utils.py:60-97) with u injected: mid_points [R,n_mid],
  *   weights [R,n_weights], u [R,n_samples] -> out [R,n_samples] (unsorted). */
 int knerf_positional_encoding(void* stream, const float* x, long long n_rows, int L, float* out);
+/* ray(t) = o + t d (utils.py:193-194): o, d [R,3], t [R,S] -> out [R,S,3] */
+int knerf_ray_points(void* stream, const float* o, const float* d, const float* t, int n_rays, int n_samples, float* out);
 /* the two image metrics NeRF.update_and_return_metrics logs (nerf.py:306-330; tf.image.psnr / tf.image.ssim defaults):
  * a, b [n_images, H, W, C] device; sums [n_images][2] = {sum of the SSIM terms over the (H-10)(W-10) VALID windows and C
  * channels, sum of squared differences}: ssim = sums[0] / ((H-10)(W-10)C), psnr = -10 log10(sums[1] / (HWC)). */
 int knerf_image_metrics(void* stream, const float* a, const float* b, int n_images, int height, int width, int channels,
                         float* sums);
-int knerf_composite(void* stream, const float* raw, const float* t, int n_rays, int n_samples, int white_background,
+int knerf_composite(void* stream, const float* raw, const float* t, int n_rays, int n_samples, int white_background /* bit 0: white background, bit 1: no clip (utils.py:99-134) */,
                     float* image, float* depth, float* weights);
 int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weights, const float* u, int n_rays, int n_mid,
                       int n_weights, int n_samples, int oob_clamp, float* out);

@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     }
     sr = wave_sum(sr); sgc = wave_sum(sgc); sb = wave_sum(sb); sd = wave_sum(sd); sw = wave_sum(sw);
     float pre[3] = {sr, sgc, sb};
-    if (a.white) { const float bg = 1.f - sw; pre[0] += bg; pre[1] += bg; pre[2] += bg; }
+    if (a.white & 1) { const float bg = 1.f - sw; pre[0] += bg; pre[1] += bg; pre[2] += bg; }
     float img[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) img[k] = fminf(fmaxf(pre[k], 0.f), 1.f);
+    for (int k = 0; k < 3; ++k) img[k] = (a.white & 2) ? pre[k] : fminf(fmaxf(pre[k], 0.f), 1.f);   // bit 1: the non-chunk twin (utils.py:99-134) does not clip
     if (lane < 3) a.image[(size_t)ray * 3 + lane] = lane == 0 ? img[0] : (lane == 1 ? img[1] : img[2]);
     if (a.depth && lane == 0) a.depth[ray] = sd;
     if (a.weights) {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     if (lane == 0) s_loss[wv] = l2 * a.loss_scale;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(a.loss, (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
-    const float gsum = a.white ? (gi[0] + gi[1] + gi[2]) : 0.f;
+    const float gsum = (a.white & 1) ? (gi[0] + gi[1] + gi[2]) : 0.f;
     float dw[C], pr[C];
     float suffix = 0.f;            // lane-local exclusive suffix sums of dw*w, built right to left
     float Ql[C];

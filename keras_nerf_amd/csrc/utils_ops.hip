@@ -57,6 +57,16 @@ __global__ void inverse_cdf_kernel(const float* mids, const float* w, const floa
     }
 }
 
+// ray(t) = o + t d for every sample (utils.py:193-194), separate multiply and add like the reference's two ops
+__global__ __launch_bounds__(256) void ray_points_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ t,
+                                                        long long n, int S, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 3) return;
+    const long long m = i / 3; const int c = (int)(i % 3);
+    const long long ray = m / S;
+    out[i] = __fadd_rn(o[ray * 3 + c], __fmul_rn(d[ray * 3 + c], t[m]));
+}
+
 // tf.image.psnr / tf.image.ssim with their defaults as logged by NeRF.update_and_return_metrics (nerf.py:306-330):
 // SSIM = mean over VALID 11x11 Gaussian (sigma 1.5) windows and channels of luminance x contrast-structure, k1 0.01,
 // k2 0.03, max_val 1.  One thread per window position; out[b] = {sum of window-channel SSIM terms, sum of squared
@@ -103,6 +113,13 @@ __global__ __launch_bounds__(256) void image_metrics_kernel(MetricArgs m) {
 }  // namespace knerf
 
 using namespace knerf;
+
+extern "C" int knerf_ray_points(void* stream, const float* o, const float* d, const float* t, int n_rays, int n_samples, float* out) {
+    if (!o || !d || !t || !out || n_rays <= 0 || n_samples <= 0) return KNERF_ERR_INVALID;
+    const long long n = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(ray_points_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, d, t, n, n_samples, out);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
 
 extern "C" int knerf_image_metrics(void* stream, const float* a, const float* b, int n_images, int height, int width, int channels,
                                    float* sums) {

@@ -252,7 +252,10 @@ class NeRF:
         images, rays = inputs
         images = self._ctx.f32(images)[..., :3].contiguous()
         coarse, fine = self.predict_and_render_images(rays, u)
-        cl = torch.mean((images - coarse["image"]) ** 2); fl = torch.mean((images - fine["image"]) ** 2)
+        # whole-image MSE (nerf.py:484-487) from the metrics kernel's squared-difference sums
+        from .metrics import _image_sums
+        (sc, _, npx), (sf, _, _) = _image_sums(images, coarse["image"]), _image_sums(images, fine["image"])
+        cl = sc[:, 1].sum() / (npx * images.shape[0]); fl = sf[:, 1].sum() / (npx * images.shape[0])
         return self.update_and_return_metrics(images, coarse["image"], fine["image"], cl, fl)
 
     # ------------------------------------------------------------------ fit: the part of tf.keras.Model.fit the reference uses

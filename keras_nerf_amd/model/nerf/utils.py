@@ -53,7 +53,11 @@ class NeRFUtils:
     # utils.py:188-210
     def encode_position_and_directions(self, ray_origin, ray_direction, coarse_points):
         o, d, t = _dev(ray_origin), _dev(ray_direction), _dev(coarse_points)
-        pos = o[..., None, :] + d[..., None, :] * t[..., None]          # ray(t) = o + t d (utils.py:193-194)
+        S = t.shape[-1]
+        R = t.numel() // S
+        pos = torch.empty(tuple(t.shape) + (3,), device="cuda")
+        self._chk(self._lib.knerf_ray_points(_stream(), _p(o.reshape(R, 3).contiguous()), _p(d.reshape(R, 3).contiguous()),
+                                             _p(t.reshape(R, S).contiguous()), R, S, _p(pos)))   # ray(t) = o + t d (utils.py:193-194)
         enc = self.positional_encoding(pos, self.pos_emb_xyz)
         dirs = d[..., None, :].expand_as(pos).contiguous()
         return enc, self.positional_encoding(dirs, self.pos_emb_dir)
@@ -64,20 +68,18 @@ class NeRFUtils:
         R = t.numel() // S
         raw = torch.cat([rgb.reshape(R, S, 3), sigma.reshape(R, S, 1)], dim=-1).contiguous()
         image = torch.empty((R, 3), device="cuda"); depth = torch.empty((R,), device="cuda"); w = torch.empty((R, S), device="cuda")
-        self._chk(self._lib.knerf_composite(_stream(), _p(raw), _p(t.reshape(R, S)), R, S, int(bool(white)), _p(image), _p(depth), _p(w)))
+        self._chk(self._lib.knerf_composite(_stream(), _p(raw), _p(t.reshape(R, S)), R, S, int(white), _p(image), _p(depth), _p(w)))
         return image.reshape(lead + (3,)), depth.reshape(lead), w.reshape(lead + (S,))
 
     # utils.py:16-58 (epsilon is the reference's fixed 1e-10)
     def render_image_depth_chunk(self, rgb, sigma, sample_points, epsilon=1e-10):
         if epsilon != 1e-10:
             raise ValueError("the kernel implements the reference's epsilon = 1e-10")
-        return self._composite(rgb, sigma, sample_points, self.white_background)
+        return self._composite(rgb, sigma, sample_points, 1 if self.white_background else 0)
 
     # utils.py:99-134: the non-chunk twin omits the white background AND the clip
     def render_image_depth(self, rgb, sigma, sample_points, epsilon=1e-10):
-        rgb_t, t = _dev(rgb), _dev(sample_points)
-        _, depth, w = self._composite(rgb_t, sigma, t, False)
-        return torch.sum(w[..., None] * rgb_t, dim=-2), depth, w
+        return self._composite(rgb, sigma, sample_points, 2)          # mode bit 1: black background, no clip
 
     def _inverse_cdf(self, mid_points, weights, n_samples, u=None):
         m, w = _dev(mid_points), _dev(weights)
