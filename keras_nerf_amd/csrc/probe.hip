@@ -88,6 +88,49 @@ __global__ __launch_bounds__(512, 2) void probe_rate(const char* in0, const bf16
     }
     out[blockIdx.x * 512 + tid] = sink;
 }
+// the same loop with 64 samples per wave: 4 waves per workgroup (one per SIMD), every A fragment feeds TWO B tiles, so
+// the LDS bytes per FLOP halve (candidate layout for the inference kernel)
+__global__ __launch_bounds__(256) void probe_rate64(const char* in0, const bf16x8* in1, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 96 * 1024 / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(in0)[i];
+    bf16x8 b0[16], b1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { b0[k] = in1[k * 64 + lane]; b1[k] = in1[(16 + k) * 64 + lane]; }
+    __syncthreads();
+    float sink = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        unsigned bo = lane * 16;
+        asm volatile("" : "+v"(bo));
+        const char* base = lds + bo;
+        bf16x8 pf0 = *reinterpret_cast<const bf16x8*>(base), pf1 = *reinterpret_cast<const bf16x8*>(base + 1024),
+               pf2 = *reinterpret_cast<const bf16x8*>(base + 2048), pf3 = *reinterpret_cast<const bf16x8*>(base + 3072);
+#pragma unroll
+        for (int ot = 0; ot < 6; ++ot) {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 4) {
+                const int blk = ot * 16 + ks;
+                bf16x8 c0 = pf0; pf0 = *reinterpret_cast<const bf16x8*>(base + ((blk + 4) % 96) * 1024);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b0[ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b1[ks], a1, 0, 0, 0);
+                bf16x8 c1 = pf1; pf1 = *reinterpret_cast<const bf16x8*>(base + ((blk + 5) % 96) * 1024);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b0[ks + 1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b1[ks + 1], a1, 0, 0, 0);
+                bf16x8 c2 = pf2; pf2 = *reinterpret_cast<const bf16x8*>(base + ((blk + 6) % 96) * 1024);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, b0[ks + 2], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, b1[ks + 2], a1, 0, 0, 0);
+                bf16x8 c3 = pf3; pf3 = *reinterpret_cast<const bf16x8*>(base + ((blk + 7) % 96) * 1024);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, b0[ks + 3], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, b1[ks + 3], a1, 0, 0, 0);
+            }
+            sink += a0[0] + a1[15];
+        }
+    }
+    out[blockIdx.x * 256 + tid] = sink;
+}
 }  // namespace knerf
 
 extern "C" int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream) {
@@ -99,6 +142,15 @@ extern "C" int knerf_debug_rate_probe(int shape, const void* in0, const void* in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_rate<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_rate<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
         done = true;
+    }
+    if (shape == 64) {
+        static bool done64 = false;
+        if (!done64) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_rate64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
+            done64 = true;
+        }
+        hipLaunchKernelGGL(probe_rate64, dim3(blocks), dim3(256), lds, s, (const char*)in0, (const bf16x8*)in1, (float*)out, iters);
+        return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
     }
     if (shape == 32) hipLaunchKernelGGL(probe_rate<32>, dim3(blocks), dim3(512), lds, s, (const char*)in0, (const bf16x8*)in1, (float*)out, iters);
     else if (shape == 16) hipLaunchKernelGGL(probe_rate<16>, dim3(blocks), dim3(512), lds, s, (const char*)in0, (const bf16x8*)in1, (float*)out, iters);

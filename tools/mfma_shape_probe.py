@@ -19,7 +19,7 @@ out = torch.empty(blocks * 512, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 flop = blocks * 8 * iters * 96 * 32768
 for rep in range(2):
-    for shape in (32, 16, 32, 16):
+    for shape in (32, 16, 64, 32, 16, 64):
         for _ in range(2):
             assert lib.knerf_debug_rate_probe(shape, a.data_ptr(), b.data_ptr(), out.data_ptr(), blocks, iters, s) == 0
         torch.cuda.synchronize()
@@ -29,4 +29,4 @@ for rep in range(2):
             lib.knerf_debug_rate_probe(shape, a.data_ptr(), b.data_ptr(), out.data_ptr(), blocks, iters, s)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print(json.dumps({"shape": "32x32x16" if shape == 32 else "16x16x32", "ms": round(ms, 3), "TFLOPs": round(flop / ms / 1e9, 1)}), flush=True)
+        print(json.dumps({"shape": {32: "32x32x16", 16: "16x16x32", 64: "32x32x16, 64 samples per wave, 4 waves per CU"}[shape], "ms": round(ms, 3), "TFLOPs": round(flop / ms / 1e9, 1)}), flush=True)
