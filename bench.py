@@ -239,9 +239,9 @@ def main():
         s_fine, s_coarse = chunks * (nerf.n_coarse + nerf.n_fine), chunks * nerf.n_coarse
         per_launch_samples = s_coarse if dom.endswith("coarse") else s_fine
         flop = {"mlp_fwd": FWD_FLOP, "mlp_bwd": DGRAD_FLOP, "wgrad": WGRAD_FLOP}.get(dom.rsplit("_", 1)[0], 0) * per_launch_samples
-        # wgrad streams the saved activations and dZ once: (158 + 156) KiB per 32-sample tile + re-read of enc/h7
+        # wgrad streams the saved activations and dZ once: (158 + 156) KiB per 32-sample tile + 4 KiB re-read of enc
         if dom.startswith("wgrad"):
-            byts = per_launch_samples / 32 * 334 * 1024
+            byts = per_launch_samples / 32 * 318 * 1024
             roofline = {"bound": "hbm", "kernel": dom, "achieved": byts / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
         else:

@@ -120,14 +120,18 @@ __device__ __forceinline__ void poll_flag_blocking(const unsigned* f, unsigned e
     if ((threadIdx.x & 63) == 0) atomicExch(abort_flag, 1);
 }
 
-template <int NI, int NO, class Seq>
+// SIG (the `features` job only): the `sigma` head reads the same input h7 and its dZ tile sits right behind dfeat in the dZ
+// run, so its gradient is one more B fragment and one more accumulator per wave here (wave w takes input tile w, wave 0
+// also the bias row) instead of a job of its own that would read h7 from HBM a second time.
+template <int NI, int NO, class Seq, bool SIG = false>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
                                                const Seq seq, char* smem) {
     constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
     constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
     constexpr int ROWS = NI + 1;
     constexpr int NACC = (ROWS + WI - 1) / WI;
-    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO;
+    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO + (SIG ? 2 : 0);
+    static_assert(!SIG || (NO == 8 && NI == 8), "SIG rides on the 8 x 8 features job");
     constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
     constexpr int G_IN = (BLK_IN + kWgWaves - 1) / kWgWaves, G_DZ = (BLK_DZ + kWgWaves - 1) / kWgWaves;
     constexpr int G = G_IN + G_DZ + (Seq::kFlags ? 1 : 0);   // LDS-DMA instructions per wave per iteration (uniform)
@@ -194,6 +198,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     f32x16 acc[NACC];
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
+    f32x16 acc_s = zero_acc(), acc_sb = zero_acc();      // SIG: sigma kernel rows of input tile `wave`; sigma bias (wave 0)
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -239,6 +244,14 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             }
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
+            if constexpr (SIG) {
+                const bf16x8 bs = tr_frag(dz_reg, NO, kk, lane_off);             // the sigma dZ tile: pair NO of the dZ region
+                static_for<NI>([&](auto n_) {                                    // uniform branch: input tile `wave`
+                    constexpr int n = decltype(n_)::value;
+                    if (wave == n) acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], bs, acc_s, 0, 0, 0);
+                });
+                if (wave == 0) acc_sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bs, acc_sb, 0, 0, 0);
+            }
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
 #ifdef KNERF_WGRAD_STAMPS
@@ -274,6 +287,19 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
         }
     }
+    if constexpr (SIG) {
+        const int* ds = a.dst + a.job_off[9];            // the sigma job's table: (32 NI + 1) rows x 32 columns
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int d = ds[row * 32 + c];
+            if (d >= 0) atomicAdd(a.grad + d, acc_s[i]);
+        }
+        if (wave == 0) {
+            const int d = ds[NI * 32 * 32 + c];
+            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc_sb[0]);
+        }
+    }
 }
 
 // one job of the plan over the given tile sequence
@@ -288,8 +314,12 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, cons
         case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, seq, smem); break;
         case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, seq, smem); break;
         case 7: wgrad_job_body<8, 8>(a, 7, act_h(6), 16 * 7, seq, smem); break;
+#ifdef KNERF_SEPARATE_SIGMA_JOB
         case 8: wgrad_job_body<8, 8>(a, 8, kActH7, kDzFeat, seq, smem); break;
         case 9: wgrad_job_body<8, 1>(a, 9, kActH7, kDzSig, seq, smem); break;
+#else
+        case 8: wgrad_job_body<8, 8, Seq, true>(a, 8, kActH7, kDzFeat, seq, smem); break;     // features + sigma
+#endif
         case 10: wgrad_job_body<9, 4>(a, 10, kActFeat, kDzF2, seq, smem); break;
         case 11: wgrad_job_body<4, 1>(a, 11, kActF2, kDzRgb, seq, smem); break;
         default: break;
