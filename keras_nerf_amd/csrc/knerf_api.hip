@@ -39,7 +39,7 @@ struct Tables {
 // s_memtime stamps of a -DKNERF_WGRAD_STAMPS build, tools/kbench.py): the streaming jobs are HBM-bound, the small ones
 // (sigma, rgb heads) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
 #ifndef KNERF_FEATSIG_COST
-#define KNERF_FEATSIG_COST 260      // swept 225..340 with tools/kbench.py: 1.27 ms per fine launch at 260 (1.43 at 225, 1.31 at 340)
+#define KNERF_FEATSIG_COST 260      // swept 225..340 with tools/kbench.py (1.43 ms per fine launch at 225, 1.27 at 260, 1.31 at 340)
 #endif
 std::vector<int32_t> build_wgrad_plan(int n_wg) {
     int cost[kWgradJobs], total = 0;
@@ -50,7 +50,8 @@ std::vector<int32_t> build_wgrad_plan(int n_wg) {
 #ifdef KNERF_SEPARATE_SIGMA_JOB
             if (j == 0) c = 109; else if (j == 5) c = 248; else if (j == 9) c = 106; else if (j == 10) c = 162; else if (j == 11) c = 73;
             else c = 204;
-#else       // the sigma head rides on the features job (wgrad_body.h, SIG): no workgroups of its own, features a little dearer
+#else       // the sigma head rides on the features job (wgrad_body.h, SIG): no workgroups of its own.  Re-deriving every weight
+            // from the final kernels' stamps (104/195/243/240/162/88) was not better than these (1.31 vs 1.29 ms per fine launch)
             if (j == 0) c = 109; else if (j == 5) c = 248; else if (j == 8) c = KNERF_FEATSIG_COST; else if (j == 9) c = 0;
             else if (j == 10) c = 162; else if (j == 11) c = 73;
             else c = 204;

@@ -245,12 +245,13 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
             if constexpr (SIG) {
+                // branch-free: the wave re-reads "its" input tile by a run-time pair index (LDS has headroom) instead of
+                // selecting among afr[] -- eight uniform branches around single MFMAs cost 700 cycles per tile; every wave
+                // accumulates the bias row, wave 0 flushes it
                 const bf16x8 bs = tr_frag(dz_reg, NO, kk, lane_off);             // the sigma dZ tile: pair NO of the dZ region
-                static_for<NI>([&](auto n_) {                                    // uniform branch: input tile `wave`
-                    constexpr int n = decltype(n_)::value;
-                    if (wave == n) acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], bs, acc_s, 0, 0, 0);
-                });
-                if (wave == 0) acc_sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bs, acc_sb, 0, 0, 0);
+                const bf16x8 as = tr_frag(in_reg, wave, kk, lane_off);
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, bs, acc_s, 0, 0, 0);
+                acc_sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bs, acc_sb, 0, 0, 0);
             }
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
