@@ -158,6 +158,9 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
 int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream);
 /* MFMA-shape rate probe (shape 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16) with the chain kernels' operand
  * traffic; `blocks` workgroups of 512 threads, 96 * 2^15 * 16 FLOP per wave and iteration.  Diagnostic only. */
+/* HBM write-pattern probe (diagnostic): `workgroups` x 8 waves each store `blocks` 1 KiB blocks into tiles `tile_stride`
+ * bytes apart; mode 0 = the chain kernels' pattern, 1 = the 8 waves of a workgroup interleaved. */
+int knerf_debug_write_probe(void* out, int workgroups, int blocks, long long tile_stride, int mode, int spin, void* stream);
 int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""HBM write rate of the saved-activation store pattern vs a linear fill (diagnostic).  GPU box: python tools/write_probe.py"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from keras_nerf_amd import _lib
+lib = _lib.load()
+wgs, blocks, stride = 3072, 158, 158 * 1024 + 256
+buf = torch.empty(wgs * 8 * stride, dtype=torch.uint8, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+byts = wgs * 8 * blocks * 1024
+def run(mode, spin):
+    for _ in range(2): lib.knerf_debug_write_probe(buf.data_ptr(), wgs, blocks, stride, mode, spin, s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): lib.knerf_debug_write_probe(buf.data_ptr(), wgs, blocks, stride, mode, spin, s)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 5
+for spin in (0, 8, 16, 32):
+    for mode in (0, 1):
+        ms = run(mode, spin)
+        print(json.dumps({"mode": ["tile-major", "workgroup-interleaved"][mode], "spin_nops": spin, "ms": round(ms, 3), "TBs": round(byts / ms / 1e9, 2)}), flush=True)
+x = torch.empty(byts // 4, dtype=torch.float32, device="cuda")
+x.fill_(1.0); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): x.fill_(2.0)
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"mode": "linear fill", "TBs": round(byts / (e0.elapsed_time(e1) / 5) / 1e9, 2)}))
