@@ -155,6 +155,10 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
 /* hardware-fact probes for tests: kind 0 = one v_mfma_f32_32x32x16_bf16 (in0 = A fragments [64][8] bf16, in1 = B
  * fragments, out = [64][16] f32); kind 1 = one ds_read_b64_tr_b16 (in0 = 4 KiB LDS image, in1 = [64] int32 byte
  * offsets, out = [64][4] u16).  All device pointers. */
+/* the general-shape path's layer program for a config (no device needed): 16 int32 per Dense layer in Keras order =
+ * {kernel offset, bias offset, fan_in, fan_out, padded input width, padded output width, n_seg, seg0 (buffer col0, width,
+ * kernel row0), seg1 (...), relu, head (-1 | 0 sigma | 1 rgb), padded width of the output buffer or -1}. */
+int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n);
 int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream);
 /* MFMA-shape rate probe (shape 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16) with the chain kernels' operand
  * traffic; `blocks` workgroups of 512 threads, 96 * 2^15 * 16 FLOP per wave and iteration.  Diagnostic only. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "knerf_debug_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "knerf_debug_probe": (C.c_int, [C.c_int, _P, _P, _P, _P]),
     "knerf_debug_write_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, _P]),
+    "knerf_debug_generic_plan": (C.c_int, [_P, _P, _P]),
     "knerf_debug_rate_probe": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
 }
 

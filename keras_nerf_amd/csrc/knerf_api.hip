@@ -291,6 +291,23 @@ size_t knerf_param_count_for(const knerf_config* cfg) {
 
 const char* knerf_last_error(const knerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n) {
+    if (!cfg || !n || knerf_param_count_for(cfg) == 0) return KNERF_ERR_INVALID;
+    const gen::Plan p = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
+    std::vector<int32_t> v;
+    for (const gen::Layer& L : p.layers) {
+        const int32_t row[16] = {L.w_off, L.b_off, L.k_real, L.n_real, p.buf_ld[L.in_buf], L.np, L.n_seg, L.seg[0].col0, L.seg[0].width,
+                                 L.seg[0].wrow0, L.seg[1].col0, L.seg[1].width, L.seg[1].wrow0, L.relu, L.head, L.out_buf < 0 ? -1 : p.buf_ld[L.out_buf]};
+        v.insert(v.end(), row, row + 16);
+    }
+    if (out) {
+        if (*n < v.size()) return KNERF_ERR_INVALID;
+        memcpy(out, v.data(), v.size() * sizeof(int32_t));
+    }
+    *n = v.size();
+    return KNERF_OK;
+}
+
 int knerf_debug_table(int kind, int32_t* out, size_t* n) {
     if (!n) return KNERF_ERR_INVALID;
     const Tables& t = host_tables();

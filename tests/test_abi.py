@@ -71,3 +71,42 @@ def test_product_code_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_general_shape_layer_program_matches_the_keras_layer_list():
+    """csrc/generic.hip build_plan (host code, no device): offsets, shapes, concat segments and paddings of every Dense layer
+    against the layer list of mlp.py:11-27 for several shapes"""
+    import numpy as np
+    from keras_nerf_amd.model.nerf.mlp import layer_shapes
+    lib = _lib.load()
+    r32 = lambda v: (v + 31) // 32 * 32
+    for nl, u, sk, lx, ld in ((8, 256, 4, 10, 4), (4, 128, 2, 6, 2), (3, 64, 1, 4, 1), (2, 96, 4, 10, 4), (5, 160, 3, 12, 5), (1, 2, 1, 0, 0)):
+        cfg = _lib.KnerfConfig(64, 128, lx, ld, nl, u, sk, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
+        n = C.c_size_t(0)
+        assert lib.knerf_debug_generic_plan(C.byref(cfg), None, C.byref(n)) == 0
+        buf = (C.c_int32 * n.value)()
+        assert lib.knerf_debug_generic_plan(C.byref(cfg), buf, C.byref(n)) == 0
+        rows = np.array(buf[:]).reshape(-1, 16)
+        xyz, dr = 3 + 6 * lx, 3 + 6 * ld
+        shapes = layer_shapes(nl, u, sk, xyz, dr)
+        assert len(rows) == len(shapes) == nl + 4
+        off = 0
+        for i, (row, (name, fi, fo)) in enumerate(zip(rows, shapes)):
+            w_off, b_off, k, nn, in_ld, np_, n_seg, c0, w0, r0, c1, w1, r1, relu, head, out_ld = row
+            assert (w_off, b_off, k, nn) == (off, off + fi * fo, fi, fo), name
+            off += fi * fo + fo
+            assert np_ == r32(fo) and in_ld % 32 == 0
+            assert w0 + (w1 if n_seg == 2 else 0) == fi and (c0, r0) == (0, 0), name     # segments cover the kernel rows
+            if n_seg == 2:
+                assert c1 == r32(w0) and r1 == w0, name                                   # [h ; enc]: enc rows follow the h rows
+                assert in_ld == r32(w0) + r32(w1), name
+            else:
+                assert in_ld == r32(fi), name
+            assert relu == (1 if name.startswith("layer_") else 0)
+            assert head == {"sigma": 0, "rgb": 1}.get(name, -1)
+            # a layer's output buffer is widened by the padded xyz encoding exactly when the concat follows it (mlp.py:36-38)
+            if name.startswith("layer_"):
+                li = int(name.split("_")[1])
+                cat = li % sk == 0 and li > 0
+                assert out_ld == r32(u) + (r32(xyz) if cat else 0), name
+        assert off == lib.knerf_param_count_for(C.byref(cfg))
