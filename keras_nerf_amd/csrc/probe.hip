@@ -131,15 +131,16 @@ __global__ __launch_bounds__(256) void probe_rate64(const char* in0, const bf16x
     }
     out[blockIdx.x * 256 + tid] = sink;
 }
-// write-pattern probe: every wave streams `blocks` 1 KiB blocks into its own tile (tile stride as the saved activations),
-// mode 0: nt stores as the chain kernels issue them, block after block; mode 1: the 8 waves of a workgroup interleave
-// their blocks ([workgroup][block][wave]) so that a workgroup writes 8 KiB contiguous runs
+// write-pattern probe: every wave streams `blocks` 1 KiB blocks (nt stores, as the chain kernels issue them)
 __global__ __launch_bounds__(512, 2) void probe_write(char* out, int blocks, long long tile_stride, int mode, int spin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile = (long long)blockIdx.x * 8 + wave;
     u32x4 v = {(unsigned)tile, (unsigned)lane, 3u, 4u};
-    char* base = mode == 0 ? out + tile * tile_stride : out + (long long)blockIdx.x * 8 * tile_stride + wave * 1024;
-    const long long bstride = mode == 0 ? 1024 : 8 * 1024;
+    // mode 0: tile-major; mode g > 0: groups of g tiles stored block-major ([group][block][tile in group]), so that waves
+    // that are resident together write neighbouring KiB (g = 8: the waves of one workgroup)
+    const long long grp = mode > 0 ? mode : 1;
+    char* base = mode == 0 ? out + tile * tile_stride : out + (tile / grp) * grp * tile_stride + (tile % grp) * 1024;
+    const long long bstride = mode == 0 ? 1024 : grp * 1024;
     for (int b = 0; b < blocks; ++b) {
         for (int k = 0; k < spin; ++k) asm volatile("s_nop 7");          // stands in for the MFMAs between two epilogues
         v[2] += b;

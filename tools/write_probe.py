@@ -17,10 +17,11 @@ def run(mode, spin):
     for _ in range(5): lib.knerf_debug_write_probe(buf.data_ptr(), wgs, blocks, stride, mode, spin, s)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 5
-for spin in (0, 8, 16, 32):
-    for mode in (0, 1):
+for spin in (0, 16):
+    for mode in (0, 8, 64, 512, 4096, 24576):
         ms = run(mode, spin)
-        print(json.dumps({"mode": ["tile-major", "workgroup-interleaved"][mode], "spin_nops": spin, "ms": round(ms, 3), "TBs": round(byts / ms / 1e9, 2)}), flush=True)
+        print(json.dumps({"layout": "tile-major" if mode == 0 else f"block-major in groups of {mode} tiles", "spin_nops": spin,
+                          "ms": round(ms, 3), "TBs": round(byts / ms / 1e9, 2)}), flush=True)
 x = torch.empty(byts // 4, dtype=torch.float32, device="cuda")
 x.fill_(1.0); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
