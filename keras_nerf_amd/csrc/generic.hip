@@ -108,6 +108,76 @@ struct GemmArgs {
     float* Cf; int ldcf;                 // fp32 output (may be null)
 };
 
+// epilogue shared by the two GEMM kernels: bias, relu, relu mask of the dgrad, bf16 / fp32 stores.  The launch-uniform
+// switches (fp32 or bf16 output, mask or not) are taken ONCE around the element loops and every address is a base pointer
+// plus a uniform multiple of the row pitch: left as per-element branches and 64-bit multiplies (what hipcc makes of the
+// straightforward loop) the epilogue costs more than the tile's 128 MFMAs.
+template <int NT, bool TR>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NT], long long m0, int n0, int r, int h) {
+    if constexpr (!TR) {
+        // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
+        const size_t row0 = (size_t)(m0 + 4 * h);
+        if (g.Cf) {                                   // fp32 head outputs (no mask, no relu)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = n0 + 32 * t + r;
+                const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
+                float* p = g.Cf + row0 * g.ldcf + col;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldcf] = acc[t][i] + b;
+            }
+        } else {
+            const bool relu = g.relu != 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = n0 + 32 * t + r;
+                const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
+                u16* p = g.Cb + row0 * g.ldc + col;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[t][i] + b;
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
+                }
+            }
+        }
+    } else {
+        // D'[n][m]: lane (m = r, hh = h), registers i -> column n = (i&3) + 8(i>>2) + 4hh: four consecutive columns of one
+        // row per register quad (dgrad: no bias, no relu; bf16 output; mask optional)
+        const size_t row = (size_t)(m0 + r);
+        u16* p = g.Cb + row * g.ldc + n0 + 4 * h;
+        auto put = [&](int t, int q, const float (&v)[4]) {
+            uint2 o;
+            o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+            o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(p + 32 * t + 8 * q) = o;
+        };
+        if (g.aux) {
+            const u16* ax = g.aux + row * g.ldaux + n0 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint2 a = *reinterpret_cast<const uint2*>(ax + 32 * t + 8 * q);
+                    float v[4];
+                    v[0] = (short)(a.x & 0xffffu) > 0 ? acc[t][4 * q + 0] : 0.f;
+                    v[1] = (short)(a.x >> 16) > 0 ? acc[t][4 * q + 1] : 0.f;
+                    v[2] = (short)(a.y & 0xffffu) > 0 ? acc[t][4 * q + 2] : 0.f;
+                    v[3] = (short)(a.y >> 16) > 0 ? acc[t][4 * q + 3] : 0.f;
+                    put(t, q, v);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                    put(t, q, v);
+                }
+        }
+    }
+}
+
 // Workgroup = 8 waves x 32 rows; the Bt slab of the current 64-wide K chunk ([32 NT][64] bf16) is staged in LDS once per
 // workgroup (rows padded to 144 B: the 16-byte fragment reads of 16 lanes then cover all 64 banks exactly once) and
 // double-buffered, so the weights cross L2 once per 256 rows instead of once per 32; A fragments come straight from
@@ -188,55 +258,95 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
     if (!live) return;
-    if constexpr (!TR) {
-        // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = n0 + 32 * t + r;
-            const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long long row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float v = acc[t][i] + b;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.aux) { const short a = (short)g.aux[(size_t)row * g.ldaux + col]; v = a > 0 ? v : 0.f; }
-                if (g.Cb) g.Cb[(size_t)row * g.ldc + col] = to_bf16(v);
-                if (g.Cf) g.Cf[(size_t)row * g.ldcf + col] = v;
-            }
-        }
-    } else {
-        // D'[n][m]: lane (m = r, hh = h), registers i -> column n = (i&3) + 8(i>>2) + 4hh: four consecutive columns of one
-        // row per register quad
-        const long long row = m0 + r;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = n0 + 32 * t + 8 * q + 4 * h;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float b = (g.bias && col + e < g.n_real) ? g.bias[col + e] : 0.f;
-                    v[e] = acc[t][4 * q + e] + b;
-                    if (g.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (g.aux) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(g.aux + (size_t)row * g.ldaux + col);
-                    if ((short)(a.x & 0xffffu) <= 0) v[0] = 0.f;
-                    if ((short)(a.x >> 16) <= 0) v[1] = 0.f;
-                    if ((short)(a.y & 0xffffu) <= 0) v[2] = 0.f;
-                    if ((short)(a.y >> 16) <= 0) v[3] = 0.f;
-                }
-                if (g.Cb) {
-                    uint2 o;
-                    o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
-                    o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(g.Cb + (size_t)row * g.ldc + col) = o;
-                }
-                if (g.Cf) *reinterpret_cast<float4*>(g.Cf + (size_t)row * g.ldcf + col) = float4{v[0], v[1], v[2], v[3]};
-            }
-        }
+    gemm_epilogue<NT, TR>(g, acc, m0, n0, r, h);
+}
+
+// Weights-stationary variant for the common case that a whole Bt slab [32 NT][K] fits in LDS: it is staged ONCE per workgroup
+// (K zero-padded to a multiple of 64; row pitch 2 K64 + 16 bytes: pitch/4 = 4 (odd) -> the 16-byte fragment reads of 16
+// lanes hit 64 distinct banks), the workgroup is persistent over row tiles and its waves never synchronise again: each
+// wave streams its own rows (A fragments one 64-wide chunk ahead, across tile boundaries) against the resident weights.
+// The chunk body is branch-free and fully unrolled with the B fragments read 4 MFMAs ahead (left to itself hipcc emits
+// ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per fragment: 48 cycles per MFMA instead of 8).
+template <int NT, bool TR>
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, int pitch) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    constexpr int NB = NT * 32;
+    constexpr int NF = 4 * NT;                        // fragments per 64-wide chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * NB;
+    const int K64 = (g.K + 63) / 64 * 64;
+    const int gpr = K64 / 8;                          // 16-byte granules per staged row
+    for (int q = tid; q < NB * gpr; q += kGemmWaves * 64) {
+        const int row = q / gpr, cc = q % gpr;
+        *reinterpret_cast<uint4*>(gsm + row * pitch + cc * 16) =
+            cc * 8 < g.K ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + row) * g.ldb + cc * 8) : uint4{0, 0, 0, 0};
     }
+    __syncthreads();
+    const long long n_tiles = g.M / 32;
+    const char* B = gsm + r * pitch + h * 16;
+    const long long stride = (long long)gridDim.x * kGemmWaves;
+    long long tile = (long long)blockIdx.x * kGemmWaves + wave;
+    bf16x8 a_cur[4], a_nxt[4];
+    auto fetch_a = [&](long long t, int k, bf16x8 (&a)[4]) {          // one 64-wide chunk of this wave's 32 rows
+        const u16* A = g.A + (size_t)(t * 32 + r) * g.lda + 8 * h + k;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (k + ks * 16 < g.K) a[ks] = *reinterpret_cast<const bf16x8*>(A + ks * 16);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[ks][j] = (__bf16)0.f;     // K tail: the staged weights there are zero as well
+            }
+        }
+    };
+    auto frag = [&](int k, int f) { return *reinterpret_cast<const bf16x8*>(B + (f % NT) * 32 * pitch + (k + (f / NT) * 16) * 2); };
+    if (tile < n_tiles) fetch_a(tile, 0, a_cur);
+    for (; tile < n_tiles; tile += stride) {
+        const long long m0 = tile * 32;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = zero16();
+        bf16x8 pf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) pf[f] = frag(0, f);
+        for (int k = 0; k < K64; k += kGemmKC) {
+            const bool more = k + kGemmKC < K64;
+            const bool next_tile = !more && tile + stride < n_tiles;
+            if (more) fetch_a(tile, k + kGemmKC, a_nxt);
+            else if (next_tile) fetch_a(tile + stride, 0, a_nxt);
+            const int kn = more ? k + kGemmKC : k;          // where the ring's look-ahead reads at the end of this chunk
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const bf16x8 cur = pf[f % 4];
+                pf[f % 4] = f + 4 < NF ? frag(k, f + 4) : frag(kn, f + 4 - NF);
+                if (TR) acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, a_cur[f / NT], acc[f % NT], 0, 0, 0);
+                else acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[f / NT], cur, acc[f % NT], 0, 0, 0);
+            }
+            if (more || next_tile) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a_cur[ks] = a_nxt[ks];
+            }
+        }
+        gemm_epilogue<NT, TR>(g, acc, m0, n0, r, h);
+    }
+}
+
+constexpr size_t kGemmWsLds = 150 * 1024;
+template <int NT, bool TR>
+hipError_t launch_gemm_ws(const GemmArgs& g, int gy, hipStream_t s) {
+    const int pitch = (g.K + 63) / 64 * 64 * 2 + 16;
+    const size_t lds = (size_t)NT * 32 * pitch;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<NT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmWsLds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    long long gx = (g.M / 32 + kGemmWaves - 1) / kGemmWaves;
+    const long long cap = 512 / gy > 0 ? 512 / gy : 1;           // persistent: about two workgroups per CU in all
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((gemm_ws_kernel<NT, TR>), dim3((unsigned)gx, gy), dim3(kGemmWaves * 64), lds, s, g, pitch);
+    return hipGetLastError();
 }
 
 template <int NT, bool TR>
@@ -256,6 +366,14 @@ hipError_t launch_gemm_nt(const GemmArgs& g, int gy, hipStream_t s) {
 template <bool TR>
 hipError_t launch_gemm_tr(const GemmArgs& g, hipStream_t s) {
     const int nt = g.N / 32;
+    const size_t row_bytes = (size_t)(g.K + 63) / 64 * 64 * 2 + 16;
+#ifndef KNERF_GEN_NO_WS
+    // the widest column block whose weight slab fits in LDS, resident for the whole launch
+    if (nt % 8 == 0 && 256 * row_bytes <= kGemmWsLds) return launch_gemm_ws<8, TR>(g, nt / 8, s);
+    if (nt % 4 == 0 && 128 * row_bytes <= kGemmWsLds) return launch_gemm_ws<4, TR>(g, nt / 4, s);
+    if (nt % 2 == 0 && 64 * row_bytes <= kGemmWsLds) return launch_gemm_ws<2, TR>(g, nt / 2, s);
+    if (32 * row_bytes <= kGemmWsLds) return launch_gemm_ws<1, TR>(g, nt, s);
+#endif
     if (nt % 8 == 0) return launch_gemm_nt<8, TR>(g, nt / 8, s);
     if (nt % 4 == 0) return launch_gemm_nt<4, TR>(g, nt / 4, s);
     if (nt % 2 == 0) return launch_gemm_nt<2, TR>(g, nt / 2, s);
