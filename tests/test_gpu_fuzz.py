@@ -1,0 +1,56 @@
+"""Seeded random configurations of the fused path against the oracle: ray counts that are not multiples of the 32-sample
+tile or the 256-sample workgroup, odd sample counts, both backgrounds and out-of-range modes, several chunkings."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from tests.problem import make_problem
+from tests.test_gpu_forward import log_stats
+from tests.test_gpu_train import per_tensor_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(20261003)
+    out = []
+    for i in range(8):
+        nc = int(rng.integers(2, 97))
+        nf = int(rng.integers(0, 130))
+        out.append(dict(n_coarse=nc, n_fine=nf, rays=int(rng.integers(1, 200)), white=bool(rng.integers(0, 2)),
+                        oob=["zero", "clamp"][int(rng.integers(0, 2))], seed=int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"nc{c['n_coarse']}_nf{c['n_fine']}_r{c['rays']}_{'w' if c['white'] else 'b'}_{c['oob']}")
+def test_random_configuration_matches_oracle(case):
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = O.NerfConfig(n_coarse=case["n_coarse"], n_fine=case["n_fine"])
+    P = make_problem(n_images=1, wh=16, seed=case["seed"], weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    R = case["rays"]
+    o, d, t, img = (P[k].reshape(P["N"], -1)[:R].copy() for k in ("o", "d", "t", "img"))
+    u = P["u"].reshape(P["N"], -1)[:R].copy() if case["n_fine"] else None
+    ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, white_background=case["white"], oob=case["oob"])
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    ci, cd, cw = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
+    rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, case["white"], emulate_bf16=True)
+    np.testing.assert_allclose(ci, rc["image"], atol=1e-2)
+    np.testing.assert_allclose(cw, rc["weights"], atol=1e-2)
+    if case["n_fine"] == 0:
+        ctx.close(); return
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, u, loss=loss)
+    S = cfg.n_coarse + cfg.n_fine
+    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:R * S].reshape(R, S)
+    w_c = ctx.debug_buffer(6).view(torch.float32).cpu().numpy()[:R * cfg.n_coarse].reshape(R, cfg.n_coarse)
+    np.testing.assert_array_equal(t_fine, O.fine_points(t, w_c, u, case["oob"]))          # sampler + sort: bit exact
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    _, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, case["white"], emulate_bf16=True)
+    _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, case["white"], emulate_bf16=True)
+    ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+    log_stats("fuzz_" + "_".join(f"{k}{v}" for k, v in case.items() if k != "seed"), coarse_worst=ec[0], fine_worst=ef[0])
+    tol = 8e-2 if R * cfg.n_coarse < 2048 else 5e-2          # few samples: the bf16 roundings do not average out
+    assert ec[0] < tol and ef[0] < tol, (ec, ef)
+    assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    ctx.close()
