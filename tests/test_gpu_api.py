@@ -1,5 +1,7 @@
 """The reference's class surface (NeRF / NeRFUtils / NeRFMLP / RaysGenerator) on the GPU: shapes and semantics the
 reference's own tests assert (tests/model/nerf/*.py, tests/data/test_rays.py there) plus numeric parity with the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -230,3 +232,38 @@ def test_loader_monitor_fit_end_to_end(tmp_path):
     assert list(rows[0].keys()) == ["epoch", "coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim",
                                     "val_coarse_loss", "val_coarse_psnr", "val_coarse_ssim", "val_fine_loss", "val_fine_psnr", "val_fine_ssim"]
     assert NeRFTrainMonitor(te, log_dir, batch_size=1, update_freq=2).last_epoch == 3        # resume: last CSV epoch + 1
+
+
+def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
+    """train.py:75-157 semantics with two processes on this GPU (gloo; tests/dp_gpu_worker.py): both ranks start from rank
+    0's weights, SUM their accumulated gradients and end with identical weights that equal a single-process step on the
+    summed gradients."""
+    import subprocess
+    import sys
+    from keras_nerf_amd.runtime import KnerfContext
+    from tests.dp_gpu_worker import problem
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(a["w_start"], b["w_start"])                  # mirrored variables (broadcast at compile)
+    np.testing.assert_array_equal(a["w_end"], b["w_end"])                      # identical updates on both replicas
+    assert np.abs(a["w_end"] - a["w_start"]).max() > 1e-4
+    assert float(a["coarse_loss"]) != float(b["coarse_loss"])             # per-replica losses (fit() averages them for the logs)
+    # single process: accumulate both shards' gradients (SUM), one Adam step
+    poses, focal, img, u = problem()
+    ctx = KnerfContext(n_coarse=32, n_fine=32, white_background=True)
+    n = ctx.param_count
+    ctx.set_weights(0, a["w_start"][:n]); ctx.set_weights(1, a["w_start"][n:])
+    for rank, z in enumerate((a, b)):
+        # the worker's Philox seed for its first step: (seed << 20) ^ (rank << 40) ^ 1 with seed = 100 + rank, u injected anyway
+        ctx.train_batch(z["o"].reshape(-1, 3), z["d"].reshape(-1, 3), z["t"].reshape(-1, 32), img[rank].reshape(-1, 3),
+                        u[rank].reshape(-1, 32), seed=0, ray_chunks=128)
+    ctx.apply_adam()
+    w = np.concatenate([ctx.get_weights(0), ctx.get_weights(1)])
+    moved = np.abs(a["w_end"] - a["w_start"]) > 1e-5
+    assert np.mean(np.sign(w - a["w_start"])[moved] == np.sign(a["w_end"] - a["w_start"])[moved]) > 0.999
+    np.testing.assert_allclose(w, a["w_end"], atol=2e-5)                      # fp32 atomics: summation order only
+    ctx.close()
