@@ -468,6 +468,10 @@ __device__ __forceinline__ void transpose_tile(const RawTile& t, const bf16x8& i
     if (colsum) *colsum += s;
 }
 
+#ifndef KNERF_GEN_WG_DEPTH
+#define KNERF_GEN_WG_DEPTH 3
+#endif
+constexpr int kWgDepth = KNERF_GEN_WG_DEPTH;
 template <int KT, int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -490,30 +494,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     const bool do_bias = blockIdx.x == 0;
     const long long stride = (long long)gridDim.z * 4;
     long long s = (long long)blockIdx.z * 4 + wave;
-    RawTile xr[KT], zr[NT];   // one m-step ahead: the loads of step s + stride fly under the MFMAs of step s
-    auto fetch = [&](long long st) {
+    // kWgDepth m-steps are in flight: one step of this wave is 16 MFMAs (~0.5 us with its SIMD partner), a first-touch
+    // HBM load takes several times that
+    constexpr int D = kWgDepth;
+    RawTile xr[D][KT], zr[D][NT];
+    auto fetch = [&](long long st, RawTile (&x)[KT], RawTile (&z)[NT]) {
         const u16* X = g.X + (size_t)st * 32 * g.ldx + k0;
         const u16* Z = g.Z + (size_t)st * 32 * g.ldz + n0;
 #pragma unroll
-        for (int a = 0; a < KT; ++a) xr[a] = load_tile(X + 32 * a, g.ldx, r, h);
+        for (int a = 0; a < KT; ++a) x[a] = load_tile(X + 32 * a, g.ldx, r, h);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) zr[b] = load_tile(Z + 32 * b, g.ldz, r, h);
+        for (int b = 0; b < NT; ++b) z[b] = load_tile(Z + 32 * b, g.ldz, r, h);
     };
-    if (s < g.steps) fetch(s);
-    for (; s < g.steps; s += stride) {
-        bf16x8 xa[KT][2], zb[NT][2];
 #pragma unroll
-        for (int a = 0; a < KT; ++a) transpose_tile(xr[a], ilo, ihi, xa[a], nullptr);
+    for (int dd = 0; dd < D; ++dd)
+        if (s + dd * stride < g.steps) fetch(s + dd * stride, xr[dd], zr[dd]);
+    for (; s < g.steps; s += D * stride) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) transpose_tile(zr[b], ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
-        if (s + stride < g.steps) fetch(s + stride);
+        for (int dd = 0; dd < D; ++dd) {
+            const long long st = s + dd * stride;
+            if (st < g.steps) {                       // wave-uniform
+                bf16x8 xa[KT][2], zb[NT][2];
 #pragma unroll
-        for (int a = 0; a < KT; ++a)
+                for (int a = 0; a < KT; ++a) transpose_tile(xr[dd][a], ilo, ihi, xa[a], nullptr);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][0], zb[b][0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][1], zb[b][1], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < NT; ++b) transpose_tile(zr[dd][b], ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
+                if (st + D * stride < g.steps) fetch(st + D * stride, xr[dd], zr[dd]);
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][0], zb[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a][1], zb[b][1], acc[a][b], 0, 0, 0);
+                    }
             }
+        }
     }
     // flush: lane (col = r, hh = h), register i -> input column k0 + 32a + (i&3) + 8(i>>2) + 4hh
 #pragma unroll
