@@ -22,6 +22,7 @@ namespace gen {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(4))) short s16x4g;
 
 namespace {
 
@@ -549,8 +550,136 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     }
 }
 
+// Cooperative wgrad for layers of at least 128 x 128: a workgroup of 8 waves owns a 256 (inputs) x 256 (outputs) block of dW
+// and walks 32-sample steps; per step the X and dZ slabs [32][256] are staged ONCE in LDS (double-buffered, row pitch
+// 576 B = 16 banks mod 64: the transposed reads below are conflict-free) and every wave builds its operand fragments with
+// ds_read_b64_tr_b16 -- lane 4q+p of a 16-lane group supplies the address of sample row q / feature quad p and receives
+// feature `lane` of the four samples, i.e. exactly the MFMA operand layout with samples as k (tests/test_gpu_probe.py pins
+// the instruction).  Against the per-wave kernel above: operands cross L2 once per 256 x 256 block instead of 4 x, and
+// no MFMA is spent on transposing.  Wave (wa, wb) = (wave >> 1, wave & 1): input tiles 2wa, 2wa+1, output tiles 4wb..4wb+3.
+constexpr int kCoopPitch = 576, kCoopSlab = 32 * kCoopPitch, kCoopBuf = 2 * kCoopSlab;
+__global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) char csm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+    const int k0 = blockIdx.x * 256, n0 = blockIdx.y * 256;
+    const int r = lane & 31, h = lane >> 5;
+    // transposed-read lane offsets: group gq = lane >> 4 -> feature half (gq & 1), k half (gq >> 1); i = lane & 15 -> q = i >> 2, p = i & 3
+    const int gq = lane >> 4, il = lane & 15;
+    const int tr_off = ((8 * (gq >> 1) + (il >> 2)) * kCoopPitch) + (16 * (gq & 1) + 4 * (il & 3)) * 2;
+    typedef __attribute__((address_space(3))) s16x4g* lds_s16x4g_ptr;
+    auto frag = [&](const char* slab, int tile, int kk) {
+        const char* p = slab + tr_off + (16 * kk) * kCoopPitch + tile * 64;
+        const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4g_ptr)p);
+        const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4g_ptr)(p + 4 * kCoopPitch));
+        typedef __attribute__((ext_vector_type(8))) short s16x8g;
+        const s16x8g v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // staging: 2 granules of X and 2 of dZ per thread and step
+    uint4 sx[2], sz[2];
+    auto fetch = [&](long long st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + 512 * j, row = q >> 5, cc = q & 31;
+            sx[j] = k0 + cc * 8 < K ? *reinterpret_cast<const uint4*>(g.X + (size_t)(st * 32 + row) * g.ldx + k0 + cc * 8) : uint4{0, 0, 0, 0};
+            sz[j] = n0 + cc * 8 < N ? *reinterpret_cast<const uint4*>(g.Z + (size_t)(st * 32 + row) * g.ldz + n0 + cc * 8) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + 512 * j, row = q >> 5, cc = q & 31;
+            *reinterpret_cast<uint4*>(csm + buf * kCoopBuf + row * kCoopPitch + cc * 16) = sx[j];
+            *reinterpret_cast<uint4*>(csm + buf * kCoopBuf + kCoopSlab + row * kCoopPitch + cc * 16) = sz[j];
+        }
+    };
+    f32x16 acc[2][4], acc_b[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = zero16();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc_b[b] = zero16();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const bool do_bias = blockIdx.x == 0 && wa == 0;                     // wave-uniform
+    const bool k_ok[2] = {k0 + 32 * (2 * wa) < K, k0 + 32 * (2 * wa + 1) < K};
+    const bool n_ok[4] = {n0 + 32 * (4 * wb) < N, n0 + 32 * (4 * wb + 1) < N, n0 + 32 * (4 * wb + 2) < N, n0 + 32 * (4 * wb + 3) < N};
+    long long st = blockIdx.z;
+    if (st < g.steps) { fetch(st); put(0); }
+    __syncthreads();
+    int buf = 0;
+    for (; st < g.steps; st += gridDim.z) {
+        const bool more = st + gridDim.z < g.steps;
+        if (more) fetch(st + gridDim.z);                                 // flies under this step's reads and MFMAs
+        const char* xs = csm + buf * kCoopBuf;
+        const char* zs = xs + kCoopSlab;
+        if (k_ok[0] && n_ok[0]) {                                        // a wave whose first tiles are out of range has nothing to do
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 zb[4], xa[2];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) zb[b] = frag(zs, 4 * wb + b, kk);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) xa[a] = frag(xs, 2 * wa + a, kk);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (k_ok[a] && n_ok[b]) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a], zb[b], acc[a][b], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc_b[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, zb[b], acc_b[b], 0, 0, 0);
+                }
+            }
+        }
+        if (more) put(buf ^ 1);                                          // the other buffer was last read before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+    // flush: lane (col = r, hh = h), register i -> input column 32 tile + (i&3) + 8(i>>2) + 4hh
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int col = n0 + 32 * (4 * wb + b) + r;
+        if (col >= g.n_real) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = k0 + 32 * (2 * wa + a) + (i & 3) + 8 * (i >> 2) + 4 * h;
+                int wrow = -1;
+                for (int sg = 0; sg < g.n_seg; ++sg)
+                    if (kc >= g.seg[sg].col0 && kc < g.seg[sg].col0 + g.seg[sg].width) wrow = g.seg[sg].wrow0 + kc - g.seg[sg].col0;
+                if (wrow >= 0) atomicAdd(g.grad + g.w_off + (size_t)wrow * g.n_real + col, acc[a][b][i]);
+            }
+        if (do_bias && h == 0) atomicAdd(g.grad + g.b_off + col, acc_b[b][0]);   // every row of the ones product holds the column sum
+    }
+}
+
 hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     const int kt = K / 32, nt = N / 32;
+#ifndef KNERF_GEN_NO_COOP
+    if (kt >= 4 && nt >= 4) {
+        static bool attr_done = false;
+        const size_t lds = 2 * (size_t)kCoopBuf;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        const int gx = (K + 255) / 256, gy = (N + 255) / 256;
+#ifndef KNERF_GEN_COOP_WGS
+#define KNERF_GEN_COOP_WGS 256      // one workgroup per CU: each flushes a whole 256 x 256 block with atomics (512: +8 %, 1024: +23 %)
+#endif
+        long long gz = KNERF_GEN_COOP_WGS / ((long long)gx * gy);
+        if (gz > g.steps) gz = g.steps;
+        if (gz < 1) gz = 1;
+        hipLaunchKernelGGL(wgrad_coop_kernel, dim3(gx, gy, (unsigned)gz), dim3(512), lds, s, g, K, N);
+        return hipGetLastError();
+    }
+#endif
 #ifndef KNERF_GEN_MAXKT
 #define KNERF_GEN_MAXKT 2
 #endif
