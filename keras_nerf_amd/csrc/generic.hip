@@ -154,12 +154,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
             *reinterpret_cast<uint2*>(p + 32 * t + 8 * q) = o;
         };
         if (g.aux) {
+            // the mask words do not depend on the products: all of them are requested up front (32 x 8 B per lane for
+            // NT = 8, accumulators are dead one tile at a time) instead of one load -> wait -> store per register quad
             const u16* ax = g.aux + row * g.ldaux + n0 + 4 * h;
+            uint2 m[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[t][q] = *reinterpret_cast<const uint2*>(ax + 32 * t + 8 * q);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(ax + 32 * t + 8 * q);
+                    const uint2 a = m[t][q];
                     float v[4];
                     v[0] = (short)(a.x & 0xffffu) > 0 ? acc[t][4 * q + 0] : 0.f;
                     v[1] = (short)(a.x >> 16) > 0 ? acc[t][4 * q + 1] : 0.f;
