@@ -165,6 +165,9 @@ int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, voi
 /* HBM write-pattern probe (diagnostic): `workgroups` x 8 waves each store `blocks` 1 KiB blocks into tiles `tile_stride`
  * bytes apart; mode 0 = the chain kernels' pattern, 1 = the 8 waves of a workgroup interleaved. */
 int knerf_debug_write_probe(void* out, int workgroups, int blocks, long long tile_stride, int mode, int spin, void* stream);
+/* HBM read-pattern probe (diagnostic): each of workgroups x 8 waves streams bytes_per_wave contiguous bytes in 1 KiB
+ * instructions; mode 0 = nt LDS-DMA (wgrad's loads), 1 = plain register loads. */
+int knerf_debug_read_probe(const void* in, int workgroups, long long bytes_per_wave, int mode, void* out, void* stream);
 int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus

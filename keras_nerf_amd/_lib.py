@@ -58,6 +58,7 @@ SIGNATURES = {
     "knerf_debug_probe": (C.c_int, [C.c_int, _P, _P, _P, _P]),
     "knerf_debug_write_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, _P]),
     "knerf_debug_generic_plan": (C.c_int, [_P, _P, _P]),
+    "knerf_debug_read_probe": (C.c_int, [_P, C.c_int, C.c_longlong, C.c_int, _P, _P]),
     "knerf_debug_rate_probe": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
 }
 

@@ -150,6 +150,50 @@ __global__ __launch_bounds__(512, 2) void probe_write(char* out, int blocks, lon
 }
 }  // namespace knerf
 
+namespace knerf {
+// read-pattern probe: `workgroups` x 8 waves stream contiguous ranges with 16-byte-per-lane loads (1 KiB per wave
+// instruction, `depth` instructions in flight per wave), mode 0: nt LDS-DMA as wgrad issues them, mode 1: plain loads into
+// registers.  Nothing is computed: this is the HBM read ceiling of the access pattern.
+__global__ __launch_bounds__(512, 2) void probe_read(const char* in, long long bytes_per_wave, int mode, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* p = in + ((long long)blockIdx.x * 8 + wave) * bytes_per_wave + lane * 16;
+    const long long n = bytes_per_wave / 1024;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    if (mode == 0) {
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + wave * 16 * 1024);
+        for (long long b = 0; b < n; ++b) {
+            const unsigned m0v = dst + (unsigned)(b & 15) * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0\n\ts_waitcnt vmcnt(12)"
+                         : "=&s"(keep) : "v"(p + b * 1024), "s"(m0v) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (long long b = 0; b < n; b += 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const u32x4*>(p + (b + k) * 1024);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc ^= v[k];
+        }
+    }
+    if (acc[0] == 0x12345u) out[threadIdx.x] = 1.f;
+}
+}  // namespace knerf
+
+extern "C" int knerf_debug_read_probe(const void* in, int workgroups, long long bytes_per_wave, int mode, void* out, void* stream) {
+    using namespace knerf;
+    const size_t lds = 128 * 1024;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_read), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
+        done = true;
+    }
+    hipLaunchKernelGGL(probe_read, dim3(workgroups), dim3(512), lds, (hipStream_t)stream, (const char*)in, bytes_per_wave, mode, (float*)out);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
+
 extern "C" int knerf_debug_write_probe(void* out, int workgroups, int blocks, long long tile_stride, int mode, int spin, void* stream) {
     using namespace knerf;
     hipLaunchKernelGGL(probe_write, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (char*)out, blocks, tile_stride, mode, spin);

@@ -29,3 +29,19 @@ e0.record()
 for _ in range(5): x.fill_(2.0)
 e1.record(); torch.cuda.synchronize()
 print(json.dumps({"mode": "linear fill", "TBs": round(byts / (e0.elapsed_time(e1) / 5) / 1e9, 2)}))
+
+# read side: the ceiling of wgrad's streaming pattern (8 GB per launch, one workgroup per CU)
+src = torch.empty(8 << 30, dtype=torch.uint8, device="cuda"); src.zero_()
+o = torch.zeros(512, device="cuda")
+for wg in (252, 504):
+    per_wave = (8 << 30) // (wg * 8) // 8192 * 8192
+    for mode in (0, 1):
+        for _ in range(2): lib.knerf_debug_read_probe(src.data_ptr(), wg, per_wave, mode, o.data_ptr(), s)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): lib.knerf_debug_read_probe(src.data_ptr(), wg, per_wave, mode, o.data_ptr(), s)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(json.dumps({"read": ["nt LDS-DMA", "register loads"][mode], "workgroups": wg, "ms": round(ms, 3),
+                          "TBs": round(per_wave * wg * 8 / ms / 1e9, 2)}), flush=True)
