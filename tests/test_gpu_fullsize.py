@@ -108,3 +108,35 @@ def test_first_adam_step_moves_every_touched_weight_by_the_learning_rate(setup):
         if small.any():
             assert np.abs(dw[small]).max() < 0.5e-3
     ctx2.close()
+
+
+def test_one_large_chunk_equals_eight_small_ones():
+    """ray_chunks = 32768 (6.3 M fine samples, 60 GB of saved activations and dZ: every index is 64-bit) against the same
+    rays in 8 chunks of 4096: images bit-identical, gradients equal up to fp32 summation order"""
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    from keras_nerf_amd.runtime import KnerfContext
+    ctx = KnerfContext(white_background=True)
+    for net in (0, 1):
+        m = NeRFMLP(seed=30 + net); m.build(); ctx.set_weights(net, m.get_flat_weights() * 1.5)
+    poses = np.stack([pose_spherical(15.0 + 100.0 * i, -30.0, 4.0) for i in range(2)])
+    o, d, t = ctx.generate_rays(poses, get_focal_from_fov(0.6911112070083618, 128), 128, 128, 2.0, 6.0, NC, None, seed=11)
+    N = 2 * 128 * 128
+    o, d, t = o.reshape(N, 3).contiguous(), d.reshape(N, 3).contiguous(), t.reshape(N, NC).contiguous()
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    tgt = torch.rand((N, 3), device="cuda", generator=g); u = torch.rand((N, NF), device="cuda", generator=g)
+    res = []
+    for chunk in (4096, N):
+        loss = torch.zeros(2, device="cuda")
+        ci = torch.empty((N, 3), device="cuda"); fi = torch.empty((N, 3), device="cuda")
+        ctx.zero_grads()
+        ctx.train_batch(o, d, t, tgt, u, seed=0, ray_chunks=chunk, loss=loss, c_image=ci, f_image=fi)
+        torch.cuda.synchronize()
+        res.append((ci.clone(), fi.clone(), loss.clone(), ctx.grads_view().clone()))
+    (c0, f0, l0, g0), (c1, f1, l1, g1) = res
+    assert torch.equal(c0, c1) and torch.equal(f0, f1)
+    assert float((l0 - l1).abs().max()) < 1e-5
+    # the per-chunk factor 1/C enters dL/dimage before the bf16 rounding of dZ: relative 2^-9 per element, averaged out
+    assert float((g0 - g1).abs().max()) <= 2e-3 * float(g0.abs().max())
+    assert float(g0.abs().max()) > 0
+    ctx.close()
