@@ -160,7 +160,23 @@ __global__ __launch_bounds__(512, 2) void probe_read(const char* in, long long b
     const char* p = in + ((long long)blockIdx.x * 8 + wave) * bytes_per_wave + lane * 16;
     const long long n = bytes_per_wave / 1024;
     u32x4 acc = {0u, 0u, 0u, 0u};
-    if (mode == 0) {
+    if (mode == 2 || mode == 3) {
+        // wgrad's rhythm: G = 4 (mode 2) or 8 (mode 3) copies per wave, wait until all but the youngest 2 G have landed,
+        // workgroup barrier -- 3 "tiles" in flight, one barrier per tile
+        const int G = mode == 2 ? 4 : 8;
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + wave * 16 * 1024);
+        for (long long b = 0; b < n; b += G) {
+            for (int k = 0; k < G; ++k) {
+                const unsigned m0v = dst + (unsigned)((b + k) & 15) * 1024;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(p + (b + k) * 1024), "s"(m0v) : "memory");
+            }
+            if (G == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (mode == 0) {
         const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + wave * 16 * 1024);
         for (long long b = 0; b < n; ++b) {
             const unsigned m0v = dst + (unsigned)(b & 15) * 1024;

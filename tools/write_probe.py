@@ -35,7 +35,7 @@ src = torch.empty(8 << 30, dtype=torch.uint8, device="cuda"); src.zero_()
 o = torch.zeros(512, device="cuda")
 for wg in (252, 504):
     per_wave = (8 << 30) // (wg * 8) // 8192 * 8192
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):
         for _ in range(2): lib.knerf_debug_read_probe(src.data_ptr(), wg, per_wave, mode, o.data_ptr(), s)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,5 +43,5 @@ for wg in (252, 504):
         for _ in range(5): lib.knerf_debug_read_probe(src.data_ptr(), wg, per_wave, mode, o.data_ptr(), s)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print(json.dumps({"read": ["nt LDS-DMA", "register loads"][mode], "workgroups": wg, "ms": round(ms, 3),
+        print(json.dumps({"read": ["nt LDS-DMA", "register loads", "nt LDS-DMA, barrier per 4 KiB/wave (3 tiles in flight)", "nt LDS-DMA, barrier per 8 KiB/wave"][mode], "workgroups": wg, "ms": round(ms, 3),
                           "TBs": round(per_wave * wg * 8 / ms / 1e9, 2)}), flush=True)
