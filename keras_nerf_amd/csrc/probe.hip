@@ -142,10 +142,15 @@ __global__ __launch_bounds__(512, 2) void probe_write(char* out, int blocks, lon
     char* base = mode == 0 ? out + tile * tile_stride : out + (tile / grp) * grp * tile_stride + (tile % grp) * 1024;
     const long long bstride = mode == 0 ? 1024 : grp * 1024;
     for (int b = 0; b < blocks; ++b) {
-        for (int k = 0; k < spin; ++k) asm volatile("s_nop 7");          // stands in for the MFMAs between two epilogues
+        for (int k = 0; k < (spin & 0xffff); ++k) asm volatile("s_nop 7");          // stands in for the MFMAs between two epilogues
         v[2] += b;
         char* p = base + b * bstride + lane * 16;
-        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        // spin's upper bits select the cache policy (diagnostic): 0 nt (the kernels' choice), 1 plain, 2 sc1, 3 sc0 sc1
+        const int pol = spin >> 16;
+        if (pol == 0) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        else if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
     }
 }
 }  // namespace knerf
@@ -212,7 +217,14 @@ extern "C" int knerf_debug_read_probe(const void* in, int workgroups, long long 
 
 extern "C" int knerf_debug_write_probe(void* out, int workgroups, int blocks, long long tile_stride, int mode, int spin, void* stream) {
     using namespace knerf;
-    hipLaunchKernelGGL(probe_write, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (char*)out, blocks, tile_stride, mode, spin);
+    // spin bit 30: reserve 100 KiB of LDS so that one workgroup fills a CU (2048 resident waves, as in the chain kernels)
+    const size_t lds = (spin >> 30) & 1 ? 100 * 1024 : 0;
+    static bool done = false;
+    if (!done && lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KNERF_ERR_HIP;
+        done = true;
+    }
+    hipLaunchKernelGGL(probe_write, dim3(workgroups), dim3(512), lds, (hipStream_t)stream, (char*)out, blocks, tile_stride, mode, spin & ~(1 << 30));
     return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
 }
 

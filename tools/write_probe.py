@@ -17,6 +17,11 @@ def run(mode, spin):
     for _ in range(5): lib.knerf_debug_write_probe(buf.data_ptr(), wgs, blocks, stride, mode, spin, s)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 5
+for pol, pname in ((0, "nt"), (1, "plain"), (2, "sc1"), (3, "sc0 sc1")):
+    ms = run(0, pol << 16)
+    print(json.dumps({"layout": "tile-major", "policy": pname, "ms": round(ms, 3), "TBs": round(byts / ms / 1e9, 2)}), flush=True)
+ms = run(0, 1 << 30)
+print(json.dumps({"layout": "tile-major", "policy": "nt", "resident": "one workgroup per CU", "ms": round(ms, 3), "TBs": round(byts / ms / 1e9, 2)}), flush=True)
 for spin in (0, 16):
     for mode in (0, 8, 64, 512, 4096, 24576):
         ms = run(mode, spin)
