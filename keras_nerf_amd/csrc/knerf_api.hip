@@ -531,6 +531,24 @@ int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float
     return run_pass(ctx, s, KNERF_FINE, o, d, tf, n_rays, Na, f_image, f_depth, f_weights, nullptr, 1.f, nullptr);
 }
 
+int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u, uint64_t seed,
+                       int n_rays, int ray_chunks, float* c_image, float* c_depth, float* c_weights, float* f_image, float* f_depth,
+                       float* f_weights) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
+        return fail(ctx, KNERF_ERR_INVALID, "render_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
+    const size_t Nc = (size_t)ctx->cfg.n_coarse, Nf = (size_t)ctx->cfg.n_fine, Na = Nc + Nf;
+    for (int i = 0; i < n_rays / ray_chunks; ++i) {
+        const size_t r0 = (size_t)i * ray_chunks;
+        if (int r = knerf_render_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, u ? u + r0 * Nf : nullptr, seed, (uint64_t)r0,
+                                       ray_chunks, c_image ? c_image + r0 * 3 : nullptr, c_depth ? c_depth + r0 : nullptr,
+                                       c_weights ? c_weights + r0 * Nc : nullptr, f_image ? f_image + r0 * 3 : nullptr,
+                                       f_depth ? f_depth + r0 : nullptr, f_weights ? f_weights + r0 * Na : nullptr, nullptr))
+            return r;
+    }
+    return KNERF_OK;
+}
+
 int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
                       const float* u, uint64_t seed, uint64_t ray_offset, int n_rays, float inv_chunks, float* loss,
                       float* c_image, float* f_image) {

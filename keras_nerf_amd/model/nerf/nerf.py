@@ -199,10 +199,8 @@ class NeRF:
         buf = dict(c_image=e(N, 3), c_depth=e(N), c_weights=e(N, Nc), f_image=e(N, 3), f_depth=e(N), f_weights=e(N, Na))
         uf = None if u is None else self._ctx.f32(u).reshape(N, self.n_fine)
         seed = self._next_seed()
-        for i in range(self.sequential_chunks):
-            sl = slice(i * R, (i + 1) * R)
-            self._ctx.render_chunk(o[sl], d[sl], t[sl], None if uf is None else uf[sl], seed, i * R,
-                                   out={k: v[sl] for k, v in buf.items()})
+        # the chunk loop of nerf.py:236-288 runs inside the library: one host call per batch of images
+        self._ctx.render_batch(o, d, t, uf, seed, R, out=buf)
         B, H, W = self.batch_size, self.image_height, self.image_width
         coarse = {"image": buf["c_image"].reshape(B, H, W, 3), "depth": buf["c_depth"].reshape(B, H, W),
                   "weights": buf["c_weights"].reshape(B, H, W, Nc)}

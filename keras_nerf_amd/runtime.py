@@ -143,6 +143,22 @@ class KnerfContext:
                                                 _ptr(out.get("f_weights")), _ptr(out.get("t_fine"))))
         return out
 
+    def render_batch(self, o, d, t, u=None, seed=0, ray_chunks=None, out=None):
+        """the whole chunk loop of predict_and_render_images in one host call; `out` as in render_chunk but [N,...]"""
+        o, d, t = self.f32(o), self.f32(d), self.f32(t)
+        u = None if u is None else self.f32(u)
+        N = t.shape[0]
+        Na = self.n_coarse + self.n_fine
+        if out is None:
+            def e(*s):
+                return torch.empty(s, device=self.device)
+            out = dict(c_image=e(N, 3), c_depth=e(N), c_weights=e(N, self.n_coarse), f_image=e(N, 3), f_depth=e(N), f_weights=e(N, Na))
+        self._check(self.lib.knerf_render_batch(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(u), seed, N,
+                                                int(ray_chunks or N), _ptr(out["c_image"]), _ptr(out.get("c_depth")),
+                                                _ptr(out.get("c_weights")), _ptr(out["f_image"]), _ptr(out.get("f_depth")),
+                                                _ptr(out.get("f_weights"))))
+        return out
+
     # ---- training
     def train_chunk(self, o, d, t, target, u=None, seed=0, ray_offset=0, inv_chunks=1.0, loss=None, c_image=None,
                     f_image=None):
