@@ -9,9 +9,11 @@
 // every segment padded to a multiple of 32 columns with zeros), so that both MFMA operands of `out = in . W` are
 // K-contiguous 16-byte loads: A fragment = 8 consecutive features of a sample, B fragment = 8 consecutive input weights
 // of an output unit (weights are packed transposed, Wt[out][in]).  dgrad uses the same kernel with Wd[in][out].
-// wgrad contracts over samples (the row index of both operands): each 32x32 block is transposed in registers by two MFMAs
-// against identity fragments -- D = A.[I|0] + A'.[0|I] leaves lane = feature, registers = samples, which is an MFMA
-// operand with a fixed sample permutation shared by both factors -- so no LDS and no workgroup barrier is involved.
+// wgrad contracts over samples (the row index of both operands).  Layers of at least 128 x 128: a workgroup stages [32][256]
+// slabs of X and dZ in LDS and reads sample-major operand fragments with ds_read_b64_tr_b16 (wgrad_coop_kernel).  Smaller
+// layers: each 32x32 block is transposed in registers by two MFMAs against identity fragments -- D = A.[I|0] + A'.[0|I]
+// leaves lane = feature, registers = samples, an MFMA operand with a fixed sample permutation shared by both factors --
+// so neither LDS nor a workgroup barrier is involved (wgrad_kernel).
 #include "generic.h"
 
 #include <cmath>
