@@ -242,9 +242,12 @@ def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     import sys
     from keras_nerf_amd.runtime import KnerfContext
     from tests.dp_gpu_worker import problem
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py"), str(tmp_path)]
+           "--master-port", str(port), os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py"), str(tmp_path)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
