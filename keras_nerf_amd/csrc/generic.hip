@@ -115,75 +115,52 @@ struct GemmArgs {
 // switches (fp32 or bf16 output, mask or not) are taken ONCE around the element loops and every address is a base pointer
 // plus a uniform multiple of the row pitch: left as per-element branches and 64-bit multiplies (what hipcc makes of the
 // straightforward loop) the epilogue costs more than the tile's 128 MFMAs.
-template <int NT, bool TR>
+template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NT], long long m0, int n0, int r, int h) {
-    if constexpr (!TR) {
-        // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
-        const size_t row0 = (size_t)(m0 + 4 * h);
-        if (g.Cf) {                                   // fp32 head outputs (no mask, no relu)
+    // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
+    const size_t row0 = (size_t)(m0 + 4 * h);
+    if (g.Cf) {                                   // fp32 head outputs (no mask, no relu)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = n0 + 32 * t + r;
-                const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
-                float* p = g.Cf + row0 * g.ldcf + col;
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + 32 * t + r;
+            const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
+            float* p = g.Cf + row0 * g.ldcf + col;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldcf] = acc[t][i] + b;
+            for (int i = 0; i < 16; ++i) p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldcf] = acc[t][i] + b;
+        }
+    } else if (g.aux) {
+        // dgrad through the plain orientation (KNERF_GEN_DGRAD_PLAIN): the mask halfwords of tile t + 1 are requested
+        // while tile t is masked and stored
+        const u16* ax = g.aux + row0 * g.ldaux + n0 + r;
+        u16 mk[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mk[0][i] = ax[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldaux];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mk[(t + 1) & 1][i] = ax[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldaux + 32 * (t + 1)];
             }
-        } else {
-            const bool relu = g.relu != 0;
+            u16* p = g.Cb + row0 * g.ldc + n0 + 32 * t + r;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = n0 + 32 * t + r;
-                const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
-                u16* p = g.Cb + row0 * g.ldc + col;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = acc[t][i] + b;
-                    v = relu ? fmaxf(v, 0.f) : v;
-                    p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const float v = (short)mk[t & 1][i] > 0 ? acc[t][i] : 0.f;
+                p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
             }
         }
     } else {
-        // D'[n][m]: lane (m = r, hh = h), registers i -> column n = (i&3) + 8(i>>2) + 4hh: four consecutive columns of one
-        // row per register quad (dgrad: no bias, no relu; bf16 output; mask optional)
-        const size_t row = (size_t)(m0 + r);
-        u16* p = g.Cb + row * g.ldc + n0 + 4 * h;
-        auto put = [&](int t, int q, const float (&v)[4]) {
-            uint2 o;
-            o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
-            o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(p + 32 * t + 8 * q) = o;
-        };
-        if (g.aux) {
-            // the mask words do not depend on the products: all of them are requested up front (32 x 8 B per lane for
-            // NT = 8, accumulators are dead one tile at a time) instead of one load -> wait -> store per register quad
-            const u16* ax = g.aux + row * g.ldaux + n0 + 4 * h;
-            uint2 m[NT][4];
+        const bool relu = g.relu != 0;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + 32 * t + r;
+            const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
+            u16* p = g.Cb + row0 * g.ldc + col;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) m[t][q] = *reinterpret_cast<const uint2*>(ax + 32 * t + 8 * q);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint2 a = m[t][q];
-                    float v[4];
-                    v[0] = (short)(a.x & 0xffffu) > 0 ? acc[t][4 * q + 0] : 0.f;
-                    v[1] = (short)(a.x >> 16) > 0 ? acc[t][4 * q + 1] : 0.f;
-                    v[2] = (short)(a.y & 0xffffu) > 0 ? acc[t][4 * q + 2] : 0.f;
-                    v[3] = (short)(a.y >> 16) > 0 ? acc[t][4 * q + 3] : 0.f;
-                    put(t, q, v);
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-                    put(t, q, v);
-                }
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[t][i] + b;
+                v = relu ? fmaxf(v, 0.f) : v;
+                p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
+            }
         }
     }
 }
@@ -194,10 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // global memory (each wave owns its rows) and are fetched one chunk ahead.
 constexpr int kGemmWaves = 8, kGemmKC = 64, kGemmRowB = 144;
 
-// TR: form the product transposed (weights as the A operand).  Measured on the default shape: the plain orientation is the
-// faster forward (303 vs 239 TFLOP/s: its 2-byte stores cover 64 contiguous bytes of two rows per instruction), the
-// transposed one the faster dgrad (four 8-byte mask loads per tile instead of sixteen 2-byte ones: 9.9 vs 12.6 ms).
-template <int NT, bool TR>
+template <int NT>
 __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int NB = NT * 32;                       // staged Bt rows
@@ -255,8 +229,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + t * 32 * kGemmRowB + ks * 32);
-                    if (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a_cur[ks], acc[t], 0, 0, 0);   // D'[n][m]
-                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[ks], b, acc[t], 0, 0, 0);        // D[m][n]
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[ks], b, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -268,7 +241,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
     if (!live) return;
-    gemm_epilogue<NT, TR>(g, acc, m0, n0, r, h);
+    gemm_epilogue<NT>(g, acc, m0, n0, r, h);
 }
 
 // Weights-stationary variant for the common case that a whole Bt slab [32 NT][K] fits in LDS: it is staged ONCE per workgroup
@@ -277,7 +250,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
 // wave streams its own rows (A fragments one 64-wide chunk ahead, across tile boundaries) against the resident weights.
 // The chunk body is branch-free and fully unrolled with the B fragments read 4 MFMAs ahead (left to itself hipcc emits
 // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per fragment: 48 cycles per MFMA instead of 8).
-template <int NT, bool TR>
+template <int NT>
 __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, int pitch) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int NB = NT * 32;
@@ -329,69 +302,64 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
             for (int f = 0; f < NF; ++f) {
                 const bf16x8 cur = pf[f % 4];
                 pf[f % 4] = f + 4 < NF ? frag(k, f + 4) : frag(kn, f + 4 - NF);
-                if (TR) acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, a_cur[f / NT], acc[f % NT], 0, 0, 0);
-                else acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[f / NT], cur, acc[f % NT], 0, 0, 0);
+                acc[f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[f / NT], cur, acc[f % NT], 0, 0, 0);
             }
             if (more || next_tile) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) a_cur[ks] = a_nxt[ks];
             }
         }
-        gemm_epilogue<NT, TR>(g, acc, m0, n0, r, h);
+        gemm_epilogue<NT>(g, acc, m0, n0, r, h);
     }
 }
 
 constexpr size_t kGemmWsLds = 150 * 1024;
-template <int NT, bool TR>
+template <int NT>
 hipError_t launch_gemm_ws(const GemmArgs& g, int gy, hipStream_t s) {
     const int pitch = (g.K + 63) / 64 * 64 * 2 + 16;
     const size_t lds = (size_t)NT * 32 * pitch;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<NT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmWsLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmWsLds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     long long gx = (g.M / 32 + kGemmWaves - 1) / kGemmWaves;
     const long long cap = 512 / gy > 0 ? 512 / gy : 1;           // persistent: about two workgroups per CU in all
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((gemm_ws_kernel<NT, TR>), dim3((unsigned)gx, gy), dim3(kGemmWaves * 64), lds, s, g, pitch);
+    hipLaunchKernelGGL((gemm_ws_kernel<NT>), dim3((unsigned)gx, gy), dim3(kGemmWaves * 64), lds, s, g, pitch);
     return hipGetLastError();
 }
 
-template <int NT, bool TR>
+template <int NT>
 hipError_t launch_gemm_nt(const GemmArgs& g, int gy, hipStream_t s) {
     const size_t lds = 2 * (size_t)NT * 32 * kGemmRowB;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<NT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const unsigned gx = (unsigned)((g.M + kGemmWaves * 32 - 1) / (kGemmWaves * 32));
-    hipLaunchKernelGGL((gemm_kernel<NT, TR>), dim3(gx, gy), dim3(kGemmWaves * 64), lds, s, g);
+    hipLaunchKernelGGL((gemm_kernel<NT>), dim3(gx, gy), dim3(kGemmWaves * 64), lds, s, g);
     return hipGetLastError();
 }
 
-template <bool TR>
-hipError_t launch_gemm_tr(const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int nt = g.N / 32;
     const size_t row_bytes = (size_t)(g.K + 63) / 64 * 64 * 2 + 16;
 #ifndef KNERF_GEN_NO_WS
     // the widest column block whose weight slab fits in LDS, resident for the whole launch
-    if (nt % 8 == 0 && 256 * row_bytes <= kGemmWsLds) return launch_gemm_ws<8, TR>(g, nt / 8, s);
-    if (nt % 4 == 0 && 128 * row_bytes <= kGemmWsLds) return launch_gemm_ws<4, TR>(g, nt / 4, s);
-    if (nt % 2 == 0 && 64 * row_bytes <= kGemmWsLds) return launch_gemm_ws<2, TR>(g, nt / 2, s);
-    if (32 * row_bytes <= kGemmWsLds) return launch_gemm_ws<1, TR>(g, nt, s);
+    if (nt % 8 == 0 && 256 * row_bytes <= kGemmWsLds) return launch_gemm_ws<8>(g, nt / 8, s);
+    if (nt % 4 == 0 && 128 * row_bytes <= kGemmWsLds) return launch_gemm_ws<4>(g, nt / 4, s);
+    if (nt % 2 == 0 && 64 * row_bytes <= kGemmWsLds) return launch_gemm_ws<2>(g, nt / 2, s);
+    if (32 * row_bytes <= kGemmWsLds) return launch_gemm_ws<1>(g, nt, s);
 #endif
-    if (nt % 8 == 0) return launch_gemm_nt<8, TR>(g, nt / 8, s);
-    if (nt % 4 == 0) return launch_gemm_nt<4, TR>(g, nt / 4, s);
-    if (nt % 2 == 0) return launch_gemm_nt<2, TR>(g, nt / 2, s);
-    return launch_gemm_nt<1, TR>(g, nt, s);
+    if (nt % 8 == 0) return launch_gemm_nt<8>(g, nt / 8, s);
+    if (nt % 4 == 0) return launch_gemm_nt<4>(g, nt / 4, s);
+    if (nt % 2 == 0) return launch_gemm_nt<2>(g, nt / 2, s);
+    return launch_gemm_nt<1>(g, nt, s);
 }
-// forward layers (no mask) take the plain orientation, dgrad the transposed one
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) { return g.aux ? launch_gemm_tr<true>(g, s) : launch_gemm_tr<false>(g, s); }
-
 // ---- heads ----------------------------------------------------------------------------------------------------------
 // raw[m] = (sigmoid(zc[m][0..2]), relu(zs[m][0]))   (mlp.py:44-49)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ zc, long long n, float* __restrict__ raw) {
