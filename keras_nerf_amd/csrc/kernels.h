@@ -37,6 +37,7 @@ struct WgradArgs {
     const void* plan;       // device array of WgradPlan, one per workgroup
     long long n_tiles;
     int n_plan;
+    int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
     int job_off[14];        // offset of each job's table inside dst
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);

@@ -259,7 +259,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
-        wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan;
+        wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
         if (ctx->fused_producers > 0) {
             FusedArgs f{};

@@ -3,6 +3,9 @@
 
 namespace knerf {
 
+// NET only names the instantiation (0 = coarse pass, 1 = fine pass) so that profiler summaries list the two launch sizes
+// separately (profiles/*kernel_stats*.csv against bench.py's wgrad_coarse / wgrad_fine)
+template <int NET>
 __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgradPlan pl = reinterpret_cast<const WgradPlan*>(a.plan)[blockIdx.x];
@@ -20,11 +23,14 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     const size_t lds = 160 * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_plan), dim3(kWgThreads), lds, stream, a);
+    if (a.net == 0) hipLaunchKernelGGL(wgrad_kernel<0>, dim3(a.n_plan), dim3(kWgThreads), lds, stream, a);
+    else hipLaunchKernelGGL(wgrad_kernel<1>, dim3(a.n_plan), dim3(kWgThreads), lds, stream, a);
     return hipGetLastError();
 }
 
