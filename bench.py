@@ -253,6 +253,11 @@ def main():
         roofline["kernel_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof.items()}
         roofline["step_train_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP / (elapsed / args.steps) / 1e12
         roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
+        # whole-step HBM view: per 32-sample tile the step writes 158 KiB of activations, 8 KiB of relu
+        # masks and 156 KiB of dZ and reads 162 + 8 + 156 KiB of them back (wgrad, dgrad), plus raw/draw: 650.5 KiB
+        step_bytes = n_rays * samples_per_ray / 32 * 650.5 * 1024
+        roofline["step_algorithmic_gbytes"] = step_bytes / 1e9
+        roofline["step_frac_of_hbm_peak"] = step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
