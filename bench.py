@@ -152,8 +152,8 @@ def pmc_traffic(kernel):
     tools/pmc_report.py: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
     reads on gfx950, WRITE_SIZE as is, both in KiB).  None when no summary is committed for this kernel."""
     import glob
-    name = {"wgrad_fine": ("wgrad_kernel", max), "wgrad_coarse": ("wgrad_kernel", min), "mlp_fwd_fine": ("mlp_fwd_kernel<true>", max),
-            "mlp_fwd_coarse": ("mlp_fwd_kernel<true>", min), "mlp_bwd_fine": ("mlp_bwd_kernel", max),
+    name = {"wgrad_fine": ("wgrad_kernel", max), "wgrad_coarse": ("wgrad_kernel", min), "mlp_fwd_fine": ("mlp_fwd_kernel<true", max),
+            "mlp_fwd_coarse": ("mlp_fwd_kernel<true", min), "mlp_bwd_fine": ("mlp_bwd_kernel", max),
             "mlp_bwd_coarse": ("mlp_bwd_kernel", min)}.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
     if not name or not files:

@@ -16,6 +16,7 @@ struct FwdArgs {
     char* mask;             // SAVE: [tiles][kMaskBlocks][1 KiB]
     long long n_samples;    // R*S
     int S;
+    int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
 };
 hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream);
 
@@ -26,6 +27,7 @@ struct BwdArgs {
     const char* mask;       // relu masks saved by the forward
     char* dz;               // out: [tiles][kDzBlocks][1 KiB]
     long long n_samples;
+    int net;                // 0 coarse / 1 fine: kernel instantiation name only
 };
 hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 

@@ -235,7 +235,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     FwdArgs fa{};
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
     fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw; fa.act = ctx->act; fa.mask = ctx->mask;
-    fa.n_samples = (long long)R * S; fa.S = S;
+    fa.n_samples = (long long)R * S; fa.S = S; fa.net = net == KNERF_COARSE ? 0 : 1;
     if (ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F);
         HIPCHK(gen::forward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->net[net].w, o, d, t, fa.n_samples, S, ctx->raw, s));
@@ -255,7 +255,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     } else if (train) {
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
-        ba.n_samples = fa.n_samples;
+        ba.n_samples = fa.n_samples; ba.net = fa.net;
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);

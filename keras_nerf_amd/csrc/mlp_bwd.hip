@@ -3,6 +3,8 @@
 
 namespace knerf {
 
+// NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries
+template <int NET>
 __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     mlp_bwd_tile(a, smem, blockIdx.x);
@@ -14,11 +16,14 @@ hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = kRingBytes;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(kThreads), lds, stream, a);
+    if (a.net == 0) hipLaunchKernelGGL(mlp_bwd_kernel<0>, dim3(grid), dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL(mlp_bwd_kernel<1>, dim3(grid), dim3(kThreads), lds, stream, a);
     return hipGetLastError();
 }
 

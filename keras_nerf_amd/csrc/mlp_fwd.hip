@@ -57,7 +57,8 @@ constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
 struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<11, kFwdBlocks>(kFwdStores); };
 struct FwdWaitPlain { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<1, kFwdBlocks>(kNoStores); };
 
-template <bool SAVE>
+// NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries
+template <bool SAVE, int NET>
 __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bias_lds = reinterpret_cast<float*>(smem + kRingBytes);
@@ -191,14 +192,22 @@ hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
     const size_t lds = kRingBytes + kFwdBiasTiles * 32 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {reinterpret_cast<const void*>(mlp_fwd_kernel<false, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<false, 1>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<true, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<true, 1>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
-    if (save) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), lds, stream, a);
-    else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), lds, stream, a);
+    const dim3 g(grid), b(kThreads);
+    if (save) {
+        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<true, 0>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<true, 1>), g, b, lds, stream, a);
+    } else {
+        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<false, 0>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<false, 1>), g, b, lds, stream, a);
+    }
     return hipGetLastError();
 }
 
