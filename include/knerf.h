@@ -87,11 +87,12 @@ int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float
                        float* f_image, float* f_depth, float* f_weights, float* t_fine);
 
 /* predict_and_render_images (nerf.py:229-304): the chunk loop of knerf_render_chunk over n_rays = C * ray_chunks rays in one
- * host call; outputs are whole-batch arrays ([n_rays, ...], images mandatory, the rest optional).  ray_offset of chunk i is
- * i * ray_chunks, so results equal C separate knerf_render_chunk calls. */
+ * host call; outputs are whole-batch arrays ([n_rays, ...], images mandatory, the rest optional; t_fine [n_rays,
+ * n_coarse+n_fine] receives the merged t-values of nerf.py:190-191).  ray_offset of chunk i is i * ray_chunks, so results
+ * equal C separate knerf_render_chunk calls. */
 int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u, uint64_t seed,
                        int n_rays, int ray_chunks, float* c_image, float* c_depth, float* c_weights, float* f_image, float* f_depth,
-                       float* f_weights);
+                       float* f_weights, float* t_fine);
 
 /* One iteration of train_step's chunk loop (nerf.py:351-421): coarse forward+backward, fine forward+backward,
  * gradients accumulated as acc += g * inv_chunks, chunk losses accumulated into loss[0] (coarse) / loss[1] (fine)

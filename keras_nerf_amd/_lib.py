@@ -40,7 +40,7 @@ SIGNATURES = {
     "knerf_train_batch": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_int, C.c_int, _F, _F, _F]),
     "knerf_apply_adam": (C.c_int, [_P, _P]),
     "knerf_zero_grads": (C.c_int, [_P, _P]),
-    "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "knerf_ray_points": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "knerf_image_metrics": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "knerf_mlp_call": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_uint64, _P]),

@@ -533,7 +533,7 @@ int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float
 
 int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u, uint64_t seed,
                        int n_rays, int ray_chunks, float* c_image, float* c_depth, float* c_weights, float* f_image, float* f_depth,
-                       float* f_weights) {
+                       float* f_weights, float* t_fine) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "render_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
@@ -543,7 +543,8 @@ int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float
         if (int r = knerf_render_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, u ? u + r0 * Nf : nullptr, seed, (uint64_t)r0,
                                        ray_chunks, c_image ? c_image + r0 * 3 : nullptr, c_depth ? c_depth + r0 : nullptr,
                                        c_weights ? c_weights + r0 * Nc : nullptr, f_image ? f_image + r0 * 3 : nullptr,
-                                       f_depth ? f_depth + r0 : nullptr, f_weights ? f_weights + r0 * Na : nullptr, nullptr))
+                                       f_depth ? f_depth + r0 : nullptr, f_weights ? f_weights + r0 * Na : nullptr,
+                                       t_fine ? t_fine + r0 * Na : nullptr))
             return r;
     }
     return KNERF_OK;

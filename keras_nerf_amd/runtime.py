@@ -144,7 +144,8 @@ class KnerfContext:
         return out
 
     def render_batch(self, o, d, t, u=None, seed=0, ray_chunks=None, out=None):
-        """the whole chunk loop of predict_and_render_images in one host call; `out` as in render_chunk but [N,...]"""
+        """the whole chunk loop of predict_and_render_images in one host call; `out` as in render_chunk but [N,...]
+        (an optional out["t_fine"] [N, n_coarse+n_fine] receives the merged t-values)"""
         o, d, t = self.f32(o), self.f32(d), self.f32(t)
         u = None if u is None else self.f32(u)
         N = t.shape[0]
@@ -156,7 +157,7 @@ class KnerfContext:
         self._check(self.lib.knerf_render_batch(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(u), seed, N,
                                                 int(ray_chunks or N), _ptr(out["c_image"]), _ptr(out.get("c_depth")),
                                                 _ptr(out.get("c_weights")), _ptr(out["f_image"]), _ptr(out.get("f_depth")),
-                                                _ptr(out.get("f_weights"))))
+                                                _ptr(out.get("f_weights")), _ptr(out.get("t_fine"))))
         return out
 
     # ---- training

@@ -108,6 +108,8 @@ def test_nerf_utils_ops_match_oracle():
     xo, do_ = O.encode_position_and_directions(o, d, t, 10, 4)
     np.testing.assert_allclose(e2.cpu().numpy(), do_, atol=1e-5)
     np.testing.assert_allclose(e1.cpu().numpy()[..., :3], xo[..., :3], atol=1e-6)
+    np.testing.assert_allclose(e1.cpu().numpy(), xo, atol=3e-4)                        # all 63 columns: sin/cos of up to 2^9 |p| rad
+    assert np.abs(xo[..., 3:]).max() > 0.99
     rgb = rng.random((1024, 32, 3), dtype=np.float32); sig = (rng.random((1024, 32, 1), dtype=np.float32) * 3)
     tt = np.sort(rng.uniform(2, 6, (1024, 32)).astype(np.float32), -1)
     img, depth, w = U.render_image_depth_chunk(rgb, sig, tt)

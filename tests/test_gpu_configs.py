@@ -1,0 +1,195 @@
+"""BASELINE.json's single-GPU configurations at their real sizes, against the oracle:
+
+cfg5  inference.py-shaped render, 256x256, ray_chunks 4096 (16 chunks): RaysGenerator -> predict_and_render_images;
+      256 sampled rays against the oracle (coarse image / weights, merged t-values bit for bit, fine image / weights on
+      the GPU's own t-values).
+cfg3  400x400, batch 1: ray_chunks 16384 violates the divisibility assert (nerf.py:100), 16000 trains; one train_batch
+      equals ten train_chunk calls; the gradients of a sampled sub-chunk against the oracle.
+cfg1  the coarse-only configuration (n_fine = 0) TRAINED, not only rendered: gradients of both nets against the oracle.
+cfg4 needs eight GPUs and is the driver's to run; its per-GPU work is cfg2's with one image.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from tests.test_gpu_forward import log_stats
+from tests.test_gpu_train import per_tensor_err
+
+pytestmark = pytest.mark.gpu
+
+FOV = 0.6911112070083618          # inference.py:27
+GRAD_TOL_EMU, GRAD_TOL_FP32 = 2.5e-2, 8e-2      # of each tensor's max |g|: vs the oracle in kernel arithmetic / in fp32
+
+
+def scaled_params(cfg, seed, scale=1.5, bias_std=0.05):
+    rng = np.random.default_rng(100 + seed)
+    p = [w * np.float32(scale) for w in O.init_params(cfg, seed)]
+    for b in p[1::2]:
+        b += rng.normal(0, bias_std, b.shape).astype(np.float32)
+    return p
+
+
+def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
+    from keras_nerf_amd.data.rays import RaysGenerator
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    wh, R = 256, 4096
+    cfg = O.NerfConfig()
+    cp, fp = scaled_params(cfg, 0), scaled_params(cfg, 1)
+    nerf = NeRF(seed=0)
+    nerf.compile("adam", "mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=R, white_background=True, is_training=False)
+    assert nerf.sequential_chunks == 16
+    nerf.coarse.set_flat_weights(O.flatten_params(cp)); nerf.fine.set_flat_weights(O.flatten_params(fp))
+    rg = RaysGenerator(get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, cfg.n_coarse, seed=3)
+    o, d, t = rg(pose_spherical(70.0, -30.0, 4.0))                      # inference.py:84-87
+    N = wh * wh
+    u = torch.rand((N, cfg.n_fine), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    coarse, fine = nerf.predict_and_render_images((o[None], d[None], t[None]), u=u)
+    assert fine["image"].shape == (1, wh, wh, 3) and fine["depth"].shape == (1, wh, wh) and fine["weights"].shape == (1, wh, wh, 192)
+    # the same library call with the merged t-values exposed
+    of, df, tf_ = o.reshape(N, 3).contiguous(), d.reshape(N, 3).contiguous(), t.reshape(N, -1).contiguous()
+    buf = dict(c_image=torch.empty((N, 3), device="cuda"), c_weights=torch.empty((N, 64), device="cuda"),
+               f_image=torch.empty((N, 3), device="cuda"), f_weights=torch.empty((N, 192), device="cuda"),
+               t_fine=torch.empty((N, 192), device="cuda"))
+    nerf._ctx.render_batch(of, df, tf_, u, 0, R, out=buf)
+    assert torch.equal(buf["f_image"].reshape(1, wh, wh, 3), fine["image"]) and torch.equal(buf["c_image"].reshape(1, wh, wh, 3), coarse["image"])
+    # 256 rays, a few from every chunk
+    idx = np.sort(np.random.default_rng(1).choice(N, 256, replace=False))
+    assert len(set(idx // R)) == 16
+    g = lambda x: x.cpu().numpy()[idx]
+    so, sd, st, su = g(of), g(df), g(tf_), g(u)
+    rc = O.predict_and_render_chunk_single(cp, so, sd, st, cfg, True, emulate_bf16=True)
+    ci, cw, tfine = g(buf["c_image"]), g(buf["c_weights"]), g(buf["t_fine"])
+    np.testing.assert_array_equal(tfine, O.fine_points(st, cw, su, "zero"))          # sampler + 192-way merge: bit exact
+    rf = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True, emulate_bf16=True)
+    rf32 = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True)
+    fi, fw = g(buf["f_image"]), g(buf["f_weights"])
+    log_stats("cfg5_render_256", c_img=np.abs(ci - rc["image"]).max(), c_w=np.abs(cw - rc["weights"]).max(),
+              f_img=np.abs(fi - rf["image"]).max(), f_w=np.abs(fw - rf["weights"]).max(), f_img_fp32=np.abs(fi - rf32["image"]).max())
+    np.testing.assert_allclose(ci, rc["image"], atol=1e-2); np.testing.assert_allclose(cw, rc["weights"], atol=1e-2)
+    np.testing.assert_allclose(fi, rf["image"], atol=1e-2); np.testing.assert_allclose(fw, rf["weights"], atol=1e-2)
+    assert np.abs(fi - rf32["image"]).max() < 2e-2                                   # stated tolerance
+    assert cw.std() > 1e-3 and fw.std() > 1e-3
+
+
+def test_cfg3_400x400_ten_chunks_of_16000():
+    from keras_nerf_amd.data.rays import RaysGenerator
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    wh, R = 400, 16000
+    cfg = O.NerfConfig()
+    cp, fp = scaled_params(cfg, 2), scaled_params(cfg, 3)
+    nerf = NeRF(seed=0)
+    with pytest.raises(AssertionError):                                              # nerf.py:100: 160000 % 16384 = 12544
+        nerf.compile("adam", "mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=16384, white_background=True)
+    nerf.compile("adam", "mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=R, white_background=True)
+    assert nerf.sequential_chunks == 10 and nerf.num_rays == 160000
+    nerf.coarse.set_flat_weights(O.flatten_params(cp)); nerf.fine.set_flat_weights(O.flatten_params(fp))
+    ctx = nerf._ctx
+    N = wh * wh
+    o, d, t = RaysGenerator(get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, cfg.n_coarse, seed=9)(pose_spherical(200.0, -30.0, 4.0))
+    o, d, t = o.reshape(N, 3).contiguous(), d.reshape(N, 3).contiguous(), t.reshape(N, -1).contiguous()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    tgt = torch.rand((N, 3), device="cuda", generator=gen); u = torch.rand((N, cfg.n_fine), device="cuda", generator=gen)
+    res = []
+    for whole in (True, False):
+        loss = torch.zeros(2, device="cuda"); ci = torch.empty((N, 3), device="cuda"); fi = torch.empty((N, 3), device="cuda")
+        ctx.zero_grads()
+        if whole:
+            ctx.train_batch(o, d, t, tgt, u, seed=0, ray_chunks=R, loss=loss, c_image=ci, f_image=fi)
+        else:
+            for c in range(N // R):
+                sl = slice(c * R, (c + 1) * R)
+                ctx.train_chunk(o[sl], d[sl], t[sl], tgt[sl], u[sl], ray_offset=c * R, inv_chunks=R / N, loss=loss, c_image=ci[sl], f_image=fi[sl])
+        torch.cuda.synchronize()
+        res.append((ci, fi, loss.clone(), ctx.grads_view().clone()))
+    (c0, f0, l0, g0), (c1, f1, l1, g1) = res
+    assert torch.equal(c0, c1) and torch.equal(f0, f1)
+    assert float((l0 - l1).abs().max()) < 1e-6
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max()) and float(g0.abs().max()) > 0   # fp32 summation order
+    assert abs(float(((f0 - tgt) ** 2).mean()) - float(l0[1])) < 1e-5                # the loss is the MSE of the returned image
+    # a sampled sub-chunk (rays from all over the image) against the oracle
+    idx = np.sort(np.random.default_rng(2).choice(N, 192, replace=False))
+    ti = torch.as_tensor(idx, device="cuda")
+    so, sd, st, sg, su = (x[ti].contiguous() for x in (o, d, t, tgt, u))
+    ctx.zero_grads()
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(so, sd, st, sg, su, loss=loss)
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:192 * 192].reshape(192, 192)
+    so, sd, st, sg = (x.cpu().numpy() for x in (so, sd, st, sg))
+    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
+        _, lc, gc = O.chunk_loss_and_grads(cp, so, sd, st, sg, cfg, True, emulate_bf16=emu)
+        _, lf, gf = O.chunk_loss_and_grads(fp, so, sd, t_fine, sg, cfg, True, emulate_bf16=emu)
+        ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+        log_stats(f"cfg3_subchunk_grads_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
+        assert ec[0] < tol and ef[0] < tol, (ec, ef)
+        assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    # the class-level step at this size (nerf.py:332-473)
+    ctx.zero_grads()
+    before = nerf.fine.get_flat_weights()
+    logs = nerf.train_step((tgt.reshape(1, wh, wh, 3), (o.reshape(1, wh, wh, 3), d.reshape(1, wh, wh, 3), t.reshape(1, wh, wh, -1))),
+                           u=u, with_metrics=False)
+    assert abs(float(logs["fine_loss"]) - float(l0[1])) < 1e-5
+    assert 0 < np.abs(nerf.fine.get_flat_weights() - before).max() <= 1.01e-3       # one Adam step of lr 1e-3
+
+
+def test_coarse_only_configuration_trains_both_nets_against_oracle():
+    """BASELINE configs[0] (coarse-only, 64 samples): with n_fine = 0 the reference's fine branch degenerates to
+    sort(concat(t, [])) = t (nerf.py:182-191), so both networks train on the coarse t-values."""
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = O.NerfConfig(n_coarse=64, n_fine=0)
+    cp, fp = scaled_params(cfg, 4), scaled_params(cfg, 5)
+    rng = np.random.default_rng(0)
+    wh = 16
+    o, d, t = O.generate_rays(O.pose_spherical(33.0, -30.0, 4.0), O.get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, 64, rng.random((wh, wh, 64)))
+    N = wh * wh
+    o, d, t = o.reshape(N, 3), d.reshape(N, 3), t.reshape(N, 64)
+    img = rng.random((N, 3), dtype=np.float32)
+    ctx = KnerfContext(n_coarse=64, n_fine=0, white_background=False)
+    ctx.set_weights(0, O.flatten_params(cp)); ctx.set_weights(1, O.flatten_params(fp))
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, None, loss=loss)
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:N * 64].reshape(N, 64)
+    np.testing.assert_array_equal(t_fine, t)
+    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
+        _, lc, gc = O.chunk_loss_and_grads(cp, o, d, t, img, cfg, False, emulate_bf16=emu)
+        _, lf, gf = O.chunk_loss_and_grads(fp, o, d, t, img, cfg, False, emulate_bf16=emu)
+        ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+        log_stats(f"coarse_only_train_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
+        assert ec[0] < tol and ef[0] < tol, (ec, ef)
+        assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    ctx.apply_adam()
+    assert ctx.step == 1 and np.abs(ctx.get_weights(0) - O.flatten_params(cp)).max() > 0
+    ctx.close()
+
+
+def test_lego_camera_of_the_reference_ray_test():
+    """The one camera matrix the reference's tests hold (tests/data/test_rays.py:21-47; committed as data under
+    tests/golden/lego_c2w.json) through RaysGenerator with that test's own assertions (:50-87), and against the oracle."""
+    import json
+    import os
+    from keras_nerf_amd.data.rays import RaysGenerator
+    F = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lego_c2w.json")))
+    c2w = np.asarray(F["camera_to_world"], np.float32)
+    W, H, S = F["image_width"], F["image_height"], F["n_sample"]
+    rg = RaysGenerator(F["focal_length"], W, H, F["near"], F["far"], S)
+    last = None
+    for _ in range(4):
+        o, d, t = [x.cpu().numpy() for x in rg(c2w)]
+        assert o.shape == (H, W, 3) and d.shape == (H, W, 3) and t.shape == (H, W, S)
+        assert o.dtype == np.float32 and d.dtype == np.float32 and t.dtype == np.float32
+        assert not np.isnan(o).any() and not np.isnan(d).any() and not np.isnan(t).any()
+        assert t.min() >= 2.0 - 4.0 / 32.0 and t.max() <= 6.0 + 4.0 / 32.0
+        if last is not None:
+            assert np.allclose(last[0], o) and np.allclose(last[1], d) and np.allclose(last[2], t, atol=4.0 / 32.0)
+            assert np.abs(last[2] - t).max() > 0                                    # the jitter is redrawn per call (rays.py:122-123)
+        last = (o, d, t)
+    noise = np.random.default_rng(0).random((H, W, S), dtype=np.float32)
+    o, d, t = [x.cpu().numpy() for x in rg(c2w, noise=noise)]
+    eo, ed, et = O.generate_rays(c2w, F["focal_length"], W, H, F["near"], F["far"], S, noise)
+    np.testing.assert_array_equal(o, eo); np.testing.assert_allclose(d, ed, atol=2e-7); np.testing.assert_allclose(t, et, atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)            # rays.py:108-109
+    np.testing.assert_array_equal(o, np.broadcast_to(c2w[:3, 3], o.shape))            # rays.py:111-113

@@ -1,8 +1,8 @@
 """GPU parity of the training path (knerf_train_chunk / knerf_apply_adam) against the CPU oracle.
 
 Gradients: compared per tensor against the oracle in the kernels' arithmetic (emulate_bf16: bf16 matmul operands, fp32
-accumulate) to 4e-2 of the tensor's max |g|, and against the fp32 oracle (the reference's arithmetic) to 1e-1; the
-measured values are logged.  Adam: weights after several steps against the oracle's Keras-form Adam."""
+accumulate) to 2.5e-2 of the tensor's max |g|, and against the fp32 oracle (the reference's arithmetic) to 8e-2 (about
+twice the measured 1.1e-2 / 5e-2); the measured values are logged.  Adam: weights after several steps against the oracle's Keras-form Adam."""
 import numpy as np
 import pytest
 import torch
@@ -61,7 +61,7 @@ def test_train_chunk_gradients_and_losses():
              act=ctx.debug_buffer(0).cpu().numpy()[:2 * 158 * 1024], mask=ctx.debug_buffer(1).cpu().numpy()[:2 * 8 * 1024],
              dz=ctx.debug_buffer(2).cpu().numpy()[:2 * 156 * 1024],
              raw=ctx.debug_buffer(3).view(torch.float32).cpu().numpy()[:P["N"] * 192 * 4], t_fine=t_fine)
-    for emu, tol in ((True, 4e-2), (False, 1e-1)):
+    for emu, tol in ((True, 2.5e-2), (False, 8e-2)):
         rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=emu)
         rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=emu)
         ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
@@ -126,8 +126,8 @@ def test_adam_steps_follow_oracle():
         moved = np.abs(ref - init) > 1e-4
         agree = np.mean(np.sign(w - init)[moved] == np.sign(ref - init)[moved])
         log_stats("adam_direction_agreement", agree=agree, mean_abs_diff=np.abs(w - ref).mean(), mean_abs_move=np.abs(ref - init).mean())
-        assert agree > 0.97
-        assert np.abs(w - ref).mean() < 0.1 * np.abs(ref - init).mean()
+        assert agree > 0.995                                            # measured 0.9984 / 0.9999
+        assert np.abs(w - ref).mean() < 0.03 * np.abs(ref - init).mean()   # measured 0.2 % / 1.1 % of the movement
     # gradients were zeroed by apply_adam (nerf.py:464-471)
     assert float(ctx.grads_view().abs().max()) == 0.0
     ctx.close()
@@ -163,7 +163,7 @@ def test_ragged_chunk_training_matches_oracle():
     rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=True)
     ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
     log_stats("ragged_train_chunk", coarse_worst=ec[0], loss_c=abs(float(loss[0]) - float(lc)))
-    assert ec[0] < 4e-2, ec
+    assert ec[0] < 2.5e-2, ec
     assert abs(float(loss[0]) - float(lc)) < 2e-3
     ctx.close()
 
@@ -184,7 +184,7 @@ def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
     ci, cd, cw = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
     rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, white, emulate_bf16=True)
     np.testing.assert_allclose(ci, rc["image"], atol=1e-2); np.testing.assert_allclose(cw, rc["weights"], atol=1e-2)
-    if n_fine == 0:
+    if n_fine == 0:               # coarse-only TRAINING is covered by tests/test_gpu_configs.py
         ctx.close(); return
     loss = torch.zeros(2, device="cuda")
     ctx.train_chunk(o, d, t, img, u, loss=loss)
@@ -195,7 +195,7 @@ def test_other_sample_counts_backgrounds_and_oob(n_coarse, n_fine, white, oob):
     _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, white, emulate_bf16=True)
     ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
     log_stats(f"config_{n_coarse}_{n_fine}_{white}_{oob}", coarse_worst=ec[0], fine_worst=ef[0])
-    tol = 8e-2 if n_coarse == 2 else 5e-2       # 128 + 320 samples in all: the bf16 roundings do not average out
+    tol = 8e-2 if n_coarse == 2 else 2.5e-2     # 128 + 320 samples in all: the bf16 roundings do not average out (measured 5.4e-2)
     assert ec[0] < tol and ef[0] < tol, (ec, ef)
     assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
     ctx.close()

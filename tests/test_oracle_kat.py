@@ -155,3 +155,29 @@ def test_bf16_rounding():
     r = O.round_bf16(x)
     assert r[0] == 1.0 and r[1] == 1.0 and r[3] == pytest.approx(3.140625)
     assert O.round_bf16(np.array([1.0 + 3 * 2 ** -9], np.float32))[0] == np.float32(1.0 + 2 ** -7)  # ties-to-even up
+
+
+def test_lego_camera_fixture_of_the_reference_ray_test():
+    """tests/golden/lego_c2w.json holds the camera matrix and arguments of the reference's tests/data/test_rays.py:9-47; the
+    oracle's generate_rays (rays.py:69-130) under that test's own assertions (:50-87): finite, o/d deterministic, the
+    jittered t within [near - 4/32, far + 4/32] and within 4/32 of the previous draw."""
+    import json
+    import os
+    F = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lego_c2w.json")))
+    c2w = np.asarray(F["camera_to_world"], np.float32)
+    W, H, S = F["image_width"], F["image_height"], F["n_sample"]
+    rng = np.random.default_rng(0)
+    last = None
+    for _ in range(3):
+        o, d, t = O.generate_rays(c2w, F["focal_length"], W, H, F["near"], F["far"], S, rng.random((H, W, S)))
+        assert o.shape == (H, W, 3) and d.shape == (H, W, 3) and t.shape == (H, W, S)
+        assert o.dtype == np.float32 and d.dtype == np.float32 and t.dtype == np.float32
+        assert np.isfinite(o).all() and np.isfinite(d).all() and np.isfinite(t).all()
+        assert t.min() >= 2.0 - 4.0 / 32.0 and t.max() <= 6.0 + 4.0 / 32.0
+        if last is not None:
+            assert np.array_equal(last[0], o) and np.array_equal(last[1], d) and np.allclose(last[2], t, atol=4.0 / 32.0)
+        last = (o, d, t)
+    np.testing.assert_allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)
+    np.testing.assert_array_equal(o[5, 7], c2w[:3, 3])
+    # the centre pixel looks along -z of the camera frame (rays.py:82-113: x - W/2, -(y - H/2), -1)
+    np.testing.assert_allclose(d[H // 2, W // 2], -c2w[:3, 2] / np.linalg.norm(c2w[:3, 2]), atol=1e-6)
