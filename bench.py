@@ -58,31 +58,62 @@ def make_batch(nerf, wh, batch, rank, seed=42):
     return images, (o, d, t)
 
 
-def cpu_baseline(n_rays=512, chunk=256, repeats=3):
-    """op-for-op torch-CPU restatement of the reference train step (oracle/torch_ref.py) on a bounded sample"""
+def _cpu_problem(wh, n_images, n_rays=None):
+    from oracle import nerf_oracle as O
+    rng = np.random.default_rng(42)
+    focal = O.get_focal_from_fov(0.6911112070083618, wh)
+    os_, ds_, ts_ = [], [], []
+    for i in range(n_images):
+        o, d, t = O.generate_rays(O.pose_spherical(20.0 + 40.0 * i, -30.0, 4.0), focal, wh, wh, 2.0, 6.0, 64, rng.random((wh, wh, 64)))
+        os_.append(o.reshape(-1, 3)); ds_.append(d.reshape(-1, 3)); ts_.append(t.reshape(-1, 64))
+    o, d, t = [torch.tensor(np.concatenate(a)[:n_rays]) for a in (os_, ds_, ts_)]
+    n = o.shape[0]
+    img = torch.tensor(rng.random((n, 3), dtype=np.float32))
+    u = torch.tensor(np.random.default_rng(7).random((n, 128), dtype=np.float32))
+    return o, d, t, img, u
+
+
+def _time_cpu_steps(step, want, budget_s):
+    """1 warm-up, then up to `want` timed steps while the wall-clock budget lasts (at least 2)"""
+    t0 = time.perf_counter(); step(); first = time.perf_counter() - t0
+    times, spent = [], first
+    while len(times) < want and (len(times) < 2 or spent + (times[-1] if times else first) <= budget_s):
+        t0 = time.perf_counter(); step(); times.append(time.perf_counter() - t0); spent += times[-1]
+    return times
+
+
+def cpu_baseline(budget_s=70.0):
+    """The reference's TF-CPU path cannot run here (no TensorFlow): its op-for-op torch-CPU restatement
+    (oracle/torch_ref.py, autograd backward, Keras-form Adam; kind "port") is timed on this box's host cores, as SURVEY.md
+    section 8d prescribes: (1) BASELINE configs[0] exactly -- 64x64 image, 4 chunks of 1024 rays, coarse net only, 64 samples;
+    (2) a bounded sample of the benched workload's shape (cfg2: coarse64 + fine128, one chunk).  Median of up to 5 steps
+    after 1 warm-up inside a wall-clock budget; `cores` = torch threads actually used."""
     from oracle import nerf_oracle as O
     from oracle import torch_ref as T
     cfg = O.NerfConfig()
-    rng = np.random.default_rng(42)
-    wh = 32
-    c2w = O.pose_spherical(20.0, -30.0, 4.0)
-    o, d, t = O.generate_rays(c2w, O.get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, 64, rng.random((wh, wh, 64)))
-    o, d, t = [torch.tensor(a.reshape(wh * wh, -1)[:n_rays]) for a in (o, d, t)]
-    img = torch.tensor(rng.random((n_rays, 3), dtype=np.float32))
-    u = torch.tensor(np.random.default_rng(7).random((n_rays, 128), dtype=np.float32))
-    cp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 0)]
-    fp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 1)]
-    oc, of_ = T.TorchKerasAdam(cp), T.TorchKerasAdam(fp)
-    times = []
-    for i in range(repeats + 1):
-        t0 = time.perf_counter()
-        T.train_step(cp, fp, oc, of_, img, o, d, t, u, cfg, chunk, False)
-        times.append(time.perf_counter() - t0)
-    med = statistics.median(times[1:])
-    return {"value": n_rays * 256 / med, "unit": "rays*samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays x 256 samples, ray_chunks {chunk}, coarse64+fine128 train step, median of {repeats} "
-                      f"after 1 warm-up; torch-CPU fp32 restatement of the reference's TF-CPU path ({os.cpu_count()} host cpus)",
-            "s_per_step": med}
+    threads = torch.get_num_threads()
+
+    def fresh():
+        cp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 0)]
+        fp = [torch.tensor(p, requires_grad=True) for p in O.init_params(cfg, 1)]
+        return cp, fp, T.TorchKerasAdam(cp), T.TorchKerasAdam(fp)
+    # (2) cfg2-shaped sample: 256 rays x (64 + 192) samples, one chunk
+    o, d, t, img, u = _cpu_problem(16, 1)
+    cp, fp, oc, of_ = fresh()
+    t2 = _time_cpu_steps(lambda: T.train_step(cp, fp, oc, of_, img, o, d, t, u, cfg, 256, False), 5, 0.35 * budget_s)
+    med2 = statistics.median(t2)
+    # (1) cfg1 exactly
+    o, d, t, img, u = _cpu_problem(64, 1)
+    cp, fp, oc, of_ = fresh()
+    t1 = _time_cpu_steps(lambda: T.train_step(cp, fp, oc, of_, img, o, d, t, u, cfg, 1024, False, coarse_only=True), 5, 0.65 * budget_s)
+    med1 = statistics.median(t1)
+    return {"value": 256 * 256 / med2, "unit": "rays*samples/s", "cores": threads, "kind": "port",
+            "sample": f"cfg2-shaped: 256 rays x 256 samples (coarse64 + fine128), one chunk, full train step; median of {len(t2)} after "
+                      f"1 warm-up; torch-CPU fp32 restatement of the reference's TF-CPU path, {threads} threads on {os.cpu_count()} host cpus",
+            "s_per_step": med2, "steps_timed": len(t2),
+            "cfg1": {"value": 4096 * 64 / med1, "unit": "rays*samples/s", "s_per_step": med1, "steps_timed": len(t1),
+                     "sample": "BASELINE configs[0] exactly: 64x64 image, batch 1, ray_chunks 1024 (4 chunks), coarse net only "
+                               "(64 samples), forward + backward + Adam"}}
 
 
 def sync(world):
@@ -92,15 +123,28 @@ def sync(world):
         torch.cuda.synchronize()
 
 
+RANK_ELAPSED = []      # fastest and slowest rank's elapsed time of the last timed region (filled by max_over_ranks)
+
+
 def max_over_ranks(elapsed, world):
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
+    RANK_ELAPSED[:] = [elapsed]
+    if world > 1:          # all_reduce is the one collective both RCCL and gloo run on device tensors
+        hi = torch.tensor([elapsed], device="cuda", dtype=torch.float64); lo = hi.clone()
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        RANK_ELAPSED[:] = [float(lo[0]), float(hi[0])]
+        elapsed = float(hi[0])
     return elapsed
 
 
-def bench_render(args, world, rank, wh, chunks, desc):
+def dist_fields(world, backend, steps):
+    per = [e / steps * 1e3 for e in RANK_ELAPSED]
+    return {"rccl_ranks": torch.distributed.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
+            "dist_backend": backend if world > 1 else None,
+            "ms_per_step_rank_min": min(per), "ms_per_step_rank_max": max(per)}
+
+
+def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
     """cfg5: frames/s of the 360-degree render loop of the reference's inference.py:62-114 (theta sweep at phi=-30,
     radius 4; rays generated on the device; fine image + depth copied to the host per frame as the reference does)."""
     from keras_nerf_amd.data.rays import RaysGenerator
@@ -144,27 +188,57 @@ def bench_render(args, world, rank, wh, chunks, desc):
                           "ms_per_step": elapsed / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
                           "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}"},
-                          "roofline": roofline, "cpu_baseline": None}), flush=True)
+                          "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}), flush=True)
+
+
+# per 32-sample tile, KiB (csrc/layout.h): saved activations, dZ, relu masks; wgrad re-reads the 4 enc blocks for layer_5
+ACT_KIB, DZ_KIB, MASK_KIB, WGRAD_REREAD_KIB = 158, 156, 8, 4
+LAYOUT_TAG = f"act{ACT_KIB}_dz{DZ_KIB}"
+WGRAD_KIB_PER_TILE = ACT_KIB + DZ_KIB + WGRAD_REREAD_KIB
+# whole step, per 32-sample tile: fwd writes act + masks, dgrad reads masks + raw/draw and writes dZ, wgrad reads act + dZ;
+# raw/draw/t: 32 samples x (16 B written + 16 B read) x 2 + t
+STEP_KIB_PER_TILE = 2 * (ACT_KIB + DZ_KIB + MASK_KIB) + WGRAD_REREAD_KIB + 2.5
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc*.json, produced by tools/pmc.sh +
-    tools/pmc_report.py: separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
-    reads on gfx950, WRITE_SIZE as is, both in KiB).  None when no summary is committed for this kernel."""
+    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary of THIS data layout
+    (profiles/*pmc_traffic*.json, produced by tools/pmc.sh + tools/pmc_report.py on the GPU box: separate rocprofv3 --pmc
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is, both
+    in KiB).  Counters cannot be read from inside the benched process, so the line names its source; (None, None) when no
+    summary of this layout is committed."""
     import glob
     name = {"wgrad_fine": ("wgrad_kernel", max), "wgrad_coarse": ("wgrad_kernel", min), "mlp_fwd_fine": ("mlp_fwd_kernel<true", max),
             "mlp_fwd_coarse": ("mlp_fwd_kernel<true", min), "mlp_bwd_fine": ("mlp_bwd_kernel", max),
             "mlp_bwd_coarse": ("mlp_bwd_kernel", min)}.get(kernel)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
-    if not name or not files:
-        return None
-    rep = json.load(open(files[-1]))
-    rows = [v for k, v in rep.items() if k.startswith(name[0]) and "hbm_bytes_per_launch" in v]
-    if not rows:
-        return None
-    if name[1] is max:
-        return max(r["hbm_bytes_per_launch"] for r in rows)
-    return min(r["hbm_bytes_per_launch_min"] for r in rows)
+    if not name:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        rep = json.load(open(f))
+        if rep.get("_layout", "act158_dz156") != LAYOUT_TAG:
+            continue
+        rows = [v for k, v in rep.items() if k.startswith(name[0]) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+        if not rows:
+            continue
+        val = max(r["hbm_bytes_per_launch"] for r in rows) if name[1] is max else min(r["hbm_bytes_per_launch_min"] for r in rows)
+        return val, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def spawn_ranks(args, backend, n_dev):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1), wait, exit with their code.  Rank 0's JSON line goes to the inherited stdout.  The parent has
+    not initialised HIP and replaces no process (children, not exec)."""
+    import socket
+    import subprocess
+    if backend == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
+                         f"(KNERF_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -177,14 +251,19 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
+    # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()          # counts devices without initialising the GPU
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, backend, n_dev)      # never returns; nothing in this process has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
-    backend = os.environ.get("KNERF_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py either plainly (it spawns its own ranks) or "
+                         f"under torch.distributed.run with --nproc-per-node {args.gpus}")
     if world > 1 and backend == "nccl" and local_rank >= n_dev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible (RCCL needs one GPU per rank)")
     device_index = local_rank % max(n_dev, 1)
@@ -199,7 +278,7 @@ def main():
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
     if args.config == "cfg5":
-        bench_render(args, world, rank, wh, chunks, desc)
+        bench_render(args, world, rank, wh, chunks, desc, backend)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -239,23 +318,23 @@ def main():
         s_fine, s_coarse = chunks * (nerf.n_coarse + nerf.n_fine), chunks * nerf.n_coarse
         per_launch_samples = s_coarse if dom.endswith("coarse") else s_fine
         flop = {"mlp_fwd": FWD_FLOP, "mlp_bwd": DGRAD_FLOP, "wgrad": WGRAD_FLOP}.get(dom.rsplit("_", 1)[0], 0) * per_launch_samples
-        # wgrad streams the saved activations and dZ once: (158 + 156) KiB per 32-sample tile + 4 KiB re-read of enc
+        # wgrad streams the saved activations and dZ once (+ the re-read of enc for layer_5)
         if dom.startswith("wgrad"):
-            byts = per_launch_samples / 32 * 318 * 1024
+            byts = per_launch_samples / 32 * WGRAD_KIB_PER_TILE * 1024
             roofline = {"bound": "hbm", "kernel": dom, "achieved": byts / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": byts / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
         else:
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flop / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flop / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None}
-        roofline["traffic"] = pmc_traffic(dom)
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom)
         roofline["avg_launch_ms"] = avg_ms
         roofline["launches"] = cnt
         roofline["kernel_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof.items()}
         roofline["step_train_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP / (elapsed / args.steps) / 1e12
         roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
-        # whole-step HBM view: per 32-sample tile the step writes 158 KiB of activations, 8 KiB of relu
-        # masks and 156 KiB of dZ and reads 162 + 8 + 156 KiB of them back (wgrad, dgrad), plus raw/draw: 650.5 KiB
-        step_bytes = n_rays * samples_per_ray / 32 * 650.5 * 1024
+        # whole-step HBM view: saved activations, relu masks and dZ written once and read back once
+        step_bytes = n_rays * samples_per_ray / 32 * STEP_KIB_PER_TILE * 1024
+        roofline["bytes_per_ray_sample"] = STEP_KIB_PER_TILE * 1024 / 32
         roofline["step_algorithmic_gbytes"] = step_bytes / 1e9
         roofline["step_frac_of_hbm_peak"] = step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
 
@@ -272,7 +351,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

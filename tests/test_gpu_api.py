@@ -272,3 +272,25 @@ def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     assert np.mean(np.sign(w - a["w_start"])[moved] == np.sign(a["w_end"] - a["w_start"])[moved]) > 0.999
     np.testing.assert_allclose(w, a["w_end"], atol=2e-5)                      # fp32 atomics: summation order only
     ctx.close()
+
+
+def test_bench_spawns_its_own_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes before touching HIP and rank 0's
+    line says n_gpus 2.  On this one-GPU box the ranks share the device over gloo (KNERF_DIST_BACKEND=gloo); with the default
+    backend the same command must refuse (RCCL needs one GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNERF_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "cfg4",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(base, KNERF_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and line["dist_backend"] == "gloo"
+    assert line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert line["ms_per_step_rank_min"] <= line["ms_per_step_rank_max"] <= line["ms_per_step"] * 1.0001
+    if torch.cuda.device_count() < 2:
+        r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=base)
+        assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr

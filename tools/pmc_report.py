@@ -2,6 +2,7 @@
 """Aggregates rocprofv3 --pmc CSVs (tools/pmc.sh) per kernel: mean counter value per dispatch."""
 import csv, glob, json, sys, collections
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+layout = sys.argv[2] if len(sys.argv) > 2 else None      # bench.py LAYOUT_TAG of the build that was profiled
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -11,6 +12,8 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         grid = int(r.get("Grid_Size", 0) or 0)
         agg[(k, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rep = {}
+if layout:
+    rep["_layout"] = layout
 for (k, grid), cs in sorted(agg.items()):
     rep[f"{k} grid={grid}"] = {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())}
     row = rep[f"{k} grid={grid}"]
