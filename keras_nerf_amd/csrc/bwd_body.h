@@ -2,8 +2,9 @@
 //
 // Backward of NeRFMLP.call (reference keras_nerf/model/nerf/mlp.py:29-50) as TensorFlow's tape computes it at
 // nerf.py:376-377 / 405-406, restricted to what the weight gradients need (no gradient flows to the inputs):
-//   dz_rgb = drgb * rgb(1-rgb);  df2 = W_rgb dz_rgb;  dfeat = W_rf[:256] df2;  dz_sig = dsigma * [sigma>0];
-//   dh7 = W_f dfeat + w_s dz_sig;  dz_l = dh_l * [h_l > 0];  dh_{l-1} = W_l dz_l  (layer_5: rows 0..255 only).
+//   dz_rgb = drgb * rgb(1-rgb);  dz_sig = dsigma * [sigma>0];  dh7 = H [dz_rgb ; dz_sig]  with the composed head matrix
+//   H = [W_f W_r1 W_c | w_s] (layout.h "collapsed head": the same product W_f (W_r1 (W_c dz_rgb)) + w_s dz_sig the tape forms);
+//   dz_l = dh_l * [h_l > 0];  dh_{l-1} = W_l dz_l  (layer_5: rows 0..255 only).
 // Same register-resident structure as the forward chain (chain.h) with A = W instead of W^T.  Every dZ is written
 // as B-operand blocks (layout.h "dz run") for the wgrad kernel; ReLU masks come from the forward pass.
 #pragma once
@@ -13,16 +14,15 @@
 
 namespace knerf {
 
-// store schedule: 2 dZ blocks per out tile of every stage (the dz_rgb / dz_sigma blocks are stored BEFORE the ring's
-// prologue, i.e. they are older than every LDS-DMA and never counted)
-constexpr StoreSched<10> kBwdStores = {{{0, 1, 4, 2, 0, 0}, {4, 8, 8, 2, 0, 0}, {68, 17, 8, 2, 0, 0}, {204, 16, 8, 2, 0, 0},
-                                        {332, 16, 8, 2, 0, 0}, {460, 16, 8, 2, 0, 0}, {588, 16, 8, 2, 0, 0}, {716, 16, 8, 2, 0, 0},
-                                        {844, 16, 8, 2, 0, 0}, {972, 16, 8, 2, 0, 0}}, 0};
+// store schedule: 2 dZ blocks per out tile of every stage (the dz_head block is stored BEFORE the ring's prologue, i.e. it
+// is older than every LDS-DMA and never counted)
+constexpr StoreSched<8> kBwdStores = {{{0, 1, 8, 2, 0, 0}, {8, 16, 8, 2, 0, 0}, {136, 16, 8, 2, 0, 0}, {264, 16, 8, 2, 0, 0},
+                                       {392, 16, 8, 2, 0, 0}, {520, 16, 8, 2, 0, 0}, {648, 16, 8, 2, 0, 0}, {776, 16, 8, 2, 0, 0}}, 0};
 #ifdef KNERF_CONSERVATIVE_WAIT
 constexpr StoreSched<1> kNoStoresB = {{{0, 1, 0, 0, 0, 0}}, 0};
 struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<1, kBwdBlocks>(kNoStoresB); };
 #else
-struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<10, kBwdBlocks>(kBwdStores); };
+struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<8, kBwdBlocks>(kBwdStores); };
 #endif
 
 // dgrad chain of the 8 sample tiles (8 waves x 32 samples) of workgroup tile `wg_tile`
@@ -49,20 +49,19 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
 #pragma unroll
     for (int l = 0; l < 8; ++l) asm volatile("" ::"v"(mk[l]));   // pin the waits here, not inside the pipelined loop
 
-    bf16x8 zrgb, zsig;
+    bf16x8 zhead;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { zrgb[j] = (__bf16)0.f; zsig[j] = (__bf16)0.f; }
+    for (int j = 0; j < 8; ++j) zhead[j] = (__bf16)0.f;
     if (h == 0) {
-        zrgb[0] = (__bf16)(dr[0] * raw[0] * (1.f - raw[0]));
-        zrgb[1] = (__bf16)(dr[1] * raw[1] * (1.f - raw[1]));
-        zrgb[2] = (__bf16)(dr[2] * raw[2] * (1.f - raw[2]));
-        zsig[0] = (__bf16)(raw[3] > 0.f ? dr[3] : 0.f);
+        zhead[0] = (__bf16)(dr[0] * raw[0] * (1.f - raw[0]));
+        zhead[1] = (__bf16)(dr[1] * raw[1] * (1.f - raw[1]));
+        zhead[2] = (__bf16)(dr[2] * raw[2] * (1.f - raw[2]));
+        zhead[3] = (__bf16)(raw[3] > 0.f ? dr[3] : 0.f);
     }
     char* dz = a.dz + (size_t)tile * kDzTileBytes;
-    store_block(dz, kDzRgb, lane, zrgb);     // blocks kDzRgb+1 / kDzSig+1 stay zero (buffer is zero-initialised)
-    store_block(dz, kDzSig, lane, zsig);
+    store_block(dz, kDzHead, lane, zhead);     // block kDzHead+1 stays zero (the buffer is zero-initialised)
 
-    asm volatile("" ::: "memory");            // the two stores above stay ahead of the first LDS-DMA in program order
+    asm volatile("" ::: "memory");            // the store above stays ahead of the first LDS-DMA in program order
     Ring ring{a.stream, smem, tid, wave};
     ring.prologue_issue();
     ring.prologue_wait();
@@ -70,21 +69,8 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
     pf.start<kBwdBlocks>(ring, lane);
     BwdWait waits;
 
-    bf16x8 x[17], y[16];
+    bf16x8 x[16], y[16];
     auto zero_init = [](int) { return zero_acc(); };
-    // B0: dz_rgb -> df2 (4 tiles = 8 k-steps), kept in y[0..7]
-    dense_stage<0, 1, 4, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zrgb; }, [&](int ot, f32x16 acc) {
-        pack_acc(acc, y[2 * ot], y[2 * ot + 1]);
-        store_block(dz, kDzF2 + 2 * ot, lane, y[2 * ot]);
-        store_block(dz, kDzF2 + 2 * ot + 1, lane, y[2 * ot + 1]);
-    });
-    // B1: df2 -> dfeat (8 tiles), kept in x[0..15]; x[16] = dz_sigma
-    dense_stage<4, 8, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, [&](int ot, f32x16 acc) {
-        pack_acc(acc, x[2 * ot], x[2 * ot + 1]);
-        store_block(dz, kDzFeat + 2 * ot, lane, x[2 * ot]);
-        store_block(dz, kDzFeat + 2 * ot + 1, lane, x[2 * ot + 1]);
-    });
-    x[16] = zsig;
     // masked epilogue: dz_l = dh_l * [h_l > 0], applied to the packed bf16 pairs with the forward's bit mask
     // (tile ot -> word ot>>1, byte lane ot&1; chain.h relu_mask_bits / apply_mask_packed)
     auto mask_epi = [&](auto& out, int layer) {
@@ -97,16 +83,16 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
             store_block(dz, 16 * layer + 2 * ot + 1, lane, out[2 * ot + 1]);
         };
     };
-    // B2: [dfeat ; dz_sigma] -> dh7 -> dz7 (y)
-    dense_stage<68, 17, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 7));
-    // B3..B9: dz_l -> dz_{l-1}
-    dense_stage<204, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 6));
-    dense_stage<332, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 5));
-    dense_stage<460, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 4));
-    dense_stage<588, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 3));
-    dense_stage<716, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 2));
-    dense_stage<844, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 1));
-    dense_stage<972, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 0));
+    // B0: dz_head (r, g, b, sigma) -> dh7 -> dz7 (y)
+    dense_stage<0, 1, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zhead; }, mask_epi(y, 7));
+    // B1..B7: dz_l -> dz_{l-1}
+    dense_stage<8, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 6));
+    dense_stage<136, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 5));
+    dense_stage<264, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 4));
+    dense_stage<392, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 3));
+    dense_stage<520, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 2));
+    dense_stage<648, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 1));
+    dense_stage<776, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 0));
     ring_finish<kBwdBlocks>(ring, grp);
 }
 

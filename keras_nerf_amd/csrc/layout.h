@@ -43,6 +43,25 @@ inline std::vector<TensorInfo> tensor_table() {
 constexpr int kParamCount = 595844;
 enum Layer { L0 = 0, L1, L2, L3, L4, L5, L6, L7, LSIG, LFEAT, LRF, LRGB };
 
+// ---- collapsed head ------------------------------------------------------------------------------------------------
+// In this reference `features` and `rgb_features` are LINEAR Dense layers (mlp.py:21-24,44-46: no activation argument), so
+// everything between the trunk output h7 and the sigmoid is one affine map of (h7, dir_enc):
+//   rgb_pre = h7 (W_f W_r1 W_c) + dir_enc (W_r2 W_c) + ((b_f W_r1 + b_r) W_c + b_c),   sigma_pre = h7 w_s + b_s
+// (W_r1 = rows 0..255 of the rgb_features kernel, W_r2 = its 27 dir rows).  The kernels evaluate that map as ONE out tile
+// with 4 real rows (r, g, b, sigma) instead of three dense stages (144 + 72 + 8 MFMAs per 32 samples -> 18), and its
+// backward as one 4-channel dZ.  The 283x4 "head" matrix H and its bias are derived from the fp32 master weights after
+// every weight change (optim.hip head_compose) and live behind the 595,844 parameters in the same buffer, so the packing
+// tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
+// the same identity) from M = [h7 ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
+// in an auxiliary buffer (optim.hip head_expand).
+constexpr int kHeadRows = 288;                       // 256 h7 features + 32 dir slots (27 real)
+constexpr int kHeadOff = kParamCount;                // H[row][c], c = 0..2 rgb, 3 sigma
+constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
+constexpr int kExtParamCount = kHeadBiasOff + 4;     // floats in a net's weight buffer
+// auxiliary gradient buffer of one net: M[row][c] (row = 0..255 h7, 256..282 dir; c = 0..2), then s[c]
+constexpr int kAuxM = 0, kAuxS = 283 * 3, kAuxCount = 864;
+constexpr int kAuxBase = kParamCount;                // wgrad destination indices >= kAuxBase address the aux buffer
+
 // ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
 // encoded position: 64 slots (4 k-steps).  half 0: x, y, sin(2^i p_c);  half 1: z, pad, cos(2^i p_c).
 inline int enc_feature(int q, int h, int j, int L) {
@@ -77,18 +96,25 @@ inline int bidx(const std::vector<TensorInfo>& tt, int layer, int out_col) {
 }
 
 // =====================================================================================================
-// forward stream: 1184 blocks of 1 KiB (64 lanes x 8 bf16).  Order: stage, out tile, k-step.
-// stage list: L0 | L1..L4 | L5 (16 hidden + 4 enc k-steps) | L6 L7 | FS = features(8 tiles)+sigma(1 tile) |
-//             RF = rgb_features (16 feat + 2 dir k-steps, 4 tiles) | RGB (8 k-steps, 1 tile)
+// forward stream: 978 blocks of 1 KiB (64 lanes x 8 bf16).  Order: stage, out tile, k-step.
+// stage list: L0 | L1..L4 | L5 (16 hidden + 4 enc k-steps) | L6 L7 | HEAD (16 h7 + 2 dir k-steps, 1 tile: rows r,g,b,sigma)
 // =====================================================================================================
-constexpr int kFwdBlocks = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184
-constexpr int kFwdBiasTiles = 8 * 8 + 9 + 4 + 1;                            // 78 tiles of 32 fp32
+constexpr int kFwdBlocks = 32 + 4 * 128 + 160 + 2 * 128 + 18;   // 978
+constexpr int kFwdBiasTiles = 8 * 8 + 1;                         // 65 tiles of 32 fp32
 
 struct PackTables {
-    std::vector<int32_t> fwd;       // kFwdBlocks*512 entries: param index or -1
+    std::vector<int32_t> fwd;       // kFwdBlocks*512 entries: index into the extended weight buffer or -1
     std::vector<int32_t> fwd_bias;  // kFwdBiasTiles*32
     std::vector<int32_t> bwd;       // kBwdBlocks*512
 };
+
+// row of the head matrix for k-step ks of the HEAD stage: h7 features, then the dir encoding slots
+inline int head_in_row(int ks, int h, int j) {
+    if (ks < 16) return hid_feature(ks, h, j);
+    const int e = enc_feature(ks - 16, h, j, kLd);
+    return e < 0 ? -1 : 256 + e;
+}
+inline int hidx(int row, int c) { return (row < 0 || row >= 283 || c < 0 || c > 3) ? -1 : kHeadOff + row * 4 + c; }
 
 // input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
 inline int fwd_in_row(int st, int ks, int h, int j) {
@@ -96,24 +122,21 @@ inline int fwd_in_row(int st, int ks, int h, int j) {
         case 0: return enc_feature(ks, h, j, kLx);                       // layer_0: 63 inputs in 4 k-steps
         case 5: return ks < 16 ? hid_feature(ks, h, j)                   // layer_5: [h(256), xyz_enc(63)] (mlp.py:36-38)
                                : (enc_feature(ks - 16, h, j, kLx) < 0 ? -1 : 256 + enc_feature(ks - 16, h, j, kLx));
-        case 9: return ks < 16 ? hid_feature(ks, h, j)                   // rgb_features: [features(256), dir_enc(27)]
-                               : (enc_feature(ks - 16, h, j, kLd) < 0 ? -1 : 256 + enc_feature(ks - 16, h, j, kLd));
-        default: return hid_feature(ks, h, j);                           // 256-wide (RGB stage: 128-wide, 8 k-steps)
+        case 8: return head_in_row(ks, h, j);
+        default: return hid_feature(ks, h, j);                           // 256-wide
     }
 }
 struct FwdStage { int layer; int nks; int n_ot; };
-// stage index: 0..7 trunk, 8 = FS, 9 = RF, 10 = RGB
+// stage index: 0..7 trunk, 8 = HEAD (layer = -1: addresses the head matrix)
 inline FwdStage fwd_stage(int st) {
     switch (st) {
         case 0: return {L0, 4, 8};
         case 5: return {L5, 20, 8};
-        case 8: return {LFEAT, 16, 9};
-        case 9: return {LRF, 18, 4};
-        case 10: return {LRGB, 8, 1};
+        case 8: return {-1, 18, 1};
         default: return {st, 16, 8};
     }
 }
-constexpr int kFwdStages = 11;
+constexpr int kFwdStages = 9;
 
 inline void build_fwd(PackTables& pt) {
     auto tt = tensor_table();
@@ -123,20 +146,15 @@ inline void build_fwd(PackTables& pt) {
     for (int st = 0; st < kFwdStages; ++st) {
         FwdStage s = fwd_stage(st);
         for (int ot = 0; ot < s.n_ot; ++ot) {
-            for (int r = 0; r < 32; ++r) {
-                int layer = s.layer, col = 32 * ot + r;
-                if (st == 8 && ot == 8) { layer = LSIG; col = r; }       // sigma head rides as the 9th tile (row 0 real)
-                pt.fwd_bias[(size_t)btile * 32 + r] = bidx(tt, layer, col);
-            }
+            for (int r = 0; r < 32; ++r)
+                pt.fwd_bias[(size_t)btile * 32 + r] = s.layer < 0 ? (r < 4 ? kHeadBiasOff + r : -1) : bidx(tt, s.layer, 32 * ot + r);
             ++btile;
             for (int ks = 0; ks < s.nks; ++ks, ++blk) {
                 for (int l = 0; l < 64; ++l) {
                     int r = l & 31, h = l >> 5;
-                    for (int j = 0; j < 8; ++j) {
-                        int layer = s.layer, col = 32 * ot + r;
-                        if (st == 8 && ot == 8) { layer = LSIG; col = r; }
-                        pt.fwd[blk * 512 + l * 8 + j] = kidx(tt, layer, fwd_in_row(st, ks, h, j), col);
-                    }
+                    for (int j = 0; j < 8; ++j)
+                        pt.fwd[blk * 512 + l * 8 + j] = s.layer < 0 ? hidx(fwd_in_row(st, ks, h, j), r)
+                                                                     : kidx(tt, s.layer, fwd_in_row(st, ks, h, j), 32 * ot + r);
                 }
             }
         }
@@ -146,22 +164,13 @@ inline void build_fwd(PackTables& pt) {
 // =====================================================================================================
 // backward (dgrad) stream: A = W (rows = the layer's INPUT features, k = its OUTPUT features).
 // stage order (reverse of forward):
-//   B0: dz_rgb (1 k-step: channels at half 0, j<3)      -> df2   (4 tiles)    W_rgb[f2][c]
-//   B1: df2 (8 k-steps)                                 -> dfeat (8 tiles)    W_rf[feat][f2]   (dir rows unused)
-//   B2: dfeat (16) + dz_sigma (1 k-step: half 0, j=0)   -> dh7   (8 tiles)    W_f[h][feat], w_s[h][0]
-//   B3..B9: dz_l (16) -> dh_{l-1} (8 tiles) for l = 7,6,5,4,3,2,1   (layer 5: rows 0..255 of its 319)
+//   B0: dz_head (1 k-step: channels r,g,b,sigma at half 0, j<4) -> dh7 (8 tiles)    H[h7 feature][channel]
+//   B1..B7: dz_l (16) -> dh_{l-1} (8 tiles) for l = 7,6,5,4,3,2,1   (layer 5: rows 0..255 of its 319)
 // =====================================================================================================
-constexpr int kBwdBlocks = 4 + 64 + 8 * 17 + 7 * 128;   // 1100
-constexpr int kBwdStages = 10;
+constexpr int kBwdBlocks = 8 + 7 * 128;   // 904
+constexpr int kBwdStages = 8;
 struct BwdStage { int nks; int n_ot; };
-inline BwdStage bwd_stage(int st) {
-    switch (st) {
-        case 0: return {1, 4};
-        case 1: return {8, 8};
-        case 2: return {17, 8};
-        default: return {16, 8};
-    }
-}
+inline BwdStage bwd_stage(int st) { return st == 0 ? BwdStage{1, 8} : BwdStage{16, 8}; }
 inline void build_bwd(PackTables& pt) {
     auto tt = tensor_table();
     pt.bwd.assign((size_t)kBwdBlocks * 512, -1);
@@ -174,11 +183,8 @@ inline void build_bwd(PackTables& pt) {
                     int r = l & 31, h = l >> 5, row = 32 * ot + r;   // row = input feature of the layer
                     for (int j = 0; j < 8; ++j) {
                         int v = -1;
-                        if (st == 0) { int c = 8 * h + j; v = kidx(tt, LRGB, row, c < 3 ? c : -1); }
-                        else if (st == 1) v = kidx(tt, LRF, row, hid_feature(ks, h, j) < 128 ? hid_feature(ks, h, j) : -1);
-                        else if (st == 2) v = ks < 16 ? kidx(tt, LFEAT, row, hid_feature(ks, h, j))
-                                                      : kidx(tt, LSIG, row, (h == 0 && j == 0) ? 0 : -1);
-                        else v = kidx(tt, L7 - (st - 3), row, hid_feature(ks, h, j));
+                        if (st == 0) v = hidx(row, h == 0 && j < 4 ? j : -1);
+                        else v = kidx(tt, L7 - (st - 1), row, hid_feature(ks, h, j));
                         pt.bwd[blk * 512 + l * 8 + j] = v;
                     }
                 }
@@ -190,15 +196,14 @@ inline void build_bwd(PackTables& pt) {
 // stores its 8 bf16 at byte offset saved_off(b, h, s) = (2*(s ^ 4*(b&1)) + h) * 16: the two feature halves of a
 // sample are adjacent (32 B per sample) and odd blocks rotate their sample quads, which makes the wgrad kernel's
 // ds_read_b64_tr_b16 transposed reads bank-conflict free while the store stays one coalesced 1 KiB write.
-// forward "act" run (158 blocks):  h0 h1 h2 h3 h4 enc h5 h6 h7 feat dir f2
-// backward "dz" run  (156 blocks): dz0 .. dz7  dfeat dzsig(2) df2 dzrgb(2)
-// so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5.
+// forward "act" run (134 blocks):  h0 h1 h2 h3 h4 enc h5 h6 h7 dir
+// backward "dz" run  (130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero)
+// so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5, head: act[h7..dir] x dz_head.
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
-constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, kActFeat = 132, kActDir = 148,
-              kActF2 = 150, kActBlocks = 158;
+constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, kActDir = 132, kActBlocks = 134;
 constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
-constexpr int kDzFeat = 128, kDzSig = 144, kDzF2 = 146, kDzRgb = 154, kDzBlocks = 156;
+constexpr int kDzHead = 128, kDzBlocks = 130;
 constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
 // Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
 // own tile at about the same time, so a stride that is a large power of two times a small odd number (156 KiB =
@@ -214,18 +219,15 @@ constexpr size_t kMaskTileBytes = (size_t)kMaskBlocks * 1024 + KNERF_TILE_SKEW;
 struct WgradJob {
     int act_blk, n_it;    // first act block, number of 32-row input tiles (2 blocks each)
     int dz_blk, n_ot;     // first dz block, number of 32-col output tiles
-    int layer;            // destination kernel/bias (FS job also writes LSIG from its 9th tile)
+    int layer;            // destination kernel/bias; -1: the head job (sigma column -> LSIG, rgb columns -> aux buffer)
 };
-constexpr int kWgradJobs = 13;
+constexpr int kWgradJobs = 9;
+constexpr int kHeadJob = 8;
 inline WgradJob wgrad_job(int j) {
     switch (j) {
         case 0: return {kActEnc, 2, 0, 8, L0};
         case 5: return {kActH4, 10, 16 * 5, 8, L5};             // [h4 ; enc]
-        case 8: return {kActH7, 8, kDzFeat, 8, LFEAT};
-        case 9: return {kActH7, 8, kDzSig, 1, LSIG};
-        case 10: return {kActFeat, 9, kDzF2, 4, LRF};           // [feat ; dir]
-        case 11: return {kActF2, 4, kDzRgb, 1, LRGB};
-        case 12: return {0, 0, 0, 0, -1};
+        case 8: return {kActH7, 9, kDzHead, 1, -1};             // [h7 ; dir] x (r,g,b,sigma)
         default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 1-4, 6, 7
     }
 }
@@ -239,17 +241,24 @@ inline int wgrad_in_row(int jb, int tr) {
     switch (jb) {
         case 0: return encrow(tr, kLx);
         case 5: return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
-        case 10: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
-        case 11: return tr < 128 ? tr : -1;
+        case 8: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
         default: return tr;
     }
 }
-// destination (param index) of wgrad output element; in_row == -2 selects the bias row
+// destination of wgrad output element (tile-row tr, column tc): index into the flat gradient, kAuxBase + index into the
+// aux buffer, or -1; tr == -2 selects the bias row (column sums of dz)
 inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) {
     WgradJob J = wgrad_job(jb);
-    int layer = J.layer, col = tc;
-    if (tr == -2) return bidx(tt, layer, col);
-    return kidx(tt, layer, wgrad_in_row(jb, tr), col);
+    if (J.layer < 0) {                       // head: columns 0..2 = dz_rgb, 3 = dz_sigma
+        if (tc > 3) return -1;
+        if (tr == -2) return tc == 3 ? bidx(tt, LSIG, 0) : kAuxBase + kAuxS + tc;
+        const int row = wgrad_in_row(jb, tr);
+        if (row < 0) return -1;
+        if (tc == 3) return row < 256 ? kidx(tt, LSIG, row, 0) : -1;
+        return kAuxBase + kAuxM + row * 3 + tc;
+    }
+    if (tr == -2) return bidx(tt, J.layer, tc);
+    return kidx(tt, J.layer, wgrad_in_row(jb, tr), tc);
 }
 
 }  // namespace knerf

@@ -1,10 +1,11 @@
-// mlp_fwd.hip -- fused positional encoding + 8x256 ReLU trunk + sigma / rgb heads for one NeRF MLP (gfx950).
+// mlp_fwd.hip -- fused positional encoding + 8x256 ReLU trunk + collapsed sigma / rgb head for one NeRF MLP (gfx950).
 //
 // Replaces, per sample: NeRFUtils.encode_position_and_directions (reference keras_nerf/model/nerf/utils.py:188-210),
 // NeRFUtils.positional_encoding (utils.py:176-186) and NeRFMLP.call (mlp.py:29-50).
 // Input: ray origins/directions [R,3] and t-values [R,S] (fp32).  Output: raw[R*S] = (r,g,b,sigma) fp32 after
-// sigmoid / relu.  SAVE additionally writes every layer's bf16 activations (B-operand blocks, layout.h) and the
-// ReLU masks for the backward kernels.
+// sigmoid / relu.  SAVE additionally writes every trunk layer's bf16 activations (B-operand blocks, layout.h) and the
+// ReLU masks for the backward kernels.  The three linear layers behind the trunk (features, rgb_features, rgb; mlp.py:44-48)
+// and the sigma head are evaluated as ONE 4-row stage on the composed matrix (layout.h "collapsed head").
 #include "chain.h"
 #include "kernels.h"
 #include "layout.h"
@@ -48,13 +49,13 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
 }
 
-// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile, one mask block per trunk layer,
-// the 2 dir blocks after the features stage
-constexpr StoreSched<11> kFwdStores = {{{0, 4, 8, 2, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
-                                        {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 1, 0},
-                                        {960, 16, 9, 2, 2, 1}, {1104, 18, 4, 2, 0, 0}, {1176, 8, 1, 0, 0, 0}}, 4};
+// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile and one mask block per trunk layer, the
+// 2 dir blocks right behind layer_7 (counted as that stage's end-of-stage stores); the head stage stores nothing
+constexpr StoreSched<9> kFwdStores = {{{0, 4, 8, 2, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
+                                       {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 3, 0},
+                                       {960, 18, 1, 0, 0, 0}}, 4};
 constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
-struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<11, kFwdBlocks>(kFwdStores); };
+struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<9, kFwdBlocks>(kFwdStores); };
 struct FwdWaitPlain { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<1, kFwdBlocks>(kNoStores); };
 
 // NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries
@@ -144,45 +145,25 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     dense_stage<704, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(48), [&](int ks) { return y[ks]; }, relu_epi(x, 6, mb));
     dense_stage<832, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(56), [&](int ks) { return x[ks]; }, relu_epi(y, 7, mb));
     (void)btile;
-    // features (linear, 8 tiles) + sigma (relu, 9th tile row 0)
-    float sigma = 0.f;
-    dense_stage<960, 16, 9, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(64), [&](int ks) { return y[ks]; }, [&](int ot, f32x16 acc) {
-        if (ot < 8) {
-            pack_acc(acc, x[2 * (ot < 8 ? ot : 0)], x[2 * (ot < 8 ? ot : 0) + 1]);
-            if (SAVE) {
-                store_block(act, kActFeat + 2 * ot, lane, x[2 * (ot < 8 ? ot : 0)]);
-                store_block(act, kActFeat + 2 * ot + 1, lane, x[2 * (ot < 8 ? ot : 0) + 1]);
-            }
-        } else {
-            sigma = acc[0] > 0.f ? acc[0] : 0.f;   // lanes of half 0 hold row 0
-        }
-    });
-    // rgb_features: [features, dir_enc] -> 128, LINEAR in this reference (mlp.py:23-24,46)
-    bf16x8 f2[8], dirc[2];
+    // head: [h7, dir_enc] -> (r, g, b, sigma) pre-activations, one out tile on the composed matrix (layout.h); lanes of
+    // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).
+    bf16x8 dirc[2];
     encode<kLd, 2>(dx, dy, dz, h, dirc);
     if (SAVE) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
     }
-    dense_stage<1104, 18, 4, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(73), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
-                             [&](int ot, f32x16 acc) {
-                                 pack_acc(acc, f2[2 * ot], f2[2 * ot + 1]);
-                                 if (SAVE) {
-                                     store_block(act, kActF2 + 2 * ot, lane, f2[2 * ot]);
-                                     store_block(act, kActF2 + 2 * ot + 1, lane, f2[2 * ot + 1]);
-                                 }
-                             });
-    // rgb: 128 -> 3, sigmoid
-    dense_stage<1176, 8, 1, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(77), [&](int ks) { return f2[ks]; }, [&](int, f32x16 acc) {
-        if (valid && h == 0) {
-            f32x4 r;
-            r[0] = 1.f / (1.f + expf(-acc[0]));
-            r[1] = 1.f / (1.f + expf(-acc[1]));
-            r[2] = 1.f / (1.f + expf(-acc[2]));
-            r[3] = sigma;
-            reinterpret_cast<f32x4*>(a.raw)[g] = r;
-        }
-    });
+    dense_stage<960, 18, 1, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(64), [&](int ks) { return ks < 16 ? y[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
+                            [&](int, f32x16 acc) {
+                                if (valid && h == 0) {
+                                    f32x4 r;
+                                    r[0] = 1.f / (1.f + expf(-acc[0]));
+                                    r[1] = 1.f / (1.f + expf(-acc[1]));
+                                    r[2] = 1.f / (1.f + expf(-acc[2]));
+                                    r[3] = acc[3] > 0.f ? acc[3] : 0.f;
+                                    reinterpret_cast<f32x4*>(a.raw)[g] = r;
+                                }
+                            });
     ring_finish<kFwdBlocks>(ring, grp);
 }
 

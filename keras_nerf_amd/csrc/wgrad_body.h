@@ -35,13 +35,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// agent-scope coherent variant for data another workgroup of the SAME launch published (fused_bwd.hip): sc1 re-validates
-// the line past this XCD's L2, which may still hold the previous pass's copy of the same dZ address
-__device__ __forceinline__ void glds16_sc1(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
@@ -75,69 +68,26 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// ---- tile sequences -------------------------------------------------------------------------------------------------
-// The job body walks `count()` sample tiles; tile(i) is the global sample-tile index of the i-th one.
-struct ContigSeq {                       // stand-alone wgrad kernel: a contiguous range [t0, t1)
-    static constexpr bool kFlags = false;
+// The job body walks a contiguous range [t0, t1) of sample tiles.
+struct ContigSeq {
     long long t0, t1;
     __device__ __forceinline__ long long count() const { return t1 - t0; }
     __device__ __forceinline__ long long tile(long long i) const { return t0 + i; }
-    __device__ __forceinline__ const unsigned* flag(long long) const { return nullptr; }
-};
-struct FusedSeq {                        // fused dgrad+wgrad launch: every nsplit-th workgroup tile (8 sample tiles each),
-    static constexpr bool kFlags = true; // so that all consumers follow the producers' frontier; one ready flag per workgroup tile
-    int split, nsplit;
-    long long n_wg_tiles;
-    const unsigned* flags;
-    unsigned epoch;
-    int* abort_flag;
-    int ignore_flags;                    // timing experiments only (KNERF_FUSED_DEBUG): results are then undefined
-    __device__ __forceinline__ long long count() const {
-        return split < n_wg_tiles ? ((n_wg_tiles - split + nsplit - 1) / nsplit) * kWaves : 0;
-    }
-    __device__ __forceinline__ long long wg_tile(long long i) const { return split + (i >> 3) * nsplit; }
-    __device__ __forceinline__ long long tile(long long i) const { return wg_tile(i) * kWaves + (i & 7); }
-    __device__ __forceinline__ const unsigned* flag(long long i) const { return flags + wg_tile(i); }
 };
 
-// 4-byte LDS-DMA of a flag word (every lane copies the same word): rides the tile DMA's vmcnt queue
-__device__ __forceinline__ void glds4_sc1(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// blocking poll (slow path, drains this wave's DMA queue): bounded, never hangs -- on time-out the abort flag is raised
-// and the caller proceeds (the host reports the launch as failed)
-__device__ __forceinline__ void poll_flag_blocking(const unsigned* f, unsigned epoch, int* abort_flag) {
-    for (int n = 0; n < (1 << 18); ++n) {            // ~0.5 s at 2 us per poll
-        unsigned v, ab;
-        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(v), "=&v"(ab) : "v"(f), "v"(abort_flag) : "memory");
-        if (__builtin_amdgcn_readfirstlane(v) == epoch) return;
-        if (__builtin_amdgcn_readfirstlane(ab) != 0) return;     // somebody timed out: the launch has failed, just finish
-        __builtin_amdgcn_s_sleep(32);
-    }
-    if ((threadIdx.x & 63) == 0) atomicExch(abort_flag, 1);
-}
-
-// SIG (the `features` job only): the `sigma` head reads the same input h7 and its dZ tile sits right behind dfeat in the dZ
-// run, so its gradient is one more B fragment and one more accumulator per wave here (wave w takes input tile w, wave 0
-// also the bias row) instead of a job of its own that would read h7 from HBM a second time.
-template <int NI, int NO, class Seq, bool SIG = false>
+template <int NI, int NO>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
-                                               const Seq seq, char* smem) {
+                                               const ContigSeq seq, char* smem) {
     constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
     constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
     constexpr int ROWS = NI + 1;
     constexpr int NACC = (ROWS + WI - 1) / WI;
-    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO + (SIG ? 2 : 0);
-    static_assert(!SIG || (NO == 8 && NI == 8), "SIG rides on the 8 x 8 features job");
+    constexpr int BLK_IN = 2 * NI, BLK_DZ = 2 * NO;
     constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
     constexpr int G_IN = (BLK_IN + kWgWaves - 1) / kWgWaves, G_DZ = (BLK_DZ + kWgWaves - 1) / kWgWaves;
-    constexpr int G = G_IN + G_DZ + (Seq::kFlags ? 1 : 0);   // LDS-DMA instructions per wave per iteration (uniform)
-    constexpr int kFlagLds = Seq::kFlags ? kWgWaves * 4 * 256 : 0;   // per wave 4 slots of 64 lanes x 4 B
-    constexpr int NS = (160 * 1024 - kWgScratch - kFlagLds) / TILE_BYTES >= 4 ? 4 : 3;
-    static_assert(NS * TILE_BYTES + kWgScratch + kFlagLds <= 160 * 1024, "LDS budget");
+    constexpr int G = G_IN + G_DZ;                           // LDS-DMA instructions per wave per iteration (uniform)
+    constexpr int NS = (160 * 1024 - kWgScratch) / TILE_BYTES >= 4 ? 4 : 3;
+    static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
     static_assert(NO == WO, "one output tile per wave column");
 
     const long long cnt = seq.count();
@@ -147,8 +97,6 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     const int wo = WO == 1 ? 0 : wave % WO, wi = WI == 1 ? 0 : wave / WO;
     const unsigned smem_base = lds_addr(smem);
     const unsigned scratch = smem_base + NS * TILE_BYTES + wave * 1024;
-    const unsigned flag_lds = smem_base + NS * TILE_BYTES + kWgScratch + wave * 1024;   // 4 slots x 256 B
-    const char* flag_lds_ptr = smem + NS * TILE_BYTES + kWgScratch + wave * 1024;
 
     // per-lane offsets of the two transposed reads (see layout.h saved_off and the header of this file)
     int lane_off[2];
@@ -175,40 +123,19 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_DZ;
-            const unsigned to = __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch);
-            if constexpr (Seq::kFlags) glds16_sc1(src_dz + (ok ? b : 0) * 1024, to);
-            else glds16(src_dz + (ok ? b : 0) * 1024, to);
+            glds16(src_dz + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch));
         }
     };
-    // pre-load the ready flag of the workgroup tile that sample tile i belongs to (checked 3 iterations later)
-    auto preload_flag = [&](long long i) {
-        if constexpr (Seq::kFlags) glds4_sc1(seq.flag(i < cnt ? i : cnt - 1), flag_lds + (unsigned)((i & 3) * 256));
-    };
-    auto check_flag = [&](long long i) {
-        if constexpr (Seq::kFlags) {
-            // one flag per workgroup tile = 8 consecutive sample tiles of this sequence: look only at its first one (an
-            // LDS read in front of the DMA issue costs ~1000 cycles per iteration under this kernel's LDS load)
-            if ((i & (kWaves - 1)) == 0) {
-                const unsigned v = *reinterpret_cast<const volatile unsigned*>(flag_lds_ptr + (i & 3) * 256 + lane * 4);
-                if (__builtin_amdgcn_readfirstlane(v) != seq.epoch && !seq.ignore_flags) poll_flag_blocking(seq.flag(i < cnt ? i : cnt - 1), seq.epoch, seq.abort_flag);
-            }
-        }
-    };
-
     f32x16 acc[NACC];
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
-    f32x16 acc_s = zero_acc(), acc_sb = zero_acc();      // SIG: sigma kernel rows of input tile `wave`; sigma bias (wave 0)
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    // prologue: tiles 0..NS-2 (their flags are polled the slow way), flag pre-loads for tiles NS-1..NS+1
-    if constexpr (Seq::kFlags) {
-        if (!seq.ignore_flags) poll_flag_blocking(seq.flag(0), seq.epoch, seq.abort_flag);
-    }
+    // prologue: tiles 0..NS-2
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) { issue(s, s); preload_flag(s + NS - 1); }
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
     int slot = 0;
 #ifdef KNERF_WGRAD_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
@@ -220,9 +147,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
         STAMP(s2);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
-        check_flag(i + NS - 1);                 // pre-loaded NS-1 iterations ago, retired by the wait above
         issue(i + NS - 1, nslot);
-        preload_flag(i + 2 * (NS - 1));
         STAMP(s3);
         const char* in_reg = smem + slot * TILE_BYTES;
         const char* dz_reg = in_reg + BLK_IN * 1024;
@@ -244,15 +169,6 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             }
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
-            if constexpr (SIG) {
-                // branch-free: the wave re-reads "its" input tile by a run-time pair index (LDS has headroom) instead of
-                // selecting among afr[] -- eight uniform branches around single MFMAs cost 700 cycles per tile; every wave
-                // accumulates the bias row, wave 0 flushes it
-                const bf16x8 bs = tr_frag(dz_reg, NO, kk, lane_off);             // the sigma dZ tile: pair NO of the dZ region
-                const bf16x8 as = tr_frag(in_reg, wave, kk, lane_off);
-                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, bs, acc_s, 0, 0, 0);
-                acc_sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bs, acc_sb, 0, 0, 0);
-            }
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
 #ifdef KNERF_WGRAD_STAMPS
@@ -281,31 +197,17 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 const int d = dst[row * NCOLS + 32 * wo + c];
-                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
+                if (d >= 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][i]);
             }
         } else if (it == NI) {
             const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
-            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
-        }
-    }
-    if constexpr (SIG) {
-        const int* ds = a.dst + a.job_off[9];            // the sigma job's table: (32 NI + 1) rows x 32 columns
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int d = ds[row * 32 + c];
-            if (d >= 0) atomicAdd(a.grad + d, acc_s[i]);
-        }
-        if (wave == 0) {
-            const int d = ds[NI * 32 * 32 + c];
-            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc_sb[0]);
+            if (d >= 0 && hh == 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][0]);
         }
     }
 }
 
-// one job of the plan over the given tile sequence
-template <class Seq>
-__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const Seq& seq, char* smem) {
+// one job of the plan over the given tile range
+__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const ContigSeq& seq, char* smem) {
     switch (job) {
         case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, seq, smem); break;
         case 1: wgrad_job_body<8, 8>(a, 1, act_h(0), 16 * 1, seq, smem); break;
@@ -315,14 +217,7 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, cons
         case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, seq, smem); break;
         case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, seq, smem); break;
         case 7: wgrad_job_body<8, 8>(a, 7, act_h(6), 16 * 7, seq, smem); break;
-#ifdef KNERF_SEPARATE_SIGMA_JOB
-        case 8: wgrad_job_body<8, 8>(a, 8, kActH7, kDzFeat, seq, smem); break;
-        case 9: wgrad_job_body<8, 1>(a, 9, kActH7, kDzSig, seq, smem); break;
-#else
-        case 8: wgrad_job_body<8, 8, Seq, true>(a, 8, kActH7, kDzFeat, seq, smem); break;     // features + sigma
-#endif
-        case 10: wgrad_job_body<9, 4>(a, 10, kActFeat, kDzF2, seq, smem); break;
-        case 11: wgrad_job_body<4, 1>(a, 11, kActF2, kDzRgb, seq, smem); break;
+        case 8: wgrad_job_body<9, 1>(a, 8, kActH7, kDzHead, seq, smem); break;      // head: [h7 ; dir] x (r, g, b, sigma)
         default: break;
     }
 }

@@ -22,12 +22,32 @@ FOV = 0.6911112070083618          # inference.py:27
 GRAD_TOL_EMU, GRAD_TOL_FP32 = 2.5e-2, 8e-2      # of each tensor's max |g|: vs the oracle in kernel arithmetic / in fp32
 
 
-def scaled_params(cfg, seed, scale=1.5, bias_std=0.05):
-    rng = np.random.default_rng(100 + seed)
-    p = [w * np.float32(scale) for w in O.init_params(cfg, seed)]
-    for b in p[1::2]:
-        b += rng.normal(0, bias_std, b.shape).astype(np.float32)
-    return p
+def problem_weights(cfg=None):
+    """the weights of the small parity tests (tests/problem.py: glorot x 1.5 + N(0, 0.05) biases): sigma is positive on a
+    good part of the samples, so the gradients are carried by many samples and the bf16-vs-fp32 gap is the 3-5 % that
+    DESIGN.md section 4 states (with near-empty density fields the trunk gradients are rounding noise in BOTH arithmetics)"""
+    from tests.problem import make_problem
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)     # wh fixes the bias draw
+    return P["cp"], P["fp"]
+
+
+def check_grads_against_oracle(tag, g, n, loss, cfg, white, coarse_args, fine_args):
+    """per-tensor gradient error (of the tensor's max |g|) of both nets: against the oracle in the kernels' arithmetic to
+    GRAD_TOL_EMU; against the fp32 oracle (the reference's arithmetic) to GRAD_TOL_FP32, where the problem itself must be
+    well conditioned (the oracle's own bf16-vs-fp32 gap is asserted to stay under that tolerance too)"""
+    ref = {}
+    for emu in (True, False):
+        for k, a in (("c", coarse_args), ("f", fine_args)):
+            _, l, gr = O.chunk_loss_and_grads(a[0], a[1], a[2], a[3], a[4], cfg, white, emulate_bf16=emu)
+            ref[k, emu] = (float(l), O.flatten_params(gr))
+    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
+        ec, ef = per_tensor_err(g[:n], ref["c", emu][1], cfg), per_tensor_err(g[n:], ref["f", emu][1], cfg)
+        log_stats(f"{tag}_grads_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
+        assert ec[0] < tol and ef[0] < tol, (emu, ec, ef)
+        assert abs(float(loss[0]) - ref["c", emu][0]) < 2e-3 and abs(float(loss[1]) - ref["f", emu][0]) < 2e-3
+    gap = max(per_tensor_err(ref[k, True][1], ref[k, False][1], cfg)[0] for k in "cf")
+    log_stats(f"{tag}_oracle_bf16_vs_fp32_gap", gap=gap)
+    assert gap < GRAD_TOL_FP32, gap
 
 
 def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
@@ -36,7 +56,7 @@ def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, R = 256, 4096
     cfg = O.NerfConfig()
-    cp, fp = scaled_params(cfg, 0), scaled_params(cfg, 1)
+    cp, fp = problem_weights()
     nerf = NeRF(seed=0)
     nerf.compile("adam", "mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=R, white_background=True, is_training=False)
     assert nerf.sequential_chunks == 16
@@ -79,7 +99,7 @@ def test_cfg3_400x400_ten_chunks_of_16000():
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, R = 400, 16000
     cfg = O.NerfConfig()
-    cp, fp = scaled_params(cfg, 2), scaled_params(cfg, 3)
+    cp, fp = problem_weights()
     nerf = NeRF(seed=0)
     with pytest.raises(AssertionError):                                              # nerf.py:100: 160000 % 16384 = 12544
         nerf.compile("adam", "mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=16384, white_background=True)
@@ -119,13 +139,7 @@ def test_cfg3_400x400_ten_chunks_of_16000():
     g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
     t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:192 * 192].reshape(192, 192)
     so, sd, st, sg = (x.cpu().numpy() for x in (so, sd, st, sg))
-    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
-        _, lc, gc = O.chunk_loss_and_grads(cp, so, sd, st, sg, cfg, True, emulate_bf16=emu)
-        _, lf, gf = O.chunk_loss_and_grads(fp, so, sd, t_fine, sg, cfg, True, emulate_bf16=emu)
-        ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
-        log_stats(f"cfg3_subchunk_grads_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
-        assert ec[0] < tol and ef[0] < tol, (ec, ef)
-        assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    check_grads_against_oracle("cfg3_subchunk", g, n, loss, cfg, True, (cp, so, sd, st, sg), (fp, so, sd, t_fine, sg))
     # the class-level step at this size (nerf.py:332-473)
     ctx.zero_grads()
     before = nerf.fine.get_flat_weights()
@@ -140,7 +154,7 @@ def test_coarse_only_configuration_trains_both_nets_against_oracle():
     sort(concat(t, [])) = t (nerf.py:182-191), so both networks train on the coarse t-values."""
     from keras_nerf_amd.runtime import KnerfContext
     cfg = O.NerfConfig(n_coarse=64, n_fine=0)
-    cp, fp = scaled_params(cfg, 4), scaled_params(cfg, 5)
+    cp, fp = problem_weights(cfg)
     rng = np.random.default_rng(0)
     wh = 16
     o, d, t = O.generate_rays(O.pose_spherical(33.0, -30.0, 4.0), O.get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, 64, rng.random((wh, wh, 64)))
@@ -154,13 +168,7 @@ def test_coarse_only_configuration_trains_both_nets_against_oracle():
     g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
     t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:N * 64].reshape(N, 64)
     np.testing.assert_array_equal(t_fine, t)
-    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
-        _, lc, gc = O.chunk_loss_and_grads(cp, o, d, t, img, cfg, False, emulate_bf16=emu)
-        _, lf, gf = O.chunk_loss_and_grads(fp, o, d, t, img, cfg, False, emulate_bf16=emu)
-        ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
-        log_stats(f"coarse_only_train_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
-        assert ec[0] < tol and ef[0] < tol, (ec, ef)
-        assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    check_grads_against_oracle("coarse_only_train", g, n, loss, cfg, False, (cp, o, d, t, img), (fp, o, d, t, img))
     ctx.apply_adam()
     assert ctx.step == 1 and np.abs(ctx.get_weights(0) - O.flatten_params(cp)).max() > 0
     ctx.close()
