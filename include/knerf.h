@@ -108,9 +108,14 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
                       const float* u, uint64_t seed, int n_rays, int ray_chunks, float* loss, float* c_image, float* f_image);
 
 /* coarse_optimizer.apply_gradients + fine_optimizer.apply_gradients + accumulator reset (nerf.py:455-471).
- * Call after the optional all-reduce of knerf_grads_device().  Returns KNERF_ERR_NONFINITE (weights untouched)
- * when a gradient is not finite (nerf.py:381-382).  Synchronises the stream. */
+ * Call after the optional all-reduce of knerf_grads_device().  ASYNCHRONOUS: the finite check of nerf.py:381-382 runs on the
+ * device in front of the update, and a step whose gradient is not finite leaves weights and Adam slots untouched (the
+ * accumulators are zeroed either way).  The host learns of it from knerf_poll_nonfinite. */
 int knerf_apply_adam(knerf_ctx* ctx, void* stream);
+/* Returns KNERF_ERR_NONFINITE once for every batch of skipped steps since the previous poll (and takes them back out of the
+ * step counter), KNERF_OK otherwise.  wait != 0 synchronises `stream` first, i.e. covers every knerf_apply_adam issued so far;
+ * wait == 0 reads the device-written status word as it stands (steps that have completed). */
+int knerf_poll_nonfinite(knerf_ctx* ctx, void* stream, int wait);
 int knerf_zero_grads(knerf_ctx* ctx, void* stream);
 int knerf_step_count(const knerf_ctx* ctx);
 int knerf_set_step_count(knerf_ctx* ctx, int step);
@@ -144,39 +149,11 @@ int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weight
  * Classes: 0 mlp_fwd coarse, 1 mlp_fwd fine, 2 composite, 3 sample_fine, 4 mlp_bwd coarse, 5 mlp_bwd fine,
  * 6 wgrad coarse, 7 wgrad fine, 8 adam+repack.  read() synchronises the device, returns summed milliseconds and launch
  * counts since enable/the previous read (n >= 9). */
-/* Backward schedule.  producers = 0 (default): dgrad and wgrad are separate launches.  producers = P > 0: one launch of
- * P persistent dgrad workgroups + (CUs - P) wgrad workgroups that consume dZ as it is published (fused_bwd.hip).  Results
- * are the same up to fp32 summation order.  A poll time-out inside the fused launch is reported by knerf_apply_adam
- * (KNERF_ERR_HIP); it cannot hang.  No reference counterpart (scheduling only). */
-int knerf_set_fused_backward(knerf_ctx* ctx, int producers);
-
 int knerf_profile_enable(knerf_ctx* ctx, int on);
 int knerf_profile_read(knerf_ctx* ctx, double* total_ms, int64_t* launches, int n);
 
-/* ---- introspection used by the CPU-side layout tests (no device work) ---- */
-/* kind 0: forward A-fragment table, 1: forward bias table, 2: dgrad A-fragment table, 3: wgrad destination table.
- * Entries are indices into the flat parameter vector or -1.  Pass out=NULL to query the length. */
-int knerf_debug_table(int kind, int32_t* out, size_t* n);
-/* device buffers of the last knerf_train_chunk for kernel-level tests: 0 act, 1 mask, 2 dz, 3 raw, 4 draw,
- * 5 merged fine t-values, 6 coarse weights */
-int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes);
-/* hardware-fact probes for tests: kind 0 = one v_mfma_f32_32x32x16_bf16 (in0 = A fragments [64][8] bf16, in1 = B
- * fragments, out = [64][16] f32); kind 1 = one ds_read_b64_tr_b16 (in0 = 4 KiB LDS image, in1 = [64] int32 byte
- * offsets, out = [64][4] u16).  All device pointers. */
-/* the general-shape path's layer program for a config (no device needed): 16 int32 per Dense layer in Keras order =
- * {kernel offset, bias offset, fan_in, fan_out, padded input width, padded output width, n_seg, seg0 (buffer col0, width,
- * kernel row0), seg1 (...), relu, head (-1 | 0 sigma | 1 rgb), padded width of the output buffer or -1}. */
-int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n);
-int knerf_debug_probe(int kind, const void* in0, const void* in1, void* out, void* stream);
-/* MFMA-shape rate probe (shape 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16) with the chain kernels' operand
- * traffic; `blocks` workgroups of 512 threads, 96 * 2^15 * 16 FLOP per wave and iteration.  Diagnostic only. */
-/* HBM write-pattern probe (diagnostic): `workgroups` x 8 waves each store `blocks` 1 KiB blocks into tiles `tile_stride`
- * bytes apart; mode 0 = the chain kernels' pattern, 1 = the 8 waves of a workgroup interleaved. */
-int knerf_debug_write_probe(void* out, int workgroups, int blocks, long long tile_stride, int mode, int spin, void* stream);
-/* HBM read-pattern probe (diagnostic): each of workgroups x 8 waves streams bytes_per_wave contiguous bytes in 1 KiB
- * instructions; mode 0 = nt LDS-DMA (wgrad's loads), 1 = plain register loads. */
-int knerf_debug_read_probe(const void* in, int workgroups, long long bytes_per_wave, int mode, void* out, void* stream);
-int knerf_debug_rate_probe(int shape, const void* in0, const void* in1, void* out, int blocks, int iters, void* stream);
+/* Diagnostics (layout tables, workspace views, hardware-fact and bandwidth probes) are NOT part of this library: they are
+ * declared in include/knerf_debug.h and built into libknerf_probe.so for tests/ and tools/ only. */
 
 #ifdef __cplusplus
 }

@@ -39,12 +39,12 @@ SIGNATURES = {
     "knerf_train_chunk": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_float, _F, _F, _F]),
     "knerf_train_batch": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, C.c_uint64, C.c_int, C.c_int, _F, _F, _F]),
     "knerf_apply_adam": (C.c_int, [_P, _P]),
+    "knerf_poll_nonfinite": (C.c_int, [_P, _P, C.c_int]),
     "knerf_zero_grads": (C.c_int, [_P, _P]),
     "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "knerf_ray_points": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "knerf_image_metrics": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "knerf_mlp_call": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_uint64, _P]),
-    "knerf_set_fused_backward": (C.c_int, [_P, C.c_int]),
     "knerf_step_count": (C.c_int, [_P]),
     "knerf_set_step_count": (C.c_int, [_P, C.c_int]),
     "knerf_generate_rays": (C.c_int, [_P, _P, _F, _F, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -54,13 +54,6 @@ SIGNATURES = {
     "knerf_inverse_cdf": (C.c_int, [_P, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "knerf_profile_enable": (C.c_int, [_P, C.c_int]),
     "knerf_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
-    "knerf_debug_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
-    "knerf_debug_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
-    "knerf_debug_probe": (C.c_int, [C.c_int, _P, _P, _P, _P]),
-    "knerf_debug_write_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, _P]),
-    "knerf_debug_generic_plan": (C.c_int, [_P, _P, _P]),
-    "knerf_debug_read_probe": (C.c_int, [_P, C.c_int, C.c_longlong, C.c_int, _P, _P]),
-    "knerf_debug_rate_probe": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
 }
 
 _lib = None
@@ -86,15 +79,3 @@ def load() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
-
-
-def debug_table(kind: int):
-    import numpy as np
-    lib = load()
-    n = C.c_size_t(0)
-    if lib.knerf_debug_table(kind, None, C.byref(n)) != 0:
-        raise KnerfError("knerf_debug_table failed")
-    out = np.empty(n.value, np.int32)
-    if lib.knerf_debug_table(kind, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)) != 0:
-        raise KnerfError("knerf_debug_table failed")
-    return out

@@ -1,4 +1,9 @@
-"""Builds libknerf_hip.so (gfx950 only) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Builds the HIP libraries (gfx950 only) in-tree with hipcc.  Cross-compiles without a GPU.
+
+libknerf_hip.so    the product: the C ABI of include/knerf.h
+libknerf_probe.so  diagnostics for tests/ and tools/ (include/knerf_debug.h): layout-table introspection, workspace views,
+                   hardware-fact and bandwidth probes.  Links against libknerf_hip.so; the product never loads it.
+"""
 from __future__ import annotations
 
 import os
@@ -8,9 +13,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libknerf_hip.so")
-SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "fused_bwd.hip", "generic.hip", "composite.hip", "sampler.hip", "optim.hip",
-           "raygen.hip", "probe.hip", "utils_ops.hip"]
-HEADERS = ["chain.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h")]
+PROBE_LIB = os.path.join(HERE, "libknerf_probe.so")
+SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.hip", "composite.hip", "sampler.hip", "optim.hip",
+           "raygen.hip", "utils_ops.hip"]
+PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
+HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
+           os.path.join("..", "..", "include", "knerf_debug.h")]
 # -ffp-contract=off: the parity-critical fp32 arithmetic (ray points, sampler, compositing) must round like the
 # reference's separate mul/add ops; fused multiply-adds are written explicitly (__builtin_fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
@@ -20,16 +28,10 @@ def _newer(a: str, b: str) -> bool:
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "") -> str:
-    """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py"""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
-    lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")
-    flags = FLAGS + ["-D" + d for d in defines]
-    os.makedirs(objdir, exist_ok=True)
+def _compile(hipcc, sources, objdir, flags, force, verbose):
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
-    for src in SOURCES:
+    for src in sources:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
@@ -41,8 +43,28 @@ def build(force: bool = False, verbose: bool = True, defines=(), variant: str = 
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if procs or not os.path.exists(lib):
+    return objs, bool(procs)
+
+
+def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "") -> str:
+    """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
+    lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")
+    probe = PROBE_LIB if not variant else os.path.join(HERE, f"libknerf_probe_{variant}.so")
+    flags = FLAGS + ["-D" + d for d in defines]
+    os.makedirs(objdir, exist_ok=True)
+    objs, changed = _compile(hipcc, SOURCES, objdir, flags, force, verbose)
+    pobjs, pchanged = _compile(hipcc, PROBE_SOURCES, objdir, flags, force, verbose)
+    if changed or not os.path.exists(lib):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        pchanged = True
+    if pchanged or not os.path.exists(probe):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", probe, *pobjs, "-L" + HERE, "-l:" + os.path.basename(lib),
+               "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

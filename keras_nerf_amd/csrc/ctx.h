@@ -1,0 +1,83 @@
+// ctx.h -- the context object behind the C ABI (include/knerf.h).  Internal: shared by knerf_api.hip and by the
+// diagnostics library (debug_api.hip -> libknerf_probe.so), which reads workspace pointers out of it for kernel-level tests.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/knerf.h"
+#include "generic.h"
+#include "layout.h"
+
+namespace knerf {
+
+struct Net {
+    float *w = nullptr, *m = nullptr, *v = nullptr;     // w: kExtParamCount floats on the fused path (parameters + composed head)
+    float *g = nullptr, *aux = nullptr;                 // point into knerf_ctx::grads / knerf_ctx::aux
+    char *fwd_stream = nullptr, *bwd_stream = nullptr;
+    float* bias = nullptr;
+};
+
+struct Tables {
+    PackTables host;
+    std::vector<int32_t> wgrad;        // concatenated per-job destination tables
+    std::vector<int32_t> wgrad_off;    // kWgradJobs+1 offsets
+    int *d_fwd = nullptr, *d_bias = nullptr, *d_bwd = nullptr, *d_wgrad = nullptr, *d_plan = nullptr;
+    int n_plan = 0;
+};
+
+// the packing / destination tables of layout.h, built once per process (host only)
+inline void build_wgrad_tables(Tables& t) {
+    auto tt = tensor_table();
+    t.wgrad.clear(); t.wgrad_off.clear();
+    for (int jb = 0; jb < kWgradJobs; ++jb) {
+        t.wgrad_off.push_back((int32_t)t.wgrad.size());
+        WgradJob J = wgrad_job(jb);
+        const int rows = J.n_it * 32 + 1, cols = J.n_ot * 32;     // last row = bias
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) t.wgrad.push_back(wgrad_dst(tt, jb, r == rows - 1 ? -2 : r, c));
+    }
+    t.wgrad_off.push_back((int32_t)t.wgrad.size());
+}
+inline const Tables& host_tables() {
+    static const Tables t = [] { Tables x; build_fwd(x.host); build_bwd(x.host); build_wgrad_tables(x); return x; }();
+    return t;
+}
+
+}  // namespace knerf
+
+struct knerf_ctx {
+    knerf_config cfg;
+    std::string err;
+    knerf::Net net[2];
+    float* grads = nullptr;            // [coarse | fine] flat gradient accumulators: the DP all-reduce operand
+    float* aux = nullptr;              // [coarse | fine] head accumulators (layout.h kAuxCount each), expanded into grads per batch
+    knerf::Tables tab;
+    int step = 0;
+    int* d_flag = nullptr;             // device: set by the finite check of the current step
+    int* h_status = nullptr;           // pinned host: [0] number of skipped (non-finite) steps so far, written by the device
+    int skipped_seen = 0;
+    int n_cu = 256;
+    // general-shape MLP path (generic.h): used when the config is not the default NeRFMLP shape
+    bool generic = false;
+    int n_params = knerf::kParamCount;
+    knerf::gen::Plan gplan;
+    knerf::gen::Workspace gws;
+    knerf::gen::NetDev gnet[2];
+    // knerf_mlp_call (NeRFMLP.__call__ on encoded inputs): own plan / packed weights / workspace, also on a fused-path context
+    knerf::gen::Plan call_plan; bool call_plan_ok = false;
+    knerf::gen::Workspace call_ws;
+    knerf::gen::NetDev call_net;
+    float* call_raw = nullptr;
+    // workspaces (grow-only)
+    int ws_rays = 0; bool ws_train = false;
+    float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
+    char *act = nullptr, *mask = nullptr, *dz = nullptr;
+    size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
+    // optional per-kernel timing with HIP events on the caller's stream (knerf_profile_*)
+    bool prof_on = false;
+    struct ProfRec { int id; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
+};

@@ -15,6 +15,7 @@
 // leaves lane = feature, registers = samples, an MFMA operand with a fixed sample permutation shared by both factors --
 // so neither LDS nor a workgroup barrier is involved (wgrad_kernel).
 #include "generic.h"
+#include "kernels.h"
 
 #include <cmath>
 
@@ -318,12 +319,9 @@ template <int NT>
 hipError_t launch_gemm_ws(const GemmArgs& g, int gy, hipStream_t s) {
     const int pitch = (g.K + 63) / 64 * 64 * 2 + 16;
     const size_t lds = (size_t)NT * 32 * pitch;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmWsLds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static AttrOnce once;
+    hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmWsLds); });
+    if (ae != hipSuccess) return ae;
     long long gx = (g.M / 32 + kGemmWaves - 1) / kGemmWaves;
     const long long cap = 512 / gy > 0 ? 512 / gy : 1;           // persistent: about two workgroups per CU in all
     if (gx > cap) gx = cap;
@@ -334,11 +332,10 @@ hipError_t launch_gemm_ws(const GemmArgs& g, int gy, hipStream_t s) {
 template <int NT>
 hipError_t launch_gemm_nt(const GemmArgs& g, int gy, hipStream_t s) {
     const size_t lds = 2 * (size_t)NT * 32 * kGemmRowB;
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    static AttrOnce once;
+    if (lds > 64 * 1024) {
+        hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (ae != hipSuccess) return ae;
     }
     const unsigned gx = (unsigned)((g.M + kGemmWaves * 32 - 1) / (kGemmWaves * 32));
     hipLaunchKernelGGL((gemm_kernel<NT>), dim3(gx, gy), dim3(kGemmWaves * 64), lds, s, g);
@@ -639,13 +636,10 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     const int kt = K / 32, nt = N / 32;
 #ifndef KNERF_GEN_NO_COOP
     if (kt >= 4 && nt >= 4) {
-        static bool attr_done = false;
+        static AttrOnce once;
         const size_t lds = 2 * (size_t)kCoopBuf;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (ae != hipSuccess) return ae;
         const int gx = (K + 255) / 256, gy = (N + 255) / 256;
 #ifndef KNERF_GEN_COOP_WGS
 #define KNERF_GEN_COOP_WGS 256      // one workgroup per CU: each flushes a whole 256 x 256 block with atomics (512: +8 %, 1024: +23 %)

@@ -2,8 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace knerf {
+
+// hipFuncSetAttribute once per DEVICE: a function-local `static bool` is neither per device nor safe with two host threads
+// (two racing threads may both set the attribute, which is idempotent)
+struct AttrOnce {
+    std::atomic<unsigned long long> done{0};
+    template <class F>
+    hipError_t operator()(F&& set) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = set();
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
 
 struct FwdArgs {
     const char* stream;     // packed forward A-fragments (bf16), kFwdBlocks KiB + tail pages
@@ -35,27 +53,15 @@ struct WgradArgs {
     const char* act;        // [tiles][kActBlocks][1 KiB]
     const char* dz;         // [tiles][kDzBlocks][1 KiB]
     float* grad;            // flat fp32 gradient accumulator of this net (kParamCount)
-    const int* dst;         // concatenated per-job destination tables: [(32*n_it + 1) rows][32*n_ot cols] param index or -1
+    float* aux;             // head accumulator of this net (layout.h kAuxCount): destinations >= kAuxBase land here
+    const int* dst;         // concatenated per-job destination tables: [(32*n_it + 1) rows][32*n_ot cols] index or -1
     const void* plan;       // device array of WgradPlan, one per workgroup
     long long n_tiles;
     int n_plan;
     int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
-    int job_off[14];        // offset of each job's table inside dst
+    int job_off[10];        // offset of each job's table inside dst (kWgradJobs + 1)
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
-
-// dgrad + wgrad in one launch (fused_bwd.hip)
-struct FusedArgs {
-    BwdArgs bwd;
-    WgradArgs wgrad;          // plan = consumer workgroups only
-    unsigned* flags;          // one word per 256-sample workgroup tile; == epoch when that tile's dZ is published
-    int* abort_flag;          // raised by a consumer whose bounded poll timed out
-    long long n_wg_tiles;
-    unsigned epoch;           // launch counter (flags are never cleared)
-    int n_producers;
-    int debug;                // KNERF_FUSED_DEBUG bits: 1 consumers idle, 2 producers idle, 4 consumers ignore flags
-};
-hipError_t launch_bwd_wgrad(const FusedArgs& f, hipStream_t stream);
 
 struct CompositeArgs {
     const float* raw;       // [R,S,4]
@@ -88,12 +94,18 @@ struct AdamArgs {
     float* w; float* m; float* v; float* g;   // kParamCount each; g is zeroed
     int n;
     float lr_t, b1, b2, eps;
-    int* nonfinite;                            // set to 1 when a gradient is not finite
+    const int* nonfinite;                      // device flag of this step's finite check: non-zero = skip the update
 };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 hipError_t launch_pack(const float* w, const int* table, unsigned short* out, size_t n, hipStream_t stream);
 hipError_t launch_gather_f32(const float* w, const int* table, float* out, size_t n, hipStream_t stream);
 hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t stream);
+hipError_t launch_step_status(const int* flag, int* host_status, hipStream_t stream);
+// collapsed head (layout.h): w = one net's extended weight buffer (kExtParamCount floats).  compose writes the head matrix
+// and bias behind the parameters; expand turns the wgrad head job's aux sums into the gradients of features, rgb_features
+// and rgb (added to grad, aux zeroed).
+hipError_t launch_head_compose(float* w, hipStream_t stream);
+hipError_t launch_head_expand(const float* w, float* aux, float* grad, hipStream_t stream);
 
 struct RayGenArgs {
     const float* c2w;       // [B,4,4] row-major (device)

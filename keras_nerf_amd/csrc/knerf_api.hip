@@ -11,6 +11,7 @@
 
 #include "../../include/knerf.h"
 #include "chain.h"
+#include "ctx.h"
 #include "kernels.h"
 #include "generic.h"
 #include "layout.h"
@@ -21,47 +22,21 @@ namespace {
 
 std::string g_create_error;
 
-struct Net {
-    float *w = nullptr, *m = nullptr, *v = nullptr, *g = nullptr;   // g points into ctx->grads
-    char *fwd_stream = nullptr, *bwd_stream = nullptr;
-    float* bias = nullptr;
-};
-
-struct Tables {
-    PackTables host;
-    std::vector<int32_t> wgrad;        // concatenated per-job destination tables
-    std::vector<int32_t> wgrad_off;    // kWgradJobs+1 offsets
-    int *d_fwd = nullptr, *d_bias = nullptr, *d_bwd = nullptr, *d_wgrad = nullptr, *d_plan = nullptr;
-    int n_plan = 0;
-};
-
 // Workgroups per wgrad job in proportion to the job's measured cost per sample tile (cycles per loop iteration from the
 // s_memtime stamps of a -DKNERF_WGRAD_STAMPS build, tools/kbench.py): the streaming jobs are HBM-bound, the small ones
-// (sigma, rgb heads) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
-#ifndef KNERF_FEATSIG_COST
-#define KNERF_FEATSIG_COST 260      // swept 225..340 with tools/kbench.py (1.43 ms per fine launch at 225, 1.27 at 260, 1.31 at 340)
-#endif
+// (layer_0, head) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
+// KNERF_WGRAD_COSTS="c0,c1,...,c8" overrides the table (tuning sweeps in one gpurun call).
 std::vector<int32_t> build_wgrad_plan(int n_wg) {
-    int cost[kWgradJobs], total = 0;
-    for (int j = 0; j < kWgradJobs; ++j) {
-        WgradJob J = wgrad_job(j);
-        int c = 0;
-        if (J.layer >= 0) {
-#ifdef KNERF_SEPARATE_SIGMA_JOB
-            if (j == 0) c = 109; else if (j == 5) c = 248; else if (j == 9) c = 106; else if (j == 10) c = 162; else if (j == 11) c = 73;
-            else c = 204;
-#else       // the sigma head rides on the features job (wgrad_body.h, SIG): no workgroups of its own.  Re-deriving every weight
-            // from the final kernels' stamps (104/195/243/240/162/88) was not better than these (1.31 vs 1.29 ms per fine launch)
-            if (j == 0) c = 109; else if (j == 5) c = 248; else if (j == 8) c = KNERF_FEATSIG_COST; else if (j == 9) c = 0;
-            else if (j == 10) c = 162; else if (j == 11) c = 73;
-            else c = 204;
-#endif
-        }
-        cost[j] = c; total += c;
+    int cost[kWgradJobs] = {109, 204, 204, 204, 204, 248, 204, 204, 130};
+    if (const char* e = std::getenv("KNERF_WGRAD_COSTS")) {
+        int j = 0;
+        for (const char* p = e; *p && j < kWgradJobs; ++j) { cost[j] = std::atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
     }
+    int total = 0;
+    for (int j = 0; j < kWgradJobs; ++j) total += cost[j];
     std::vector<int32_t> plan;
     for (int j = 0; j < kWgradJobs; ++j) {
-        if (!cost[j]) continue;
+        if (cost[j] <= 0) continue;
         int ns = (cost[j] * (n_wg - 4) + total / 2) / total; if (ns < 1) ns = 1;
         for (int s = 0; s < ns; ++s) { plan.push_back(j); plan.push_back(s); plan.push_back(ns); plan.push_back(0); }
     }
@@ -70,63 +45,7 @@ std::vector<int32_t> build_wgrad_plan(int n_wg) {
 
 }  // namespace
 
-struct knerf_ctx {
-    knerf_config cfg;
-    std::string err;
-    Net net[2];
-    float* grads = nullptr;
-    Tables tab;
-    int step = 0;
-    int* d_flag = nullptr;             // [0] non-finite gradient, [1] fused backward poll time-out
-    // fused dgrad+wgrad launch (fused_bwd.hip): 0 = separate kernels
-    int fused_producers = 0, n_cu = 256;
-    int* d_fplan = nullptr; int n_fplan = 0;
-    unsigned* d_ready = nullptr; size_t ready_cap = 0;
-    unsigned epoch = 0;
-    // general-shape MLP path (generic.h): used when the config is not the default NeRFMLP shape
-    bool generic = false;
-    int n_params = kParamCount;
-    gen::Plan gplan;
-    gen::Workspace gws;
-    gen::NetDev gnet[2];
-    // knerf_mlp_call (NeRFMLP.__call__ on encoded inputs): own plan / packed weights / workspace, also on a fused-path context
-    gen::Plan call_plan; bool call_plan_ok = false;
-    gen::Workspace call_ws;
-    gen::NetDev call_net;
-    float* call_raw = nullptr;
-    // workspaces (grow-only)
-    int ws_rays = 0; bool ws_train = false;
-    float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
-    char *act = nullptr, *mask = nullptr, *dz = nullptr;
-    size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
-    // optional per-kernel timing with HIP events on the caller's stream (knerf_profile_*)
-    bool prof_on = false;
-    struct ProfRec { int id; hipEvent_t e0, e1; };
-    std::vector<ProfRec> prof;
-};
-
 namespace {
-
-void build_wgrad_tables(Tables& t) {
-    auto tt = tensor_table();
-    t.wgrad.clear(); t.wgrad_off.clear();
-    for (int jb = 0; jb < kWgradJobs; ++jb) {
-        t.wgrad_off.push_back((int32_t)t.wgrad.size());
-        WgradJob J = wgrad_job(jb);
-        if (J.layer < 0) continue;
-        const int rows = J.n_it * 32 + 1, cols = J.n_ot * 32;     // last row = bias
-        for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) t.wgrad.push_back(wgrad_dst(tt, jb, r == rows - 1 ? -2 : r, c));
-    }
-    t.wgrad_off.push_back((int32_t)t.wgrad.size());
-}
-
-const Tables& host_tables() {
-    static Tables t;
-    static bool done = false;
-    if (!done) { build_fwd(t.host); build_bwd(t.host); build_wgrad_tables(t); done = true; }
-    return t;
-}
 
 int fail(knerf_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_error = msg;
@@ -139,7 +58,7 @@ int fail(knerf_ctx* c, int code, const std::string& msg) {
             return fail(ctx, KNERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-constexpr size_t kFwdStreamBytes = (size_t)(kFwdBlocks + kTailPages * kPageBlocks) * 1024;
+constexpr size_t kFwdStreamBytes = (size_t)((kFwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
 constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
 
 int repack(knerf_ctx* ctx, int n, hipStream_t s) {
@@ -148,6 +67,7 @@ int repack(knerf_ctx* ctx, int n, hipStream_t s) {
         HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n].packed, s));
         return KNERF_OK;
     }
+    HIPCHK(launch_head_compose(N.w, s));          // the composed head behind the parameters (layout.h), then the bf16 streams
     HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)kFwdBlocks * 512, s));
     HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)kBwdBlocks * 512, s));
     HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)kFwdBiasTiles * 32, s));
@@ -161,11 +81,14 @@ size_t tiles_for(long long n_samples) {
 
 template <class T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
+// grow-only workspaces; the zero-fills are enqueued on the caller's stream `s`, the one the consuming kernels run on
+// (hipMalloc / hipFree themselves synchronise the device)
+int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s) {
     if (n_rays <= ctx->ws_rays && (!train || ctx->ws_train)) return KNERF_OK;
     const int R = n_rays > ctx->ws_rays ? n_rays : ctx->ws_rays;
     const int Na = ctx->cfg.n_coarse + ctx->cfg.n_fine;
     train = train || ctx->ws_train;
+    HIPCHK(hipStreamSynchronize(s));           // nothing enqueued earlier may still use the buffers that are freed below
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
     ctx->ws_rays = 0;
@@ -181,12 +104,12 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
         g.mp = gen::padded_rows((long long)ns);
         const size_t ab = ctx->gplan.act_elems_per_row * g.mp * sizeof(unsigned short), zb = ctx->gplan.dz_elems_per_row * g.mp * sizeof(unsigned short);
         HIPCHK(hipMalloc(&g.act, ab));
-        HIPCHK(hipMemset(g.act, 0, ab));
+        HIPCHK(hipMemsetAsync(g.act, 0, ab, s));
         HIPCHK(hipMalloc(&g.zs, g.mp * 32 * sizeof(float)));
         HIPCHK(hipMalloc(&g.zc, g.mp * 32 * sizeof(float)));
         if (train) {
             HIPCHK(hipMalloc(&g.dz, zb));
-            HIPCHK(hipMemset(g.dz, 0, zb));
+            HIPCHK(hipMemsetAsync(g.dz, 0, zb, s));
             HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
         }
     } else if (train) {
@@ -196,12 +119,8 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train) {
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
         HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
-        HIPCHK(hipMemset(ctx->dz, 0, ctx->dz_bytes));     // blocks kDzSig+1 / kDzRgb+1 are never written and must read 0
-        HIPCHK(hipMemset(ctx->act, 0, ctx->act_bytes));
-        free_dev(ctx->d_ready);
-        ctx->ready_cap = tiles / kWaves;
-        HIPCHK(hipMalloc(&ctx->d_ready, ctx->ready_cap * sizeof(unsigned)));
-        HIPCHK(hipMemset(ctx->d_ready, 0, ctx->ready_cap * sizeof(unsigned)));   // epochs start at 1
+        HIPCHK(hipMemsetAsync(ctx->dz, 0, ctx->dz_bytes, s));     // block kDzHead+1 is never written and must read 0
+        HIPCHK(hipMemsetAsync(ctx->act, 0, ctx->act_bytes, s));
     }
     ctx->ws_rays = R; ctx->ws_train = train;
     return KNERF_OK;
@@ -257,25 +176,34 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = ctx->mask; ba.dz = ctx->dz;
         ba.n_samples = fa.n_samples; ba.net = fa.net;
         WgradArgs wa{};
-        wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.dst = ctx->tab.d_wgrad;
+        wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
         wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
-        if (ctx->fused_producers > 0) {
-            FusedArgs f{};
-            f.bwd = ba; f.wgrad = wa; f.wgrad.plan = ctx->d_fplan; f.wgrad.n_plan = ctx->n_fplan;
-            f.flags = ctx->d_ready; f.abort_flag = ctx->d_flag + 1; f.n_wg_tiles = wa.n_tiles / kWaves;
-            f.epoch = ++ctx->epoch; f.n_producers = ctx->fused_producers;
-            if (const char* e = std::getenv("KNERF_FUSED_DEBUG")) f.debug = std::atoi(e);
-            if ((size_t)f.n_wg_tiles > ctx->ready_cap) return fail(ctx, KNERF_ERR_INVALID, "ready-flag buffer too small");
-            ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
-            HIPCHK(launch_bwd_wgrad(f, s));
-        } else {
-            { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
-            { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F); HIPCHK(launch_wgrad(wa, s)); }
-        }
+        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
+        { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F); HIPCHK(launch_wgrad(wa, s)); }
     }
     return KNERF_OK;
+}
+
+// the wgrad head jobs leave sums in ctx->aux; this turns them into the gradients of features / rgb_features / rgb of both
+// nets (optim.hip head_expand).  Linear in the sums, so once per batch of chunks is the same as once per chunk.
+int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
+    if (ctx->generic) return KNERF_OK;
+    for (int n = 0; n < 2; ++n) HIPCHK(launch_head_expand(ctx->net[n].w, ctx->net[n].aux, ctx->net[n].g, s));
+    return KNERF_OK;
+}
+
+int train_chunk_impl(knerf_ctx* ctx, hipStream_t s, const float* o, const float* d, const float* t, const float* target,
+                     const float* u, uint64_t seed, uint64_t ray_offset, int n_rays, float inv_chunks, float* loss,
+                     float* c_image, float* f_image) {
+    const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
+    float* ci = c_image ? c_image : ctx->img_tmp;
+    float* fi = f_image ? f_image : ctx->img_tmp + (size_t)n_rays * 4;
+    float* ls = loss ? loss : ctx->loss_tmp;
+    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, ci, nullptr, ctx->w_c, target, inv_chunks, ls)) return r;
+    if (int r = knerf_sample_fine(ctx, s, t, ctx->w_c, u, seed, 0, ray_offset, n_rays, ctx->t_f)) return r;
+    return run_pass(ctx, s, KNERF_FINE, o, d, ctx->t_f, n_rays, Na, fi, nullptr, nullptr, target, inv_chunks, ls + 1);
 }
 
 }  // namespace
@@ -290,44 +218,6 @@ size_t knerf_param_count_for(const knerf_config* cfg) {
 }
 
 const char* knerf_last_error(const knerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
-
-int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n) {
-    if (!cfg || !n || knerf_param_count_for(cfg) == 0) return KNERF_ERR_INVALID;
-    const gen::Plan p = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
-    std::vector<int32_t> v;
-    for (const gen::Layer& L : p.layers) {
-        const int32_t row[16] = {L.w_off, L.b_off, L.k_real, L.n_real, p.buf_ld[L.in_buf], L.np, L.n_seg, L.seg[0].col0, L.seg[0].width,
-                                 L.seg[0].wrow0, L.seg[1].col0, L.seg[1].width, L.seg[1].wrow0, L.relu, L.head, L.out_buf < 0 ? -1 : p.buf_ld[L.out_buf]};
-        v.insert(v.end(), row, row + 16);
-    }
-    if (out) {
-        if (*n < v.size()) return KNERF_ERR_INVALID;
-        memcpy(out, v.data(), v.size() * sizeof(int32_t));
-    }
-    *n = v.size();
-    return KNERF_OK;
-}
-
-int knerf_debug_table(int kind, int32_t* out, size_t* n) {
-    if (!n) return KNERF_ERR_INVALID;
-    const Tables& t = host_tables();
-    const std::vector<int32_t>* v = nullptr;
-    std::vector<int32_t> tmp;
-    switch (kind) {
-        case 0: v = &t.host.fwd; break;
-        case 1: v = &t.host.fwd_bias; break;
-        case 2: v = &t.host.bwd; break;
-        case 3: v = &t.wgrad; break;
-        case 4: v = &t.wgrad_off; break;
-        default: return KNERF_ERR_INVALID;
-    }
-    if (out) {
-        if (*n < v->size()) return KNERF_ERR_INVALID;
-        memcpy(out, v->data(), v->size() * sizeof(int32_t));
-    }
-    *n = v->size();
-    return KNERF_OK;
-}
 
 int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     knerf_ctx* ctx = nullptr;
@@ -381,19 +271,25 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     }
     CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * NP * sizeof(float)));
-    CREATECHK(hipMalloc(&ctx->d_flag, 2 * sizeof(int)));
-    CREATECHK(hipMemset(ctx->d_flag, 0, 2 * sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->aux, 2 * (size_t)kAuxCount * sizeof(float)));
+    CREATECHK(hipMemset(ctx->aux, 0, 2 * (size_t)kAuxCount * sizeof(float)));
+    CREATECHK(hipMalloc(&ctx->d_flag, sizeof(int)));
+    CREATECHK(hipMemset(ctx->d_flag, 0, sizeof(int)));
+    CREATECHK(hipHostMalloc(&ctx->h_status, 2 * sizeof(int), hipHostMallocDefault));   // written by the device (optim.hip step_status)
+    ctx->h_status[0] = ctx->h_status[1] = 0;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
     for (int n = 0; n < 2; ++n) {
         Net& N = ctx->net[n];
-        CREATECHK(hipMalloc(&N.w, NP * sizeof(float)));
+        const size_t NW = ctx->generic ? NP : (size_t)kExtParamCount;          // fused path: parameters + composed head (layout.h)
+        CREATECHK(hipMalloc(&N.w, NW * sizeof(float)));
         CREATECHK(hipMalloc(&N.m, NP * sizeof(float)));
         CREATECHK(hipMalloc(&N.v, NP * sizeof(float)));
-        CREATECHK(hipMemset(N.w, 0, NP * sizeof(float)));
+        CREATECHK(hipMemset(N.w, 0, NW * sizeof(float)));
         CREATECHK(hipMemset(N.m, 0, NP * sizeof(float)));
         CREATECHK(hipMemset(N.v, 0, NP * sizeof(float)));
         N.g = ctx->grads + (size_t)n * NP;
+        N.aux = ctx->aux + (size_t)n * kAuxCount;
         if (ctx->generic) {
             CREATECHK(hipMalloc(&ctx->gnet[n].packed, ctx->gplan.packed_elems * sizeof(unsigned short)));
             CREATECHK(hipMemset(ctx->gnet[n].packed, 0, ctx->gplan.packed_elems * sizeof(unsigned short)));
@@ -406,9 +302,6 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         CREATECHK(hipMemset(N.bias, 0, kFwdBiasTiles * 32 * sizeof(float)));
     }
 #undef CREATECHK
-    if (const char* e = std::getenv("KNERF_FUSED_BWD")) {       // tuning override; the schedule is otherwise set by the host API
-        if (int r = knerf_set_fused_backward(ctx, std::atoi(e))) { g_create_error = ctx->err; knerf_destroy(ctx); return r; }
-    }
     *out = ctx;
     return KNERF_OK;
 }
@@ -419,7 +312,8 @@ int knerf_destroy(knerf_ctx* ctx) {
         Net& N = ctx->net[n];
         free_dev(N.w); free_dev(N.m); free_dev(N.v); free_dev(N.fwd_stream); free_dev(N.bwd_stream); free_dev(N.bias);
     }
-    free_dev(ctx->grads); free_dev(ctx->d_flag); free_dev(ctx->d_fplan); free_dev(ctx->d_ready); free_dev(ctx->loss_tmp);
+    free_dev(ctx->grads); free_dev(ctx->aux); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp);
+    if (ctx->h_status) { (void)hipHostFree(ctx->h_status); ctx->h_status = nullptr; }
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
@@ -472,7 +366,7 @@ int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, c
     if (int r = check_net(ctx, net)) return r;
     if (!o || !d || !t || !image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: null/empty argument");
     if (n_samples < 1 || n_samples > ctx->cfg.n_coarse + ctx->cfg.n_fine) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: n_samples out of range");
-    if (int r = ensure_ws(ctx, n_rays, false)) return r;
+    if (int r = ensure_ws(ctx, n_rays, false, (hipStream_t)stream)) return r;
     return run_pass(ctx, (hipStream_t)stream, net, o, d, t, n_rays, n_samples, image, depth, weights, nullptr, 1.f, nullptr);
 }
 
@@ -521,8 +415,8 @@ int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float
                        float* f_image, float* f_depth, float* f_weights, float* t_fine) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (!o || !d || !t || !c_image || !f_image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "render_chunk: null/empty argument");
-    if (int r = ensure_ws(ctx, n_rays, false)) return r;
     hipStream_t s = (hipStream_t)stream;
+    if (int r = ensure_ws(ctx, n_rays, false, s)) return r;
     const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
     float* wc = c_weights ? c_weights : ctx->w_c;
     float* tf = t_fine ? t_fine : ctx->t_f;
@@ -555,47 +449,39 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
                       float* c_image, float* f_image) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (!o || !d || !t || !target || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "train_chunk: null/empty argument");
-    if (int r = ensure_ws(ctx, n_rays, true)) return r;
     hipStream_t s = (hipStream_t)stream;
-    const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
-    float* ci = c_image ? c_image : ctx->img_tmp;
-    float* fi = f_image ? f_image : ctx->img_tmp + (size_t)n_rays * 4;
-    float* ls = loss ? loss : ctx->loss_tmp;
-    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, ci, nullptr, ctx->w_c, target, inv_chunks, ls)) return r;
-    if (int r = knerf_sample_fine(ctx, stream, t, ctx->w_c, u, seed, 0, ray_offset, n_rays, ctx->t_f)) return r;
-    return run_pass(ctx, s, KNERF_FINE, o, d, ctx->t_f, n_rays, Na, fi, nullptr, nullptr, target, inv_chunks, ls + 1);
+    if (int r = ensure_ws(ctx, n_rays, true, s)) return r;
+    if (int r = train_chunk_impl(ctx, s, o, d, t, target, u, seed, ray_offset, n_rays, inv_chunks, loss, c_image, f_image)) return r;
+    return expand_head_grads(ctx, s);
 }
 
 int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
                       const float* u, uint64_t seed, int n_rays, int ray_chunks, float* loss, float* c_image, float* f_image) {
     if (!ctx) return KNERF_ERR_INVALID;
+    if (!o || !d || !t || !target) return fail(ctx, KNERF_ERR_INVALID, "train_batch: null argument");
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "train_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
+    hipStream_t s = (hipStream_t)stream;
+    if (int r = ensure_ws(ctx, ray_chunks, true, s)) return r;
     const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
     for (int i = 0; i < C; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
-        if (int r = knerf_train_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, target + r0 * 3, u ? u + r0 * Nf : nullptr, seed,
-                                      (uint64_t)r0, ray_chunks, 1.0f / (float)C, loss, c_image ? c_image + r0 * 3 : nullptr,
-                                      f_image ? f_image + r0 * 3 : nullptr))
+        if (int r = train_chunk_impl(ctx, s, o + r0 * 3, d + r0 * 3, t + r0 * Nc, target + r0 * 3, u ? u + r0 * Nf : nullptr, seed,
+                                     (uint64_t)r0, ray_chunks, 1.0f / (float)C, loss, c_image ? c_image + r0 * 3 : nullptr,
+                                     f_image ? f_image + r0 * 3 : nullptr))
             return r;
     }
-    return KNERF_OK;
+    return expand_head_grads(ctx, s);
 }
 
 int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     if (!ctx) return KNERF_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    // finite check first so that a bad step leaves the weights untouched (reference aborts fit at nerf.py:381-382)
+    // Finite check first, on the device; the Adam kernels read its flag and leave weights and slots untouched when it is
+    // set (the reference aborts fit at nerf.py:381-382).  Nothing here waits for the GPU: the outcome reaches the host through
+    // a pinned status word (knerf_poll_nonfinite).
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
     HIPCHK(launch_check_finite(ctx->grads, 2 * ctx->n_params, ctx->d_flag, s));
-    int flag[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(flag, ctx->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (flag[1]) {
-        HIPCHK(hipMemsetAsync(ctx->d_flag + 1, 0, sizeof(int), s));
-        return fail(ctx, KNERF_ERR_HIP, "fused backward: a consumer timed out waiting for dZ (workgroups not co-resident?); gradients are invalid");
-    }
-    if (flag[0]) return fail(ctx, KNERF_ERR_NONFINITE, "Gradient is not finite");
     ctx->step += 1;
     const double b1 = ctx->cfg.beta1, b2 = ctx->cfg.beta2;
     const float lr_t = (float)((double)ctx->cfg.lr * std::sqrt(1.0 - std::pow(b2, ctx->step)) / (1.0 - std::pow(b1, ctx->step)));
@@ -607,31 +493,26 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         HIPCHK(launch_adam(a, s));
         if (int r = repack(ctx, n, s)) return r;
     }
+    HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, s));
     return KNERF_OK;
 }
 
-int knerf_set_fused_backward(knerf_ctx* ctx, int producers) {
+int knerf_poll_nonfinite(knerf_ctx* ctx, void* stream, int wait) {
     if (!ctx) return KNERF_ERR_INVALID;
-    if (producers <= 0) { ctx->fused_producers = 0; return KNERF_OK; }
-    if (producers > ctx->n_cu - kWgradJobs) return fail(ctx, KNERF_ERR_INVALID, "producers must leave one workgroup per wgrad job");
-    // producers + consumers must all be resident at once: one 160 KiB-LDS workgroup per CU
-    std::vector<int32_t> plan;
-    for (int n_wg = ctx->n_cu - producers + 4; n_wg > 0; --n_wg) {
-        plan = build_wgrad_plan(n_wg);
-        if ((int)plan.size() / 4 <= ctx->n_cu - producers) break;
+    if (wait) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const int skipped = *reinterpret_cast<volatile int*>(ctx->h_status);
+    if (skipped != ctx->skipped_seen) {
+        ctx->step -= skipped - ctx->skipped_seen;          // those updates did not happen: the step counter (Adam's t) goes back
+        ctx->skipped_seen = skipped;
+        return fail(ctx, KNERF_ERR_NONFINITE, "Gradient is not finite");
     }
-    if (plan.empty() || (int)plan.size() / 4 > ctx->n_cu - producers) return fail(ctx, KNERF_ERR_INVALID, "no consumer plan fits");
-    free_dev(ctx->d_fplan);
-    HIPCHK(hipMalloc(&ctx->d_fplan, plan.size() * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(ctx->d_fplan, plan.data(), plan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    ctx->n_fplan = (int)plan.size() / 4;
-    ctx->fused_producers = producers;
     return KNERF_OK;
 }
 
 int knerf_zero_grads(knerf_ctx* ctx, void* stream) {
     if (!ctx) return KNERF_ERR_INVALID;
     HIPCHK(hipMemsetAsync(ctx->grads, 0, 2 * (size_t)ctx->n_params * sizeof(float), (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(ctx->aux, 0, 2 * (size_t)kAuxCount * sizeof(float), (hipStream_t)stream));
     return KNERF_OK;
 }
 
@@ -671,23 +552,6 @@ int knerf_profile_read(knerf_ctx* ctx, double* total_ms, int64_t* launches, int 
         if (r.e1) (void)hipEventDestroy(r.e1);
     }
     ctx->prof.clear();
-    return KNERF_OK;
-}
-
-int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes) {
-    if (!ctx || !dev || !bytes) return KNERF_ERR_INVALID;
-    (void)net;
-    switch (which) {
-        case 0: *dev = ctx->act; *bytes = ctx->act_bytes; break;
-        case 1: *dev = ctx->mask; *bytes = ctx->mask_bytes; break;
-        case 2: *dev = ctx->dz; *bytes = ctx->dz_bytes; break;
-        case 3: *dev = ctx->raw; *bytes = ctx->raw_bytes; break;
-        case 4: *dev = ctx->draw; *bytes = ctx->raw_bytes; break;
-        case 5: *dev = ctx->t_f; *bytes = (size_t)ctx->ws_rays * (ctx->cfg.n_coarse + ctx->cfg.n_fine) * sizeof(float); break;
-        case 6: *dev = ctx->w_c; *bytes = (size_t)ctx->ws_rays * ctx->cfg.n_coarse * sizeof(float); break;
-        default: return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: unknown buffer");
-    }
-    if (!*dev) return fail(ctx, KNERF_ERR_INVALID, "debug_buffer: not allocated (no pass has run yet, or the buffer belongs to the fused path and this context runs the general-shape kernels)");
     return KNERF_OK;
 }
 

@@ -14,14 +14,13 @@ hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream) {
     const long long tiles = (a.n_samples + kTile - 1) / kTile;
     const int grid = (int)((tiles + kWaves - 1) / kWaves);
     const size_t lds = kRingBytes;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static AttrOnce once;
+    hipError_t ae = once([&]() -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ae != hipSuccess) return ae;
     if (a.net == 0) hipLaunchKernelGGL(mlp_bwd_kernel<0>, dim3(grid), dim3(kThreads), lds, stream, a);
     else hipLaunchKernelGGL(mlp_bwd_kernel<1>, dim3(grid), dim3(kThreads), lds, stream, a);
     return hipGetLastError();

@@ -171,16 +171,17 @@ hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
     const long long tiles = (a.n_samples + kTile - 1) / kTile;
     const int grid = (int)((tiles + kWaves - 1) / kWaves);
     const size_t lds = kRingBytes + kFwdBiasTiles * 32 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static AttrOnce once;
+    hipError_t ae = once([&]() -> hipError_t {
         const void* fns[4] = {reinterpret_cast<const void*>(mlp_fwd_kernel<false, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<false, 1>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<true, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<true, 1>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
-    }
+        return hipSuccess;
+    });
+    if (ae != hipSuccess) return ae;
     const dim3 g(grid), b(kThreads);
     if (save) {
         if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<true, 0>), g, b, lds, stream, a);

@@ -3,10 +3,13 @@
 // Adam restates tf.keras.optimizers Adam as used at reference keras_nerf/model/nerf/nerf.py:163-165,455-458:
 //   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host, double);  m += (g-m)(1-b1);  v += (g*g-v)(1-b2);
 //   w -= lr_t * m / (sqrt(v) + eps)      -- eps OUTSIDE the bias-corrected root, eps = 1e-7.
-// The gradient accumulator is zeroed in the same pass (nerf.py:464-471) and a non-finite gradient raises a flag
-// (the reference asserts finiteness per chunk, nerf.py:381-382,410-411; here once per step, before the update).
+// The gradient accumulator is zeroed in the same pass (nerf.py:464-471).  Finiteness (the reference asserts it per chunk,
+// nerf.py:381-382,410-411) is checked once per step BEFORE the update by check_finite_kernel; the Adam kernels read that
+// flag and skip the update when it is set, so a bad step leaves weights and slots untouched without a host round trip, and
+// step_status_kernel counts the skipped step in a pinned host word (knerf_poll_nonfinite).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "layout.h"
 
 namespace knerf {
 
@@ -14,13 +17,13 @@ __global__ void adam_kernel(AdamArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const float g = a.g[i];
-    if (!__builtin_isfinite(g)) { *a.nonfinite = 1; }
+    a.g[i] = 0.f;                                   // also after a skipped step: the next batch must not add onto NaN
+    if (*a.nonfinite) return;
     float m = a.m[i], v = a.v[i];
     m = m + (g - m) * (1.f - a.b1);
     v = v + (g * g - v) * (1.f - a.b2);
     a.m[i] = m; a.v[i] = v;
     a.w[i] = a.w[i] - a.lr_t * m / (sqrtf(v) + a.eps);
-    a.g[i] = 0.f;
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(adam_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
@@ -57,6 +60,124 @@ __global__ void check_finite_kernel(const float* g, int n, int* flag) {
 }
 hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t stream) {
     hipLaunchKernelGGL(check_finite_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, g, n, flag);
+    return hipGetLastError();
+}
+
+// host_status (pinned, device-visible): [0] += 1 when this step's finite check failed, [1] = steps processed
+__global__ void step_status_kernel(const int* flag, int* host_status) {
+    if (*flag) host_status[0] = host_status[0] + 1;
+    host_status[1] = host_status[1] + 1;
+    __threadfence_system();
+}
+hipError_t launch_step_status(const int* flag, int* host_status, hipStream_t stream) {
+    hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, flag, host_status);
+    return hipGetLastError();
+}
+
+// ---- collapsed head (layout.h) --------------------------------------------------------------------------------------
+// Offsets of the six tensors behind the trunk in the flat parameter vector (Keras order: sigma, features, rgb_features, rgb)
+namespace {
+constexpr int kOffL = 63 * 256 + 256 + 4 * (256 * 256 + 256) + (319 * 256 + 256) + 2 * (256 * 256 + 256);   // first float behind layer_7
+constexpr int kWs = kOffL, kBs = kWs + 256;                  // sigma kernel [256,1], bias [1]
+constexpr int kWf = kBs + 1, kBf = kWf + 256 * 256;          // features kernel [256,256], bias [256]
+constexpr int kWr = kBf + 256, kBr = kWr + 283 * 128;        // rgb_features kernel [283,128], bias [128]
+constexpr int kWc = kBr + 128, kBc = kWc + 128 * 3;          // rgb kernel [128,3], bias [3]
+static_assert(kBc + 3 == kParamCount, "head tensor offsets");
+}  // namespace
+
+// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < 256);  H[256+m][0..2] = (W_r2 W_c)[m], H[256+m][3] = 0 (m < 27);
+// bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP.
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w) {
+    __shared__ float P[283][3];          // W_r W_c : rows 0..255 = W_r1 W_c, 256..282 = W_r2 W_c
+    __shared__ float wc[128][3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 128 * 3; i += 256) wc[i / 3][i % 3] = w[kWc + i];
+    __syncthreads();
+    for (int r = tid; r < 283; r += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float* wr = w + kWr + (size_t)r * 128;
+        for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
+        P[r][0] = a0; P[r][1] = a1; P[r][2] = a2;
+    }
+    __syncthreads();
+    float* H = w + kHeadOff;
+    {   // row tid of A = W_f P1
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float* wf = w + kWf + (size_t)tid * 256;
+        for (int j = 0; j < 256; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
+        H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[kWs + tid];
+    }
+    if (tid < 32) {
+        const int r = 256 + tid;
+        const bool real = tid < 27;
+        H[r * 4 + 0] = real ? P[r][0] : 0.f; H[r * 4 + 1] = real ? P[r][1] : 0.f; H[r * 4 + 2] = real ? P[r][2] : 0.f; H[r * 4 + 3] = 0.f;
+    }
+    if (tid < 3) {
+        float c = w[kBc + tid];
+        for (int j = 0; j < 256; ++j) c += w[kBf + j] * P[j][tid];
+        for (int k = 0; k < 128; ++k) c += w[kBr + k] * wc[k][tid];
+        w[kHeadBiasOff + tid] = c;
+    }
+    if (tid == 3) w[kHeadBiasOff + 3] = w[kBs];
+}
+hipError_t launch_head_compose(float* w, hipStream_t stream) {
+    hipLaunchKernelGGL(head_compose_kernel, dim3(1), dim3(256), 0, stream, w);
+    return hipGetLastError();
+}
+
+// aux: M[row][c] = sum_s [h7 ; dir][s][row] dz_rgb[s][c] (row < 283), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..255,
+// M2 = rows 256..282, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
+//   d rgb/kernel          = W_r1^T Q + W_r2^T M2 + b_r (x) s        d rgb/bias          = s
+//   d rgb_features/kernel = [Q ; M2] W_c^T                          d rgb_features/bias = s W_c^T
+//   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
+// -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
+// evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void head_expand_kernel(const float* w, float* aux, float* grad) {
+    __shared__ float M[283][3], s_[3], P1[256][3], Q[256][3], wc[128][3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 283 * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
+    if (tid < 3) s_[tid] = aux[kAuxS + tid];
+    for (int i = tid; i < 128 * 3; i += 1024) wc[i / 3][i % 3] = w[kWc + i];
+    __syncthreads();
+    for (int i = tid; i < kAuxCount; i += 1024) aux[i] = 0.f;
+    if (tid < 256) {            // P1 row tid
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float* wr = w + kWr + (size_t)tid * 128;
+        for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
+        P1[tid][0] = a0; P1[tid][1] = a1; P1[tid][2] = a2;
+    } else if (tid < 512) {     // Q row j: column j of W_f against M1 (coalesced over j)
+        const int j = tid - 256;
+        const float bf = w[kBf + j];
+        float a0 = bf * s_[0], a1 = bf * s_[1], a2 = bf * s_[2];
+        for (int i = 0; i < 256; ++i) { const float v = w[kWf + (size_t)i * 256 + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
+        Q[j][0] = a0; Q[j][1] = a1; Q[j][2] = a2;
+    }
+    __syncthreads();
+    // features: kernel [256,256] += M1 P1^T, bias += s P1^T
+    for (int e = tid; e < 256 * 256; e += 1024) {
+        const int i = e >> 8, j = e & 255;
+        grad[kWf + e] += M[i][0] * P1[j][0] + M[i][1] * P1[j][1] + M[i][2] * P1[j][2];
+    }
+    if (tid < 256) grad[kBf + tid] += s_[0] * P1[tid][0] + s_[1] * P1[tid][1] + s_[2] * P1[tid][2];
+    // rgb_features: kernel [283,128] += [Q ; M2] W_c^T, bias += s W_c^T
+    for (int e = tid; e < 283 * 128; e += 1024) {
+        const int r = e >> 7, k = e & 127;
+        const float* v = r < 256 ? Q[r] : M[r];
+        grad[kWr + e] += v[0] * wc[k][0] + v[1] * wc[k][1] + v[2] * wc[k][2];
+    }
+    if (tid < 128) grad[kBr + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
+    // rgb: kernel [128,3] += W_r1^T Q + W_r2^T M2 + b_r (x) s, bias += s
+    if (tid < 384) {
+        const int k = tid / 3, c = tid % 3;
+        float a = w[kBr + k] * s_[c];
+        for (int j = 0; j < 256; ++j) a += w[kWr + (size_t)j * 128 + k] * Q[j][c];
+        for (int m = 256; m < 283; ++m) a += w[kWr + (size_t)m * 128 + k] * M[m][c];
+        grad[kWc + tid] += a;
+    }
+    if (tid < 3) grad[kBc + tid] += s_[tid];
+}
+hipError_t launch_head_expand(const float* w, float* aux, float* grad, hipStream_t stream) {
+    hipLaunchKernelGGL(head_expand_kernel, dim3(1), dim3(1024), 0, stream, w, aux, grad);
     return hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
-// probe.hip -- tiny kernels that pin the hardware facts the fused kernels rely on (tests/test_gpu_probe.py):
+// probe.hip (libknerf_probe.so, diagnostics only) -- tiny kernels that pin the hardware facts the fused kernels rely on (tests/test_gpu_probe.py):
 // the v_mfma_f32_32x32x16_bf16 operand maps and the ds_read_b64_tr_b16 transposing LDS read.
 #include <hip/hip_runtime.h>
-#include "../../include/knerf.h"
+#include "../../include/knerf_debug.h"
 #include "chain.h"
 
 namespace knerf {

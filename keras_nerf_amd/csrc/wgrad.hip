@@ -21,14 +21,13 @@ extern "C" int knerf_debug_wgrad_stamps(unsigned long long* host, int n) {
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     const size_t lds = 160 * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static AttrOnce once;
+    hipError_t ae = once([&]() -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ae != hipSuccess) return ae;
     if (a.net == 0) hipLaunchKernelGGL(wgrad_kernel<0>, dim3(a.n_plan), dim3(kWgThreads), lds, stream, a);
     else hipLaunchKernelGGL(wgrad_kernel<1>, dim3(a.n_plan), dim3(kWgThreads), lds, stream, a);
     return hipGetLastError();

@@ -238,12 +238,18 @@ class NeRF:
         self._ctx.train_batch(o, d, t, tgt, uf, seed, R, self._loss_acc, ci, fi)
         if self._dist:                                                            # nerf.py:455-458 under MirroredStrategy
             parallel.all_reduce_gradients(self._ctx.grads_view(), self.all_reduce)
-        self._ctx.apply_adam()            # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471)
+        # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471): enqueued, nothing waits for the GPU
+        self._ctx.apply_adam(check=False)
         if not with_metrics:
+            # fast path (no host synchronisation per step): a step skipped for a non-finite gradient is reported by the
+            # first later call that finds it completed
+            self._ctx.poll_nonfinite(wait=False)
             return {"coarse_loss": self._loss_acc[0], "fine_loss": self._loss_acc[1]}
         B, H, W = self.batch_size, self.image_height, self.image_width
-        return self.update_and_return_metrics(images, ci.reshape(B, H, W, 3), fi.reshape(B, H, W, 3),
+        logs = self.update_and_return_metrics(images, ci.reshape(B, H, W, 3), fi.reshape(B, H, W, 3),
                                               self._loss_acc[0].clone(), self._loss_acc[1].clone())
+        self._ctx.poll_nonfinite(wait=True)      # as the reference: the failing batch raises from its own train_step
+        return logs
 
     def test_step(self, inputs, u=None):
         """nerf.py:475-497"""

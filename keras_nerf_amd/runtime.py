@@ -177,12 +177,16 @@ class KnerfContext:
         self._check(self.lib.knerf_train_batch(self._ctx, self._stream(), _ptr(o), _ptr(d), _ptr(t), _ptr(target), _ptr(u), seed, n,
                                                int(ray_chunks or n), _ptr(loss), _ptr(c_image), _ptr(f_image)))
 
-    def apply_adam(self):
+    def apply_adam(self, check: bool = True):
+        """finite check + 2x Keras-form Adam + accumulator reset, enqueued without waiting for the GPU.  check=True then
+        waits and raises NonFiniteGradientError if the step was skipped (the reference's assert_all_finite, nerf.py:381-382);
+        check=False leaves that to a later poll_nonfinite() at a point where the caller synchronises anyway."""
         self._check(self.lib.knerf_apply_adam(self._ctx, self._stream()))
+        if check:
+            self.poll_nonfinite(wait=True)
 
-    def set_fused_backward(self, producers: int):
-        """0: dgrad and wgrad as separate launches; P>0: one launch, P persistent dgrad workgroups feeding the wgrad ones."""
-        self._check(self.lib.knerf_set_fused_backward(self._ctx, int(producers)))
+    def poll_nonfinite(self, wait: bool = False):
+        self._check(self.lib.knerf_poll_nonfinite(self._ctx, self._stream(), int(wait)))
 
     def mlp_call(self, net: int, xyz_enc, dir_enc) -> torch.Tensor:
         """NeRFMLP.__call__ on already encoded inputs [n, xyz_dim] / [n, dir_dim]: raw [n,4] = (rgb, sigma)"""
@@ -197,6 +201,7 @@ class KnerfContext:
 
     @property
     def step(self) -> int:
+        """optimizer steps applied so far (steps skipped for a non-finite gradient leave it once they have been polled)"""
         return int(self.lib.knerf_step_count(self._ctx))
 
     @step.setter
@@ -226,8 +231,3 @@ class KnerfContext:
         ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
         self._check(self.lib.knerf_profile_read(self._ctx, ms, cnt, n))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
-
-    def debug_buffer(self, which: int) -> torch.Tensor:
-        p, n = C.c_void_p(), C.c_size_t()
-        self._check(self.lib.knerf_debug_buffer(self._ctx, 0, which, C.byref(p), C.byref(n)))
-        return torch.as_tensor(_CudaView(p.value, n.value, "|u1"), device=self.device)

@@ -51,7 +51,7 @@ def fullsize():
     o, d, t, u, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["u"].reshape(N, -1), P["img"].reshape(N, 3)
     out = dict(o=o, d=d, t=t, u=u, img=img, w_c_checksum=np.array([O.flatten_params(P["cp"]).astype(np.float64).sum()]),
                w_f_checksum=np.array([O.flatten_params(P["fp"]).astype(np.float64).sum()]))
-    for emu, tag in ((False, "f32"), (True, "bf16")):
+    for emu, tag in ((False, "f32"), (O.FUSED, "bf16")):      # "bf16" = the fused kernels' arithmetic (nerf_oracle.FUSED)
         c, f = O.predict_and_render_chunk(P["cp"], P["fp"], o, d, t, u, cfg, True, "zero", emulate_bf16=emu)
         out[f"{tag}_c_image"] = c["image"]; out[f"{tag}_c_depth"] = c["depth"]; out[f"{tag}_c_weights"] = c["weights"]
         out[f"{tag}_f_image"] = f["image"]; out[f"{tag}_t_fine"] = f["t"]

@@ -260,10 +260,41 @@ def fine_points(t_coarse, w_coarse, u, oob="zero"):
 # --------------------------------------------------------------------------------------
 
 
+# ``emulate_bf16`` values (a TEST AID, not reference behaviour -- the reference computes in fp32):
+#   False    fp32 (or fp64) throughout: the reference's arithmetic
+#   True     every Dense layer as written in mlp.py, matmul operands rounded to bf16, fp32 accumulate, fp32 bias and
+#            activation: the arithmetic of the general-shape HIP kernels (csrc/generic.hip)
+#   FUSED    the arithmetic of the fused default-shape kernels (csrc/mlp_fwd.hip ...): as True for the trunk; the three
+#            linear layers behind it and the sigma head evaluated as ONE affine map of (h7, dir_enc) with a composed
+#            [283,4] matrix (see head_compose), and their gradients recovered from the sums M = [h7;dir]^T dz_rgb, s
+FUSED = "fused"
+
+
+def _rb(x):
+    """a matmul operand as the MFMA kernels see it: rounded to bf16, held in fp32"""
+    return round_bf16(x).astype(np.float32)
+
+
 def _mm(a, w, emulate_bf16):
     if emulate_bf16:
-        return round_bf16(a).astype(np.float32) @ round_bf16(w).astype(np.float32)
+        return _rb(a) @ _rb(w)
     return a @ w
+
+
+def head_compose(params, cfg: NerfConfig):
+    """mlp.py:21-27,42-48: features and rgb_features are LINEAR Dense layers, so
+        rgb_pre = h7 (W_f W_r1 W_c) + dir_enc (W_r2 W_c) + ((b_f W_r1 + b_r) W_c + b_c),   sigma_pre = h7 w_s + b_s
+    (W_r1 = first dense_units rows of the rgb_features kernel, W_r2 = its dir rows).  Returns H [units+dir_dim, 4]
+    (columns r, g, b, sigma; the dir rows of the sigma column are zero) and the bias [4], in the dtype of the params."""
+    n, U = cfg.n_layers, cfg.dense_units
+    ks, bs, kf, bf, kr, br, kc, bc = params[2 * n:2 * n + 8]
+    P = kr @ kc                                        # [U + dir_dim, 3]
+    H = np.zeros((U + cfg.dir_dim, 4), ks.dtype)
+    H[:U, :3] = kf @ P[:U]
+    H[U:, :3] = P[U:]
+    H[:U, 3] = ks[:, 0]
+    hb = np.concatenate([bf @ P[:U] + br @ kc + bc, bs])
+    return H, hb.astype(ks.dtype)
 
 
 def mlp_forward(params: Sequence[np.ndarray], xyz_enc, dir_enc, cfg: NerfConfig, emulate_bf16=False,
@@ -293,6 +324,16 @@ def mlp_forward(params: Sequence[np.ndarray], xyz_enc, dir_enc, cfg: NerfConfig,
         if i % cfg.skip_layer == 0 and i > 0:
             h = np.concatenate([h, x], axis=-1)
     trunk = h
+    if emulate_bf16 == FUSED:
+        H, hb = head_compose(params, cfg)
+        z4 = _mm(np.concatenate([trunk, dd], axis=-1), H, True) + hb
+        sigma = np.maximum(z4[:, 3:4], dt(0.0))
+        with np.errstate(over="ignore"):
+            rgb = dt(1.0) / (dt(1.0) + np.exp(-z4[:, :3]))
+        if want_cache:
+            cache = dict(ins=ins, outs=outs, trunk=trunk, sigma=sigma, rgb=rgb, x=x, dd=dd, H=H, emulate_bf16=emulate_bf16)
+            return rgb.reshape(lead + (3,)), sigma.reshape(lead + (1,)), cache
+        return rgb.reshape(lead + (3,)), sigma.reshape(lead + (1,))
     ks, bs = params[p], params[p + 1]; p += 2
     kf, bf = params[p], params[p + 1]; p += 2
     kr, br = params[p], params[p + 1]; p += 2
@@ -329,16 +370,44 @@ def mlp_backward(params, cache, drgb, dsigma, cfg: NerfConfig):
 
     def mmT(a, b):  # a^T b  (wgrad)
         if eb:
-            return round_bf16(a).T.astype(np.float32) @ round_bf16(b).astype(np.float32)
+            return _rb(a).T @ _rb(b)
         return a.T @ b
 
     def mmW(g, w):  # g w^T (dgrad)
         if eb:
-            return round_bf16(g).astype(np.float32) @ round_bf16(w).T.astype(np.float32)
+            return _rb(g) @ _rb(w).T
         return g @ w.T
 
     rgb = cache["rgb"]
     dzc = drgb * rgb * (dt(1.0) - rgb)
+    if eb == FUSED:
+        # the fused kernels: dz4 = (dz_rgb, dz_sigma) in bf16; M = [h7 ; dir]^T dz_rgb, s = sum dz_rgb (bf16 operands, fp32
+        # sums); the six head gradients by the chain rule through the three linear layers, in fp32 on the master weights
+        U = cfg.dense_units
+        kf, bf_, kr, br, kc = params[2 * n + 2], params[2 * n + 3], params[2 * n + 4], params[2 * n + 5], params[2 * n + 6]
+        dzs = dsigma * (cache["sigma"] > 0).astype(dsigma.dtype)
+        dz4 = np.concatenate([dzc, dzs], axis=-1)
+        hd = np.concatenate([cache["trunk"], cache["dd"]], axis=-1)
+        M4 = mmT(hd, dz4)                                            # [U + dir_dim, 4]
+        s4 = _rb(dz4).sum(0)
+        M1, M2, s3 = M4[:U, :3], M4[U:, :3], s4[:3]
+        P1 = kr[:U] @ kc
+        Q = kf.T @ M1 + np.outer(bf_, s3)                            # = sum_s features[s]^T dz_rgb[s]
+        g_kc = kr[:U].T @ Q + kr[U:].T @ M2 + np.outer(br, s3); g_bc = s3
+        g_kr = np.concatenate([Q, M2], axis=0) @ kc.T; g_br = s3 @ kc.T
+        g_kf = M1 @ P1.T; g_bf = s3 @ P1.T
+        g_ks, g_bs = M4[:U, 3:4], s4[3:4]
+        dh = mmW(dz4, cache["H"][:U])
+        grads_trunk = [None] * (2 * n)
+        for i in reversed(range(n)):
+            if i % cfg.skip_layer == 0 and i > 0:
+                dh = dh[:, :cfg.dense_units]
+            dz = dh * (cache["outs"][i] > 0).astype(dh.dtype)
+            grads_trunk[2 * i] = mmT(cache["ins"][i], dz)
+            grads_trunk[2 * i + 1] = _rb(dz).sum(0)
+            if i > 0:
+                dh = mmW(dz, params[2 * i])
+        return grads_trunk + [g_ks, g_bs, g_kf, g_bf, g_kr, g_br, g_kc, g_bc]
     g_kc, g_bc = mmT(cache["f2"], dzc), dzc.sum(0)
     df2 = mmW(dzc, kc)
     g_kr, g_br = mmT(cache["fcat"], df2), df2.sum(0)

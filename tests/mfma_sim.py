@@ -57,7 +57,17 @@ def bias_acc(bias_tab, flat, tile):
 
 
 FWD_STAGES = [(0, 4, 8), (32, 16, 8), (160, 16, 8), (288, 16, 8), (416, 16, 8), (544, 20, 8), (704, 16, 8), (832, 16, 8),
-              (960, 16, 9), (1104, 18, 4), (1176, 8, 1)]
+              (960, 18, 1)]
+N_PARAMS, HEAD_ROWS, AUX_M, AUX_S, AUX_COUNT = 595844, 288, 0, 283 * 3, 864
+
+
+def extended_weights(params, cfg):
+    """[flat parameters | composed head matrix [288,4] | head bias [4]]: what optim.hip head_compose leaves in a net's
+    weight buffer (csrc/layout.h "collapsed head"), here from the oracle's head_compose"""
+    from oracle import nerf_oracle as O
+    H, hb = O.head_compose(params, cfg)
+    Hp = np.zeros((HEAD_ROWS, 4), np.float32); Hp[:H.shape[0]] = H
+    return np.concatenate([O.flatten_params(params), Hp.reshape(-1), hb.astype(np.float32)])
 
 
 def forward_chain(fwd_tab, bias_tab, flat, p, d):
@@ -86,23 +96,20 @@ def forward_chain(fwd_tab, bias_tab, flat, p, d):
     for st in range(1, 8):
         inp = x + enc if st == 5 else x
         x, raw = stage(st, inp, True); act[st] = x; masks[st] = [r > 0 for r in raw]
-    fs, raw = stage(8, x, False)
-    feat = fs[:16]
-    sigma = np.maximum(raw[8][:32, 0], 0)          # half 0, reg 0 = row 0
-    f2, _ = stage(9, feat + dirc, False)
-    _, raw = stage(10, f2, False)
-    z = raw[0][:32, :3]
-    rgb = 1.0 / (1.0 + np.exp(-z))
-    return rgb, sigma, dict(enc=enc, dirc=dirc, h=act, feat=feat, f2=f2, masks=masks)
+    _, raw = stage(8, x + dirc, False)             # head: one out tile, rows r, g, b, sigma (half 0, regs 0..3)
+    z = raw[0][:32, :4]
+    rgb = 1.0 / (1.0 + np.exp(-z[:, :3]))
+    sigma = np.maximum(z[:, 3], 0)
+    return rgb, sigma, dict(enc=enc, dirc=dirc, h=act, masks=masks)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # backward: dgrad chain + saved blocks + wgrad (transposed LDS reads), mirroring mlp_bwd.hip / wgrad.hip
 # ---------------------------------------------------------------------------------------------------------------
-BWD_STAGES = [(0, 1, 4), (4, 8, 8), (68, 17, 8)] + [(204 + 128 * i, 16, 8) for i in range(7)]
+BWD_STAGES = [(0, 1, 8)] + [(8 + 128 * i, 16, 8) for i in range(7)]
 ACT_H = lambda l: 16 * l if l <= 4 else 84 + 16 * (l - 5)
-K_ACT_ENC, K_ACT_H7, K_ACT_FEAT, K_ACT_DIR, K_ACT_F2, K_ACT_BLOCKS = 80, 116, 132, 148, 150, 158
-K_DZ_FEAT, K_DZ_SIG, K_DZ_F2, K_DZ_RGB, K_DZ_BLOCKS = 128, 144, 146, 154, 156
+K_ACT_ENC, K_ACT_H7, K_ACT_DIR, K_ACT_BLOCKS = 80, 116, 132, 134
+K_DZ_HEAD, K_DZ_BLOCKS = 128, 130
 
 
 def saved_block_image(frag, blk):
@@ -116,7 +123,7 @@ def saved_block_image(frag, blk):
 
 
 def act_run(saved):
-    """forward_chain's saved dict -> [158*512] memory image of one tile's act run"""
+    """forward_chain's saved dict -> [134*512] memory image of one tile's act run"""
     run = np.zeros(K_ACT_BLOCKS * 512, np.float32)
 
     def put(b0, frags):
@@ -124,23 +131,23 @@ def act_run(saved):
             run[(b0 + i) * 512:(b0 + i + 1) * 512] = saved_block_image(f, b0 + i)
     for l in range(8):
         put(ACT_H(l), saved["h"][l])
-    put(K_ACT_ENC, saved["enc"]); put(K_ACT_DIR, saved["dirc"]); put(K_ACT_FEAT, saved["feat"]); put(K_ACT_F2, saved["f2"])
+    put(K_ACT_ENC, saved["enc"]); put(K_ACT_DIR, saved["dirc"])
     return run
 
 
 def backward_chain(bwd_tab, flat, rgb, sigma, drgb, dsigma, masks):
-    """Mirror of mlp_bwd_kernel for one wave.  Returns the dz run memory image [156*512]."""
+    """Mirror of mlp_bwd_kernel for one wave.  Returns the dz run memory image [130*512]."""
     frags = gather_blocks(bwd_tab, flat)
     run = np.zeros(K_DZ_BLOCKS * 512, np.float32)
 
     def put(b0, fr):
         for i, f in enumerate(fr):
             run[(b0 + i) * 512:(b0 + i + 1) * 512] = saved_block_image(f, b0 + i)
-    zrgb = np.zeros((64, 8), np.float32); zsig = np.zeros((64, 8), np.float32)
-    zrgb[:32, :3] = drgb * rgb * (1 - rgb)
-    zsig[:32, 0] = np.where(sigma > 0, dsigma, 0)
-    zrgb, zsig = round_bf16(zrgb), round_bf16(zsig)
-    put(K_DZ_RGB, [zrgb]); put(K_DZ_SIG, [zsig])
+    zhead = np.zeros((64, 8), np.float32)
+    zhead[:32, :3] = drgb * rgb * (1 - rgb)
+    zhead[:32, 3] = np.where(sigma > 0, dsigma, 0)
+    zhead = round_bf16(zhead)
+    put(K_DZ_HEAD, [zhead])
 
     def stage(st, inputs, mask=None):
         b0, nks, n_ot = BWD_STAGES[st]
@@ -154,11 +161,9 @@ def backward_chain(bwd_tab, flat, rgb, sigma, drgb, dsigma, masks):
             lo, hi = pack_acc(acc)
             outs += [lo, hi]
         return outs
-    df2 = stage(0, [zrgb]); put(K_DZ_F2, df2)
-    dfeat = stage(1, df2); put(K_DZ_FEAT, dfeat)
-    dz = stage(2, dfeat + [zsig], masks[7]); put(16 * 7, dz)
-    for st in range(3, 10):
-        layer = 6 - (st - 3)
+    dz = stage(0, [zhead], masks[7]); put(16 * 7, dz)
+    for st in range(1, 8):
+        layer = 6 - (st - 1)
         dz = stage(st, dz, masks[layer]); put(16 * layer, dz)
     return run
 
@@ -186,15 +191,32 @@ def tr_frag(region, pair, kk):
     return np.concatenate([tr_read(region, base + lane_off[0]), tr_read(region, base + lane_off[1])], axis=1)
 
 
-WGRAD_JOBS = {0: (K_ACT_ENC, 2, 0, 8), 5: (64, 10, 80, 8), 8: (K_ACT_H7, 8, K_DZ_FEAT, 8), 9: (K_ACT_H7, 8, K_DZ_SIG, 1),
-              10: (K_ACT_FEAT, 9, K_DZ_F2, 4), 11: (K_ACT_F2, 4, K_DZ_RGB, 1)}
+WGRAD_JOBS = {0: (K_ACT_ENC, 2, 0, 8), 5: (64, 10, 80, 8), 8: (K_ACT_H7, 9, K_DZ_HEAD, 1)}
 for _j in (1, 2, 3, 4, 6, 7):
     WGRAD_JOBS[_j] = (ACT_H(_j - 1), 8, 16 * _j, 8)
 
 
-def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params):
-    """Mirror of wgrad_kernel over a list of tiles: returns the flat gradient."""
-    grad = np.zeros(n_params, np.float64)
+def head_expand(w_ext, aux, grad):
+    """Mirror of optim.hip head_expand_kernel: aux sums -> += gradients of features / rgb_features / rgb (fp32)"""
+    f = np.float32
+    o = 63 * 256 + 256 + 4 * (256 * 256 + 256) + (319 * 256 + 256) + 2 * (256 * 256 + 256)
+    k_bs = o + 256; k_wf = k_bs + 1; k_bf = k_wf + 256 * 256; k_wr = k_bf + 256; k_br = k_wr + 283 * 128; k_wc = k_br + 128; k_bc = k_wc + 384
+    assert k_bc + 3 == N_PARAMS
+    Wf = w_ext[k_wf:k_bf].reshape(256, 256); bf = w_ext[k_bf:k_wr]; Wr = w_ext[k_wr:k_br].reshape(283, 128); br = w_ext[k_br:k_wc]
+    Wc = w_ext[k_wc:k_bc].reshape(128, 3)
+    M = aux[AUX_M:AUX_M + 283 * 3].reshape(283, 3).astype(f); s3 = aux[AUX_S:AUX_S + 3].astype(f)
+    P1 = Wr[:256] @ Wc
+    Q = Wf.T @ M[:256] + np.outer(bf, s3)
+    grad[k_wf:k_bf] += (M[:256] @ P1.T).reshape(-1); grad[k_bf:k_wr] += s3 @ P1.T
+    grad[k_wr:k_br] += (np.concatenate([Q, M[256:]], 0) @ Wc.T).reshape(-1); grad[k_br:k_wc] += s3 @ Wc.T
+    grad[k_wc:k_bc] += (Wr[:256].T @ Q + Wr[256:].T @ M[256:] + np.outer(br, s3)).reshape(-1); grad[k_bc:k_bc + 3] += s3
+    return grad
+
+
+def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext):
+    """Mirror of wgrad_kernel over a list of tiles + head_expand: returns the flat gradient.  Destinations >= n_params
+    address the head accumulator (csrc/layout.h kAuxBase)."""
+    grad = np.zeros(n_params + AUX_COUNT, np.float64)
     ones = np.ones((64, 8), np.float32)
     for jb, (ab, n_it, db, n_ot) in WGRAD_JOBS.items():
         dst = dst_tab[job_off[jb]:job_off[jb + 1]].reshape(n_it * 32 + 1, n_ot * 32)
@@ -221,4 +243,4 @@ def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params):
                     d = dst[n_it * 32, 32 * ot + c]
                     if d >= 0:
                         grad[d] += A[l, 0]
-    return grad.astype(np.float32)
+    return head_expand(w_ext, grad[n_params:].astype(np.float32), grad[:n_params].astype(np.float32))

@@ -10,10 +10,16 @@ from keras_nerf_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "knerf.h")).read()
+def declared_symbols(header="knerf.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(knerf_[a-z_]+)\s*\(", text)))
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(x.split()[-1] for x in out.splitlines() if re.search(r" T knerf_", x))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -24,6 +30,29 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/knerf.h but not exported by libknerf_hip.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in keras_nerf_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
+    assert exported(_lib.LIB_PATH) == names            # nothing else leaves the product library under the knerf_ prefix
+
+
+def test_diagnostics_live_in_their_own_library():
+    """include/knerf_debug.h + libknerf_probe.so: layout introspection, workspace views and hardware probes for tests/ and
+    tools/.  The product header and library carry no debug entry point and product code never loads the probe library."""
+    from keras_nerf_amd import debug
+    assert not [n for n in declared_symbols() if "debug" in n or "probe" in n]
+    assert not [n for n in exported(_lib.LIB_PATH) if "debug" in n]
+    names = declared_symbols("knerf_debug.h")
+    assert len(names) >= 7 and all(n.startswith("knerf_debug_") for n in names)
+    assert exported(debug.PROBE_PATH) == names == sorted(debug.SIGNATURES)
+    lib = debug.load()
+    for n in names:
+        assert hasattr(lib, n)
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "keras_nerf_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "debug.py":
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"libknerf_probe|^\s*from\s+\.+\s*import\s+debug\b|^\s*from\s+\.+debug\s+import|import\s+keras_nerf_amd\.debug", src, flags=re.M):
+                    bad.append(f)
+    assert bad == ["build.py"] or not bad, bad          # build.py names the file it links
 
 
 def test_no_cpu_fallback_create_fails_loudly_without_gpu():
@@ -77,15 +106,17 @@ def test_general_shape_layer_program_matches_the_keras_layer_list():
     """csrc/generic.hip build_plan (host code, no device): offsets, shapes, concat segments and paddings of every Dense layer
     against the layer list of mlp.py:11-27 for several shapes"""
     import numpy as np
+    from keras_nerf_amd import debug
     from keras_nerf_amd.model.nerf.mlp import layer_shapes
     lib = _lib.load()
+    dbg = debug.load()
     r32 = lambda v: (v + 31) // 32 * 32
     for nl, u, sk, lx, ld in ((8, 256, 4, 10, 4), (4, 128, 2, 6, 2), (3, 64, 1, 4, 1), (2, 96, 4, 10, 4), (5, 160, 3, 12, 5), (1, 2, 1, 0, 0)):
         cfg = _lib.KnerfConfig(64, 128, lx, ld, nl, u, sk, 0, 0, 1e-3, 0.9, 0.999, 1e-7)
         n = C.c_size_t(0)
-        assert lib.knerf_debug_generic_plan(C.byref(cfg), None, C.byref(n)) == 0
+        assert dbg.knerf_debug_generic_plan(C.byref(cfg), None, C.byref(n)) == 0
         buf = (C.c_int32 * n.value)()
-        assert lib.knerf_debug_generic_plan(C.byref(cfg), buf, C.byref(n)) == 0
+        assert dbg.knerf_debug_generic_plan(C.byref(cfg), buf, C.byref(n)) == 0
         rows = np.array(buf[:]).reshape(-1, 16)
         xyz, dr = 3 + 6 * lx, 3 + 6 * ld
         shapes = layer_shapes(nl, u, sk, xyz, dr)

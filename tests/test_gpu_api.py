@@ -28,7 +28,7 @@ def test_predict_and_render_images_shapes_and_values(model):
     coarse, fine = nerf.predict_and_render_images((P["o"], P["d"], P["t"]), u=P["u"])
     assert coarse["image"].shape == (2, 16, 16, 3) and coarse["depth"].shape == (2, 16, 16) and coarse["weights"].shape == (2, 16, 16, 64)
     assert fine["image"].shape == (2, 16, 16, 3) and fine["weights"].shape == (2, 16, 16, 192)
-    c, f = O.predict_and_render_images(P["cp"], P["fp"], P["o"], P["d"], P["t"], P["u"], P["cfg"], 128, True, emulate_bf16=True)
+    c, f = O.predict_and_render_images(P["cp"], P["fp"], P["o"], P["d"], P["t"], P["u"], P["cfg"], 128, True, emulate_bf16=O.FUSED)
     np.testing.assert_allclose(coarse["image"].cpu().numpy(), c["image"], atol=1e-2)
     assert O.psnr(fine["image"].cpu().numpy(), f["image"]).min() > 30.0
     img = fine["image"].cpu().numpy()
@@ -169,7 +169,7 @@ def test_nerf_mlp_call_shapes():
     x = np.random.default_rng(0).random((64, 63), dtype=np.float32) * 2 - 1
     dd = np.random.default_rng(1).random((64, 27), dtype=np.float32) * 2 - 1
     params = m.get_weights()
-    er, es = O.mlp_forward(params, x, dd, cfg, emulate_bf16=True)
+    er, es = O.mlp_forward(params, x, dd, cfg, emulate_bf16=O.FUSED)
     gr, gs = m((x, dd))
     np.testing.assert_allclose(gr.cpu().numpy(), er, atol=2e-3)
     np.testing.assert_allclose(gs.cpu().numpy(), es, atol=2e-3)

@@ -10,6 +10,7 @@ cfg4 needs eight GPUs and is the driver's to run; its per-GPU work is cfg2's wit
 """
 import numpy as np
 import pytest
+from keras_nerf_amd.debug import debug_buffer
 import torch
 
 from oracle import nerf_oracle as O
@@ -36,16 +37,16 @@ def check_grads_against_oracle(tag, g, n, loss, cfg, white, coarse_args, fine_ar
     GRAD_TOL_EMU; against the fp32 oracle (the reference's arithmetic) to GRAD_TOL_FP32, where the problem itself must be
     well conditioned (the oracle's own bf16-vs-fp32 gap is asserted to stay under that tolerance too)"""
     ref = {}
-    for emu in (True, False):
+    for emu in (O.FUSED, False):
         for k, a in (("c", coarse_args), ("f", fine_args)):
             _, l, gr = O.chunk_loss_and_grads(a[0], a[1], a[2], a[3], a[4], cfg, white, emulate_bf16=emu)
             ref[k, emu] = (float(l), O.flatten_params(gr))
-    for emu, tol in ((True, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
+    for emu, tol in ((O.FUSED, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
         ec, ef = per_tensor_err(g[:n], ref["c", emu][1], cfg), per_tensor_err(g[n:], ref["f", emu][1], cfg)
         log_stats(f"{tag}_grads_emulate_{emu}", coarse_worst=ec[0], fine_worst=ef[0])
         assert ec[0] < tol and ef[0] < tol, (emu, ec, ef)
         assert abs(float(loss[0]) - ref["c", emu][0]) < 2e-3 and abs(float(loss[1]) - ref["f", emu][0]) < 2e-3
-    gap = max(per_tensor_err(ref[k, True][1], ref[k, False][1], cfg)[0] for k in "cf")
+    gap = max(per_tensor_err(ref[k, O.FUSED][1], ref[k, False][1], cfg)[0] for k in "cf")
     log_stats(f"{tag}_oracle_bf16_vs_fp32_gap", gap=gap)
     assert gap < GRAD_TOL_FP32, gap
 
@@ -79,10 +80,10 @@ def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
     assert len(set(idx // R)) == 16
     g = lambda x: x.cpu().numpy()[idx]
     so, sd, st, su = g(of), g(df), g(tf_), g(u)
-    rc = O.predict_and_render_chunk_single(cp, so, sd, st, cfg, True, emulate_bf16=True)
+    rc = O.predict_and_render_chunk_single(cp, so, sd, st, cfg, True, emulate_bf16=O.FUSED)
     ci, cw, tfine = g(buf["c_image"]), g(buf["c_weights"]), g(buf["t_fine"])
     np.testing.assert_array_equal(tfine, O.fine_points(st, cw, su, "zero"))          # sampler + 192-way merge: bit exact
-    rf = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True, emulate_bf16=True)
+    rf = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True, emulate_bf16=O.FUSED)
     rf32 = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True)
     fi, fw = g(buf["f_image"]), g(buf["f_weights"])
     log_stats("cfg5_render_256", c_img=np.abs(ci - rc["image"]).max(), c_w=np.abs(cw - rc["weights"]).max(),
@@ -137,7 +138,7 @@ def test_cfg3_400x400_ten_chunks_of_16000():
     loss = torch.zeros(2, device="cuda")
     ctx.train_chunk(so, sd, st, sg, su, loss=loss)
     g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
-    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:192 * 192].reshape(192, 192)
+    t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:192 * 192].reshape(192, 192)
     so, sd, st, sg = (x.cpu().numpy() for x in (so, sd, st, sg))
     check_grads_against_oracle("cfg3_subchunk", g, n, loss, cfg, True, (cp, so, sd, st, sg), (fp, so, sd, t_fine, sg))
     # the class-level step at this size (nerf.py:332-473)
@@ -166,7 +167,7 @@ def test_coarse_only_configuration_trains_both_nets_against_oracle():
     loss = torch.zeros(2, device="cuda")
     ctx.train_chunk(o, d, t, img, None, loss=loss)
     g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
-    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:N * 64].reshape(N, 64)
+    t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * 64].reshape(N, 64)
     np.testing.assert_array_equal(t_fine, t)
     check_grads_against_oracle("coarse_only_train", g, n, loss, cfg, False, (cp, o, d, t, img), (fp, o, d, t, img))
     ctx.apply_adam()

@@ -51,7 +51,7 @@ def test_coarse_forward_chunk(ctx_and_problem):
     ctx, P = ctx_and_problem
     o, d, t, u = flat(P)
     img, depth, w = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
-    ref_b = O.predict_and_render_chunk_single(P["cp"], o, d, t, P["cfg"], True, emulate_bf16=True)
+    ref_b = O.predict_and_render_chunk_single(P["cp"], o, d, t, P["cfg"], True, emulate_bf16=O.FUSED)
     ref_f = O.predict_and_render_chunk_single(P["cp"], o, d, t, P["cfg"], True)
     log_stats("coarse_forward_chunk", img_vs_bf16=np.abs(img - ref_b["image"]).max(), w_vs_bf16=np.abs(w - ref_b["weights"]).max(),
               img_vs_fp32=np.abs(img - ref_f["image"]).max(), w_vs_fp32=np.abs(w - ref_f["weights"]).max(),
@@ -97,11 +97,11 @@ def test_render_chunk_coarse_to_fine(ctx_and_problem):
     ctx, P = ctx_and_problem
     o, d, t, u = flat(P)
     out = {k: v.cpu().numpy() for k, v in ctx.render_chunk(o, d, t, u).items()}
-    c, f = O.predict_and_render_chunk(P["cp"], P["fp"], o, d, t, u, P["cfg"], True, "zero", emulate_bf16=True)
+    c, f = O.predict_and_render_chunk(P["cp"], P["fp"], o, d, t, u, P["cfg"], True, "zero", emulate_bf16=O.FUSED)
     np.testing.assert_allclose(out["c_image"], c["image"], atol=1e-2)
     np.testing.assert_allclose(out["c_weights"], c["weights"], atol=1e-2)
     # the fine t-values depend on the coarse weights (bf16-level differences) -> compare fine outputs on the GPU's own t
-    f2 = O.predict_and_render_chunk_single(P["fp"], o, d, out["t_fine"], P["cfg"], True, emulate_bf16=True)
+    f2 = O.predict_and_render_chunk_single(P["fp"], o, d, out["t_fine"], P["cfg"], True, emulate_bf16=O.FUSED)
     log_stats("render_chunk_fine", img_vs_bf16=np.abs(out["f_image"] - f2["image"]).max(),
               w_vs_bf16=np.abs(out["f_weights"] - f2["weights"]).max())
     np.testing.assert_allclose(out["f_image"], f2["image"], atol=1e-2)
@@ -137,7 +137,7 @@ def test_ragged_ray_count(ctx_and_problem):
     o, d, t, u = flat(P)
     n = 37
     img, depth, w = [x.cpu().numpy() for x in ctx.forward_chunk(0, o[:n], d[:n], t[:n, :50].copy())]
-    ref = O.predict_and_render_chunk_single(P["cp"], o[:n], d[:n], t[:n, :50], P["cfg"], True, emulate_bf16=True)
+    ref = O.predict_and_render_chunk_single(P["cp"], o[:n], d[:n], t[:n, :50], P["cfg"], True, emulate_bf16=O.FUSED)
     np.testing.assert_allclose(img, ref["image"], atol=1e-2)
     np.testing.assert_allclose(w, ref["weights"], atol=1e-2)
 

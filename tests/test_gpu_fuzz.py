@@ -2,6 +2,7 @@
 tile or the 256-sample workgroup, odd sample counts, both backgrounds and out-of-range modes, several chunkings."""
 import numpy as np
 import pytest
+from keras_nerf_amd.debug import debug_buffer
 import torch
 
 from oracle import nerf_oracle as O
@@ -34,7 +35,7 @@ def test_random_configuration_matches_oracle(case):
     ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, white_background=case["white"], oob=case["oob"])
     ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
     ci, cd, cw = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
-    rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, case["white"], emulate_bf16=True)
+    rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, case["white"], emulate_bf16=O.FUSED)
     np.testing.assert_allclose(ci, rc["image"], atol=1e-2)
     np.testing.assert_allclose(cw, rc["weights"], atol=1e-2)
     if case["n_fine"] == 0:
@@ -42,12 +43,12 @@ def test_random_configuration_matches_oracle(case):
     loss = torch.zeros(2, device="cuda")
     ctx.train_chunk(o, d, t, img, u, loss=loss)
     S = cfg.n_coarse + cfg.n_fine
-    t_fine = ctx.debug_buffer(5).view(torch.float32).cpu().numpy()[:R * S].reshape(R, S)
-    w_c = ctx.debug_buffer(6).view(torch.float32).cpu().numpy()[:R * cfg.n_coarse].reshape(R, cfg.n_coarse)
+    t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:R * S].reshape(R, S)
+    w_c = debug_buffer(ctx, 6).view(torch.float32).cpu().numpy()[:R * cfg.n_coarse].reshape(R, cfg.n_coarse)
     np.testing.assert_array_equal(t_fine, O.fine_points(t, w_c, u, case["oob"]))          # sampler + sort: bit exact
     g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
-    _, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, case["white"], emulate_bf16=True)
-    _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, case["white"], emulate_bf16=True)
+    _, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, case["white"], emulate_bf16=O.FUSED)
+    _, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, case["white"], emulate_bf16=O.FUSED)
     ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
     log_stats("fuzz_" + "_".join(f"{k}{v}" for k, v in case.items() if k != "seed"), coarse_worst=ec[0], fine_worst=ef[0])
     tol = 8e-2 if R * cfg.n_coarse < 2048 else 5e-2          # few samples: the bf16 roundings do not average out

@@ -18,8 +18,8 @@ def _p(t):
 
 
 def test_mfma_32x32x16_bf16_lane_maps():
-    from keras_nerf_amd import _lib
-    lib = _lib.load()
+    from keras_nerf_amd import debug
+    lib = debug.load()
     rng = np.random.default_rng(0)
     a = rng.integers(-4, 5, (64, 8)).astype(np.float32)      # small integers: exact in bf16 and in the f32 sums
     b = rng.integers(-4, 5, (64, 8)).astype(np.float32)      # asymmetric on purpose
@@ -45,8 +45,8 @@ def tr_expected(img_u16, addr):
 
 
 def test_ds_read_b64_tr_b16_semantics():
-    from keras_nerf_amd import _lib
-    lib = _lib.load()
+    from keras_nerf_amd import debug
+    lib = debug.load()
     rng = np.random.default_rng(1)
     img = np.arange(2048, dtype=np.uint16)
     addr = (rng.permutation(512)[:64] * 8).astype(np.int32)

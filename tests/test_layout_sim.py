@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from keras_nerf_amd import _lib
+from keras_nerf_amd import debug as D
 from oracle import nerf_oracle as O
 from tests import mfma_sim as M
 
@@ -15,7 +16,7 @@ def setup():
     params = O.init_params(cfg, 11)
     for b in params[1::2]:
         b += rng.normal(0, 0.05, b.shape).astype(np.float32)
-    flat = O.flatten_params(params)
+    flat = M.extended_weights(params, cfg)       # parameters + the composed head (csrc/layout.h)
     o = rng.normal(0, 1.5, (32, 3)).astype(np.float32)
     d = rng.normal(0, 1, (32, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=-1, keepdims=True)
     t = rng.uniform(2, 6, (32, 1)).astype(np.float32)
@@ -24,27 +25,33 @@ def setup():
 
 
 def test_tables_cover_every_parameter_exactly_where_expected():
-    fwd, bias = _lib.debug_table(0), _lib.debug_table(1)
+    fwd, bias = D.debug_table(0), D.debug_table(1)
     n = _lib.load().knerf_param_count()
     used = np.zeros(n, bool)
-    used[fwd[fwd >= 0]] = True
-    used[bias[bias >= 0]] = True
-    assert used.all()                                   # every weight and bias is reachable by the forward stream
+    used[fwd[(fwd >= 0) & (fwd < n)]] = True
+    used[bias[(bias >= 0) & (bias < n)]] = True
+    # the trunk (layer_0..7) is streamed tensor by tensor; the four tensors behind it (sigma, features, rgb_features, rgb)
+    # reach the kernels through the composed head matrix [283 real rows][4] + bias [4] stored behind the parameters
+    n_trunk = 63 * 256 + 256 + 4 * (256 * 256 + 256) + (319 * 256 + 256) + 2 * (256 * 256 + 256)
+    assert used[:n_trunk].all() and not used[n_trunk:].any()
+    head = np.concatenate([fwd[fwd >= n], bias[bias >= n]]) - n
+    assert sorted(head) == sorted([r * 4 + c for r in range(283) for c in range(4)] + [288 * 4 + c for c in range(4)])
     vals, counts = np.unique(fwd[fwd >= 0], return_counts=True)
     assert counts.max() == 1                            # and appears once
-    assert fwd.size == 1184 * 512 and bias.size == 78 * 32
-    bwd = _lib.debug_table(2)
-    assert bwd.size == 1100 * 512
+    assert fwd.size == 978 * 512 and bias.size == 65 * 32
+    bwd = D.debug_table(2)
+    assert bwd.size == 904 * 512
     vals, counts = np.unique(bwd[bwd >= 0], return_counts=True)
     assert counts.max() == 1
+    assert sorted(bwd[bwd >= n] - n) == [r * 4 + c for r in range(256) for c in range(4)]   # dh7 = H[:256] dz_head
 
 
 def test_forward_chain_matches_oracle(setup):
     cfg, params, flat, p, d = setup
-    rgb, sigma, _ = M.forward_chain(_lib.debug_table(0), _lib.debug_table(1), flat, p, d)
+    rgb, sigma, _ = M.forward_chain(D.debug_table(0), D.debug_table(1), flat, p, d)
     xyz = O.positional_encoding(p, 10)[None]
     dire = O.positional_encoding(d, 4)[None]
-    rgb_o, sigma_o = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=True)
+    rgb_o, sigma_o = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=O.FUSED)
     np.testing.assert_allclose(rgb, rgb_o[0], atol=1e-3)   # a bf16 rounding flip of one activation moves an output by ~1e-4
     np.testing.assert_allclose(sigma, sigma_o[0, :, 0], atol=1e-3, rtol=1e-2)
     rgb32, sigma32 = O.mlp_forward(params, xyz, dire, cfg)
@@ -55,8 +62,8 @@ def test_backward_chain_and_wgrad_match_oracle(setup):
     """dgrad stream table, saved-block swizzle, transposed-read addressing and the wgrad destination tables, replayed
     on the CPU for two sample tiles, reproduce the oracle's 24 gradient tensors (bf16-emulating mode)."""
     cfg, params, flat, p, d = setup
-    fwd, bias, bwd = _lib.debug_table(0), _lib.debug_table(1), _lib.debug_table(2)
-    dst_tab, job_off = _lib.debug_table(3), _lib.debug_table(4)
+    fwd, bias, bwd = D.debug_table(0), D.debug_table(1), D.debug_table(2)
+    dst_tab, job_off = D.debug_table(3), D.debug_table(4)
     rng = np.random.default_rng(8)
     acts, dzs, xs, ds, drgbs, dsigs = [], [], [], [], [], []
     for tile in range(2):
@@ -67,10 +74,11 @@ def test_backward_chain_and_wgrad_match_oracle(setup):
         acts.append(M.act_run(saved))
         dzs.append(M.backward_chain(bwd, flat, rgb, sigma, drgb, dsig, saved["masks"]))
         xs.append(pt); ds.append(d); drgbs.append(drgb); dsigs.append(dsig)
-    grad = M.wgrad(acts, dzs, dst_tab, job_off, flat.size)
+    n_par = O.param_count(cfg)
+    grad = M.wgrad(acts, dzs, dst_tab, job_off, n_par, flat)
     xyz = O.positional_encoding(np.concatenate(xs), 10)[None]
     dire = O.positional_encoding(np.concatenate(ds), 4)[None]
-    _, _, cache = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=True, want_cache=True)
+    _, _, cache = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=O.FUSED, want_cache=True)
     g_o = O.flatten_params(O.mlp_backward(params, cache, np.concatenate(drgbs), np.concatenate(dsigs), cfg))
     scale = np.abs(g_o).max()
     err = np.abs(grad - g_o).max() / scale

@@ -96,3 +96,28 @@ def test_fp32_close_to_fp64():
     # fine pass: a searchsorted flip moves one sample continuously, so images stay close
     np.testing.assert_allclose(f32["image"], f64["image"], atol=1e-3)
     assert f32["weights"].shape == (16, cfg.n_coarse + cfg.n_fine)
+
+
+def test_collapsed_head_is_the_same_function_and_the_same_gradients(monkeypatch):
+    """The fused kernels evaluate features -> rgb_features -> rgb (all linear in the reference, mlp.py:21-24,44-48) and the
+    sigma head as one affine map of (h7, dir_enc) and recover the six head gradients from sums over samples (oracle FUSED
+    mode).  With the bf16 rounding switched off that must be the layer-by-layer computation to fp64 rounding: outputs, all
+    24 gradients, every tensor."""
+    monkeypatch.setattr(O, "_rb", lambda x: np.asarray(x))
+    cfg = O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=4, pos_emb_dir=2, n_layers=4, dense_units=32, skip_layer=2)
+    rng = np.random.default_rng(5)
+    params = [(p * 2).astype(np.float64) for p in O.init_params(cfg, 3)]
+    for b in params[1::2]:
+        b += rng.normal(0, 0.1, b.shape)
+    xyz = rng.normal(0, 1, (5, 8, cfg.xyz_dim)); dire = rng.normal(0, 1, (5, 8, cfg.dir_dim))
+    drgb = rng.normal(0, 1, (5, 8, 3)); dsig = rng.normal(0, 1, (5, 8, 1))
+    out = {}
+    for mode in (False, O.FUSED):
+        rgb, sigma, cache = O.mlp_forward(params, xyz, dire, cfg, mode, want_cache=True)
+        out[mode] = (rgb, sigma, O.mlp_backward(params, cache, drgb, dsig, cfg))
+    np.testing.assert_allclose(out[O.FUSED][0], out[False][0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(out[O.FUSED][1], out[False][1], rtol=0, atol=1e-13)
+    names = [f"{n}/{k}" for n, _, _ in O.layer_shapes(cfg) for k in ("kernel", "bias")]
+    for name, a, b in zip(names, out[O.FUSED][2], out[False][2]):
+        np.testing.assert_allclose(np.asarray(a).reshape(b.shape), b, rtol=1e-10, atol=1e-12, err_msg=name)
+        assert np.abs(b).max() > 0, name

@@ -35,7 +35,8 @@ R = args.rays
 o, d, t = o.reshape(-1, 3)[:R].contiguous(), d.reshape(-1, 3)[:R].contiguous(), t.reshape(-1, 64)[:R].contiguous()
 tgt = torch.rand((R, 3), device="cuda")
 loss = torch.zeros(2, device="cuda")
-FWD, DG, WG = 2 * 593408, 2 * (128 * 3 + 256 * 128 + 256 * 257 + 7 * 256 * 256), 2 * 593408
+TRUNK = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256       # executed MACs per sample: trunk + the composed 283x4 head
+FWD, DG, WG = 2 * (TRUNK + 283 * 4), 2 * (256 * 4 + 7 * 256 * 256), 2 * (TRUNK + 283 * 4)
 if args.shape != "8,256,4,10,4":       # FLOP per sample of an arbitrary shape: 2 x MACs of every Dense layer
     from keras_nerf_amd.model.nerf.mlp import layer_shapes
     macs = sum(i * o for _, i, o in layer_shapes(NL, NU, SK, 3 + 6 * LX, 3 + 6 * LD))
@@ -77,6 +78,6 @@ for k, (ms, n) in res.items():
     fl = FWD if "fwd" in k else DG if "bwd" in k else WG if "wgrad" in k else 0
     out[k] = {"ms": round(avg, 4), "TFLOPs": round(fl * S / (avg * 1e-3) / 1e12, 1) if fl else None}
     if "wgrad" in k:
-        out[k]["TBs"] = round(S / 32 * 318 * 1024 / (avg * 1e-3) / 1e12, 2)
+        out[k]["TBs"] = round(S / 32 * 268 * 1024 / (avg * 1e-3) / 1e12, 2)
 tot = sum(v["ms"] for k, v in out.items() if k.startswith("train_"))
 print(json.dumps({"tag": args.tag, "rays": R, "train_chunk_ms": round(tot, 3), "Mrs_per_s": round(R * 256 / tot / 1e3, 1), "kernels": out}))

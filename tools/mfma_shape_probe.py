@@ -8,7 +8,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from keras_nerf_amd import _lib
+from keras_nerf_amd import debug as _lib
 
 lib = _lib.load()
 dev = torch.device("cuda")

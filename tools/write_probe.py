@@ -3,7 +3,7 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from keras_nerf_amd import _lib
+from keras_nerf_amd import debug as _lib
 lib = _lib.load()
 wgs, blocks, stride = 3072, 158, 158 * 1024 + 256
 buf = torch.empty(wgs * 8 * stride, dtype=torch.uint8, device="cuda")
