@@ -27,7 +27,9 @@ std::string g_create_error;
 // (layer_0, head) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
 // KNERF_WGRAD_COSTS="c0,c1,...,c8" overrides the table (tuning sweeps in one gpurun call).
 std::vector<int32_t> build_wgrad_plan(int n_wg) {
-    int cost[kWgradJobs] = {109, 204, 204, 204, 204, 248, 204, 204, 130};
+    // r02 stamps (gpurun_out/r2b/stamps.json): 1180 / 2080 / 2590 / 1530 cycles per tile for layer_0 / 256x256 / layer_5 / head;
+    // head swept 100..200 (1.40 / 1.20 / 1.13 / 1.12 ms per fine launch at 100 / 130 / 160 / 200)
+    int cost[kWgradJobs] = {116, 204, 204, 204, 204, 254, 204, 204, 175};
     if (const char* e = std::getenv("KNERF_WGRAD_COSTS")) {
         int j = 0;
         for (const char* p = e; *p && j < kWgradJobs; ++j) { cost[j] = std::atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }

@@ -86,7 +86,14 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
     constexpr int G_IN = (BLK_IN + kWgWaves - 1) / kWgWaves, G_DZ = (BLK_DZ + kWgWaves - 1) / kWgWaves;
     constexpr int G = G_IN + G_DZ;                           // LDS-DMA instructions per wave per iteration (uniform)
-    constexpr int NS = (160 * 1024 - kWgScratch) / TILE_BYTES >= 4 ? 4 : 3;
+    // staged tiles: as many as LDS holds, at most KNERF_WGRAD_MAX_SLOTS -- a workgroup's rate is (bytes in flight) / (HBM
+    // latency), so the jobs with small tiles (layer_0, head: 20 KiB) need more of them in flight to keep pace with the 32 KiB ones
+#ifndef KNERF_WGRAD_MAX_SLOTS
+#define KNERF_WGRAD_MAX_SLOTS 6
+#endif
+    constexpr int NS_FIT = (160 * 1024 - kWgScratch) / TILE_BYTES;
+    constexpr int NS = NS_FIT >= KNERF_WGRAD_MAX_SLOTS ? KNERF_WGRAD_MAX_SLOTS : (NS_FIT >= 4 ? 4 : 3);
+    static_assert(G * (NS - 2) <= 60, "vmcnt immediate");
     static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
     static_assert(NO == WO, "one output tile per wave column");
 
