@@ -4,7 +4,14 @@
 (images [B,H,W,4] float32, (ray_origin [B,H,W,3], ray_direction [B,H,W,3], sample_points [B,H,W,N])) exactly like the
 reference's zipped/shuffled/batched tf.data pipeline: shuffle with a buffer of `batch_size` elements, batches of
 `batch_size`, remainder dropped, ray jitter redrawn on every pass (the tf.data `map` re-executes per epoch).
-Images are decoded on the host (ImageLoader); rays are generated on the GPU (RaysGenerator)."""
+Images are decoded on the host (ImageLoader); rays are generated on the GPU (RaysGenerator).
+
+Data parallel (one process per GPU, reference train.py:75-93): the reference builds ONE dataset with the GLOBAL batch
+`batch_size x replicas` and Keras hands replica r images [r*b, (r+1)*b) of every global batch.  Here every rank builds the
+same dataset with the per-replica `batch_size`; all ranks draw the same shuffled order (one shared seed, buffer = global
+batch), cut it into global batches of `batch_size x world` (remainder dropped) and keep their own slice, so the replicas
+see disjoint images and the SUM all-reduce of NeRF.train_step adds gradients of different data.  The ray jitter stream is
+keyed by the rank as well."""
 from __future__ import annotations
 
 import json
@@ -31,47 +38,76 @@ class _Iterator:
         return self
 
 
+def _dist_rank_world():
+    """(rank, world size) of the torch.distributed job this process belongs to, (0, 1) outside one"""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def shuffled_order(n, buffer_size, rng):
+    """tf.data shuffle(buffer_size): keep a buffer of `buffer_size` elements, emit a random one, refill in order"""
+    buf, out, nxt = [], [], 0
+    while nxt < n or buf:
+        while nxt < n and len(buf) < buffer_size:
+            buf.append(nxt); nxt += 1
+        out.append(buf.pop(int(rng.integers(len(buf)))))
+    return out
+
+
+def replica_batches(order, batch_size, rank=0, world=1, limit=None):
+    """index lists of this replica's batches: `order` cut into global batches of batch_size x world (drop_remainder=True),
+    replica r keeps elements [r*b, (r+1)*b) of each (train.py:84-93: Keras splits the global batch along dim 0)"""
+    g = batch_size * world
+    nb = len(order) // g
+    if limit is not None:
+        nb = min(nb, limit)
+    return [order[k * g + rank * batch_size:k * g + (rank + 1) * batch_size] for k in range(nb)]
+
+
 class RayImageDataset:
-    def __init__(self, image_paths, camera_params, image_loader, rays_generator_factory, batch_size, seed=0, limit=None):
+    def __init__(self, image_paths, camera_params, image_loader, rays_generator_factory, batch_size, seed=0, limit=None,
+                 rank=None, world=None):
+        """rank / world: data-parallel placement; None = taken from torch.distributed when an iteration starts"""
         self.image_paths, self.camera_params = list(image_paths), [np.asarray(c, np.float32) for c in camera_params]
         self.image_loader, self._rg_factory, self._rg = image_loader, rays_generator_factory, None
         self.batch_size, self._rng, self._limit = batch_size, np.random.default_rng(seed), limit
+        self._rank, self._world = rank, world
         self._cache = {}
 
+    def _placement(self):
+        if self._rank is not None and self._world is not None:
+            return self._rank, self._world
+        return _dist_rank_world()
+
     def __len__(self):
-        n = len(self.image_paths) // self.batch_size
+        n = len(self.image_paths) // (self.batch_size * self._placement()[1])
         return n if self._limit is None else min(n, self._limit)
 
     def take(self, n):
         return RayImageDataset(self.image_paths, self.camera_params, self.image_loader, self._rg_factory, self.batch_size,
-                               seed=int(self._rng.integers(1 << 31)), limit=n)
+                               seed=int(self._rng.integers(1 << 31)), limit=n, rank=self._rank, world=self._world)
 
     def _image(self, i):
         if i not in self._cache:
             self._cache[i] = self.image_loader(self.image_paths[i])
         return self._cache[i]
 
-    def _order(self):
-        """tf.data shuffle(buffer_size): keep a buffer of `batch_size` elements, emit a random one, refill in order"""
-        n, buf, out, nxt = len(self.image_paths), [], [], 0
-        while nxt < n or buf:
-            while nxt < n and len(buf) < self.batch_size:
-                buf.append(nxt); nxt += 1
-            out.append(buf.pop(int(self._rng.integers(len(buf)))))
-        return out
-
     def __iter__(self):
         import torch
+        rank, world = self._placement()
         if self._rg is None:
-            self._rg = self._rg_factory()
-        order, b = self._order(), self.batch_size
-        nb = len(order) // b                                           # drop_remainder=True
-        if self._limit is not None:
-            nb = min(nb, self._limit)
+            self._rg = self._rg_factory(rank)
+        # the same order on every rank (the rngs are seeded alike and advance alike), each rank keeps its slice
+        order = shuffled_order(len(self.image_paths), self.batch_size * world, self._rng)
+        batches = replica_batches(order, self.batch_size, rank, world, self._limit)
 
         def gen():
-            for k in range(nb):
-                idx = order[k * b:(k + 1) * b]
+            for idx in batches:
                 images = np.stack([self._image(i) for i in idx])
                 o, d, t = self._rg(np.stack([self.camera_params[i] for i in idx]))
                 yield torch.as_tensor(images).to(o.device), (o, d, t)
@@ -97,10 +133,10 @@ class DatasetLoader:
             cfg = self._load_json(os.path.join(self.data_dir, f"transforms_{subset}.json"))
             focal = get_focal_from_fov(cfg["camera_angle_x"], image_width)
 
-            def factory(focal=focal, k=k):
+            def factory(rank=0, focal=focal, k=k):
                 from .rays import RaysGenerator
                 return RaysGenerator(focal_length=focal, image_width=image_width, image_height=image_height, near=near, far=far,
-                                     n_sample=n_sample, seed=1000 + k)
+                                     n_sample=n_sample, seed=1000 + k + 4096 * rank)       # replicas jitter differently
             paths, cams = self._load_image_path_and_camera_param(cfg)
             out.append(RayImageDataset(paths, cams, image_loader, factory, batch_size, seed=k))
             logging.info(f"Loaded {subset} dataset. {len(paths)} images.")

@@ -3,7 +3,11 @@
 Same artefacts: `<log_dir>/log.csv` (columns `epoch` + the 12 log keys, header written at epoch 0 only, one row per
 `update_freq` epochs), `<log_dir>/model/` checkpoints (config json only at epoch 0), PNG panels `test_{i}_{epoch}.png`,
 `test_sample_{i}_{epoch}.png`, `debug_{i}_{batch}.png` (verbose), and the resume rule `last_epoch = last CSV epoch + 1`
-(the reference's reader skips the first data row when rebuilding its loss history, callback.py:38-46; kept)."""
+(the reference's reader skips the first data row when rebuilding its loss history, callback.py:38-46; kept).
+
+Data parallel (one process per GPU): every rank keeps the loss history, only rank 0 renders panels and writes files (the
+replicas hold identical weights and `fit` has already averaged the logs); the other ranks wait at a barrier so that nobody
+runs ahead of a checkpoint that is still being written."""
 from __future__ import annotations
 
 import logging
@@ -11,6 +15,8 @@ import os
 from csv import DictReader, DictWriter
 
 import numpy as np
+
+from ... import parallel
 
 
 def _np(x):
@@ -73,6 +79,8 @@ class NeRFTrainMonitor:
             return
         logging.debug(f"Batch {batch}: {logs}")
         self.coarse_log_list_batch.append(logs["coarse_loss"]); self.fine_log_list_batch.append(logs["fine_loss"])
+        if not parallel.is_main():
+            return
         coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
         curves = [(self.coarse_log_list_batch, "blue", "solid", "Coarse Train Loss"), (self.fine_log_list_batch, "orange", "solid", "Fine Train Loss")]
         for i in range(self.batch_size):
@@ -81,7 +89,9 @@ class NeRFTrainMonitor:
     def on_epoch_end(self, epoch, logs):
         self.coarse_log_list.append(logs["coarse_loss"]); self.val_coarse_log_list.append(logs["val_coarse_loss"])
         self.fine_log_list.append(logs["fine_loss"]); self.val_fine_log_list.append(logs["val_fine_loss"])
-        if epoch % self.update_freq == 0:
+        if epoch % self.update_freq == 0 and not parallel.is_main():
+            parallel.barrier()                                     # rank 0 is writing panels, log.csv and the checkpoint
+        elif epoch % self.update_freq == 0:
             coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
             curves = [(self.coarse_log_list, "blue", "solid", "Coarse Train Loss"), (self.val_coarse_log_list, "blue", "dashed", "Coarse Val Loss"),
                       (self.fine_log_list, "orange", "solid", "Fine Train Loss"), (self.val_fine_log_list, "orange", "dashed", "Fine Val Loss")]
@@ -104,5 +114,6 @@ class NeRFTrainMonitor:
                     w.writeheader()
                 w.writerow(new_logs)
             self.model.save_model(self.log_model_dir, weights_only=(epoch != 0))   # callback.py:220-222
+            parallel.barrier()
         if self.verbose:
             self.coarse_log_list_batch, self.fine_log_list_batch = [], []

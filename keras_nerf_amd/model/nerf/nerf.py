@@ -40,17 +40,44 @@ def _is_mse(loss) -> bool:
 
 def _adam_hyper(optimizer) -> Dict[str, float]:
     """tf.keras.optimizers.get('adam') defaults (nerf.py:163-165); a dict or an object with the Keras attribute names
-    overrides them."""
+    overrides them.  Only PLAIN Adam with a constant learning rate is implemented (what the reference trains with): any
+    other optimizer, amsgrad, weight decay, gradient clipping, EMA or a learning-rate schedule is refused, not ignored."""
     h = dict(lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7)
     if optimizer is None or (isinstance(optimizer, str) and optimizer.lower() == "adam"):
         return h
-    get = optimizer.get if isinstance(optimizer, dict) else (lambda k, d=None: getattr(optimizer, k, d))
     if isinstance(optimizer, str):
         raise ValueError(f"optimizer '{optimizer}': only Adam is implemented (the reference trains with 'adam')")
+    cfg = {}
+    if isinstance(optimizer, dict):
+        cfg = dict(optimizer.get("config", optimizer))          # Keras serialised form {"class_name", "config"} or a flat dict
+        name = str(optimizer.get("class_name", cfg.get("name", "adam")))
+    else:
+        name = type(optimizer).__name__
+        if callable(getattr(optimizer, "get_config", None)):
+            try:
+                cfg = dict(optimizer.get_config())
+            except Exception:
+                cfg = {}
+        for k in ("learning_rate", "lr", "beta_1", "beta_2", "epsilon", "amsgrad", "weight_decay", "clipnorm", "clipvalue",
+                  "global_clipnorm", "use_ema"):
+            if k not in cfg and getattr(optimizer, k, None) is not None:
+                cfg[k] = getattr(optimizer, k)
+        name = str(cfg.get("name", name))
+    if name.lower() not in ("adam", "dict", "simplenamespace", "namespace"):
+        raise ValueError(f"optimizer {name}: only plain Adam is implemented (the reference trains with 'adam')")
+    for k in ("amsgrad", "weight_decay", "clipnorm", "clipvalue", "global_clipnorm", "use_ema"):
+        if cfg.get(k) not in (None, False, 0, 0.0):
+            raise ValueError(f"Adam option {k}={cfg[k]!r} is not implemented by the fused optimizer kernel")
     for src, dst in (("learning_rate", "lr"), ("lr", "lr"), ("beta_1", "beta1"), ("beta_2", "beta2"), ("epsilon", "epsilon")):
-        v = get(src, None)
-        if v is not None:
+        v = cfg.get(src)
+        if v is None:
+            continue
+        if isinstance(v, dict) or callable(v) or (hasattr(v, "get_config") and not hasattr(v, "__float__")):
+            raise ValueError(f"Adam {src}: learning-rate schedules are not implemented (constant learning rate only)")
+        try:
             h[dst] = float(v)
+        except (TypeError, ValueError):
+            raise ValueError(f"Adam {src}={v!r} is not a number (learning-rate schedules are not implemented)") from None
     return h
 
 

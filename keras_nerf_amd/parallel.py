@@ -18,6 +18,20 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def rank() -> int:
+    return dist.get_rank() if is_distributed() else 0
+
+
+def is_main() -> bool:
+    """the one process that writes logs, images and checkpoints (replicas hold identical weights and logs)"""
+    return rank() == 0
+
+
+def barrier() -> None:
+    if is_distributed():
+        dist.barrier()
+
+
 def all_reduce_gradients(flat_grads: torch.Tensor, mode: str = "sum") -> torch.Tensor:
     """In-place all-reduce of the flat gradient accumulator.  mode 'sum' = Keras/MirroredStrategy semantics (the applied
     gradient is world_size x the replica mean; train.py:130-136 leaves the 1/global_batch factor commented out);

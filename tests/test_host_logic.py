@@ -108,7 +108,8 @@ def test_dataset_loader_json_and_shuffle_semantics(tmp_path):
     assert len(tr.image_paths) == 5 and len(va.image_paths) == 2 and len(te.image_paths) == 3
     assert len(tr) == 2 and len(te) == 1                          # batch 2, drop_remainder
     assert tr.image_paths[0].endswith("train/r_0.png") and tr.camera_params[0].shape == (4, 4)
-    order = tr._order()
+    from keras_nerf_amd.data.loader import shuffled_order
+    order = shuffled_order(len(tr.image_paths), tr.batch_size, tr._rng)
     assert sorted(order) == list(range(5))
     assert all(order[k] <= k + 2 for k in range(5))                # a buffer of batch_size can pull an element at most that far forward
 
@@ -130,3 +131,51 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_hip():
     assert r.returncode != 0
     assert "only" in r.stderr and "GPU(s) visible" in r.stderr and "--gpus 2" in r.stderr
     assert "{" not in r.stdout              # no JSON line
+
+
+def test_optimizer_objects_other_than_plain_adam_are_refused_not_ignored():
+    """tf.keras.optimizers.get (nerf.py:163-165) honours any optimizer; the fused kernel is plain Adam with a constant
+    learning rate, so everything else must raise instead of silently training with Adam defaults."""
+    import types
+
+    class Adam:                                   # duck-typed tf.keras.optimizers.Adam
+        def __init__(self, **kw):
+            self.cfg = dict(name="Adam", learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False); self.cfg.update(kw)
+
+        def get_config(self):
+            return dict(self.cfg)
+
+    class SGD(Adam):
+        def __init__(self):
+            super().__init__(name="SGD", momentum=0.0)
+
+    assert N._adam_hyper(Adam(learning_rate=2e-4, beta_1=0.8)) == dict(lr=2e-4, beta1=0.8, beta2=0.999, epsilon=1e-7)
+    assert N._adam_hyper({"class_name": "Adam", "config": {"learning_rate": 3e-4}})["lr"] == 3e-4
+    assert N._adam_hyper(types.SimpleNamespace(learning_rate=1e-2, epsilon=1e-8)) == dict(lr=1e-2, beta1=0.9, beta2=0.999, epsilon=1e-8)
+    for bad in (SGD(), Adam(amsgrad=True), Adam(weight_decay=0.01), Adam(clipnorm=1.0), Adam(global_clipnorm=2.0), Adam(use_ema=True),
+                Adam(learning_rate={"class_name": "ExponentialDecay", "config": {}}), Adam(learning_rate=lambda step: 1e-3),
+                {"class_name": "RMSprop", "config": {}}):
+        with pytest.raises(ValueError):
+            N._adam_hyper(bad)
+
+
+def test_data_parallel_batches_are_disjoint_slices_of_the_global_batches():
+    """train.py:75-93: one dataset of GLOBAL batches (batch_size x replicas), replica r gets rows [r*b, (r+1)*b).  Every
+    rank derives the same shuffled order from the shared seed and keeps its slice (keras_nerf_amd/data/loader.py)."""
+    from keras_nerf_amd.data.loader import RayImageDataset, replica_batches, shuffled_order
+    n, b, world = 23, 2, 3
+    orders = [shuffled_order(n, b * world, np.random.default_rng(7)) for _ in range(world)]
+    assert orders[0] == orders[1] == orders[2] and sorted(orders[0]) == list(range(n))
+    per_rank = [replica_batches(orders[r], b, r, world) for r in range(world)]
+    single = replica_batches(orders[0], b * world)                      # what one process with the global batch would see
+    assert len(single) == n // (b * world) == len(per_rank[0])
+    for k, g in enumerate(single):
+        assert sum((per_rank[r][k] for r in range(world)), []) == g      # concatenated replica slices = the global batch
+    seen = [i for r in range(world) for bt in per_rank[r] for i in bt]
+    assert len(seen) == len(set(seen))                                   # no image is used twice in an epoch
+    # tf.data shuffle(buffer) semantics: element k of the output comes from the first k + buffer inputs
+    assert all(v < k + b * world for k, v in enumerate(orders[0]))
+    # the dataset object applies exactly that plan (no GPU needed until a batch is materialised)
+    ds = [RayImageDataset([f"img{i}" for i in range(n)], [np.eye(4)] * n, None, None, b, seed=5, rank=r, world=world) for r in range(world)]
+    assert [len(d) for d in ds] == [3, 3, 3]
+    assert len(RayImageDataset(["x"] * n, [np.eye(4)] * n, None, None, b, seed=5)) == 11     # outside a process group: world 1
