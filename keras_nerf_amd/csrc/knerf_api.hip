@@ -386,11 +386,12 @@ int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, 
     const size_t mp = gen::padded_rows((long long)n);
     gen::Workspace& w = ctx->call_ws;
     if (mp > w.mp) {
+        HIPCHK(hipStreamSynchronize(s));
         free_dev(w.act); free_dev(w.zs); free_dev(w.zc); free_dev(ctx->call_raw);
         w.mp = 0;
         const size_t ab = p.act_elems_per_row * mp * sizeof(unsigned short);
         HIPCHK(hipMalloc(&w.act, ab));
-        HIPCHK(hipMemset(w.act, 0, ab));
+        HIPCHK(hipMemsetAsync(w.act, 0, ab, s));        // on the stream the consuming kernels run on
         HIPCHK(hipMalloc(&w.zs, mp * 32 * sizeof(float)));
         HIPCHK(hipMalloc(&w.zc, mp * 32 * sizeof(float)));
         w.mp = mp;

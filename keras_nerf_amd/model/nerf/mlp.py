@@ -98,9 +98,22 @@ class NeRFMLP:
     def trainable_variables(self):
         return self.get_weights()
 
-    # the reference saves Keras HDF5 (nerf.py:63-64); h5py is not a dependency here, so the same tensors go to .npz with
-    # Keras' weight names as keys
-    def save_weights(self, path: str):
+    # ---- checkpoints.  The reference calls tf.keras.Model.save_weights / load_weights on 'coarse.h5' / 'fine.h5'
+    # (nerf.py:63-64, 132-136): Keras' HDF5 weight format.  Files named *.h5 / *.hdf5 / *.keras are written and read as
+    # REAL HDF5 in that layout (keras_nerf_amd/io/hdf5_min.py: no h5py needed), so a checkpoint trained with the reference
+    # loads here and a Keras model can load ours.  Any other name is a NumPy .npz archive keyed by Keras weight names; on
+    # load the container is told from the file's magic bytes, so round-1 checkpoints (an .npz named coarse.h5) still load.
+    def _layer_names(self):
+        return [name for name, _, _ in self._shapes]
+
+    def save_weights(self, path: str, save_format: str = None):
+        fmt = save_format or ("h5" if str(path).lower().endswith((".h5", ".hdf5", ".keras")) else "npz")
+        if fmt in ("h5", "hdf5"):
+            from ...io.hdf5_min import write_keras_weights
+            write_keras_weights(path, self.name, self._layer_names(), self.get_weights())
+            return
+        if fmt != "npz":
+            raise ValueError(f"save_format {save_format!r}: expected 'h5' or 'npz'")
         arrs = {}
         for (name, _, _), k, b in zip(self._shapes, self.get_weights()[0::2], self.get_weights()[1::2]):
             arrs[f"{name}/kernel:0"] = k
@@ -109,12 +122,21 @@ class NeRFMLP:
             np.savez(f, **arrs)
 
     def load_weights(self, path: str):
-        z = np.load(path)
+        from ...io.hdf5_min import is_hdf5, read_keras_weights
+        if is_hdf5(path):
+            raw = read_keras_weights(path, self._layer_names())
+            pairs = list(zip(raw[0::2], raw[1::2]))
+        else:
+            with open(path, "rb") as f:
+                magic = f.read(4)
+            if magic[:2] != b"PK":
+                raise ValueError(f"{path}: neither an HDF5 file (Keras save_weights) nor a NumPy .npz archive")
+            z = np.load(path)
+            pairs = [(z[f"{name}/kernel:0"], z[f"{name}/bias:0"]) for name, _, _ in self._shapes]
         ws = []
-        for name, fi, fo in self._shapes:
-            k, b = z[f"{name}/kernel:0"], z[f"{name}/bias:0"]
+        for (name, fi, fo), (k, b) in zip(self._shapes, pairs):
             if k.shape != (fi, fo) or b.shape != (fo,):
-                raise ValueError(f"{path}: {name} has shape {k.shape}, expected {(fi, fo)}")
+                raise ValueError(f"{path}: {name} has shape {k.shape} / {b.shape}, expected {(fi, fo)} / {(fo,)}")
             ws += [k, b]
         self.set_weights(ws)
 

@@ -116,7 +116,7 @@ class NeRF:
                        n_layers=self.n_layers, dense_units=self.dense_units, skip_layer=self.skip_layer)
             with open(os.path.join(path, "model_config.json"), "w") as f:
                 json.dump(cfg, f)
-        # same file names as the reference; the container is .npz with Keras weight names (h5py is not a dependency)
+        # same file names AND container as the reference: Keras-layout HDF5 (keras_nerf_amd/io/hdf5_min.py)
         self.coarse.save_weights(os.path.join(path, "coarse.h5"))
         self.fine.save_weights(os.path.join(path, "fine.h5"))
 
