@@ -13,8 +13,13 @@ int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n) {
     if (!cfg || !n || knerf_param_count_for(cfg) == 0) return KNERF_ERR_INVALID;
     const gen::Plan p = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
     std::vector<int32_t> v;
-    for (const gen::Layer& L : p.layers) {
-        const int32_t row[16] = {L.w_off, L.b_off, L.k_real, L.n_real, p.buf_ld[L.in_buf], L.np, L.n_seg, L.seg[0].col0, L.seg[0].width,
+    auto r32 = [](int v) { return (v + 31) / 32 * 32; };
+    for (size_t li = 0; li < p.layers.size(); ++li) {
+        const gen::Layer& L = p.layers[li];
+        // padded input width: the buffer's ld for the trunk layers; the four head layers are evaluated together on the composed
+        // matrix (generic.h) and own no buffer, so theirs is the width a stand-alone layer would have
+        const int in_ld = (int)li < p.n_layers ? p.buf_ld[L.in_buf] : r32(L.seg[0].width) + (L.n_seg == 2 ? r32(L.seg[1].width) : 0);
+        const int32_t row[16] = {L.w_off, L.b_off, L.k_real, L.n_real, in_ld, L.np, L.n_seg, L.seg[0].col0, L.seg[0].width,
                                  L.seg[0].wrow0, L.seg[1].col0, L.seg[1].width, L.seg[1].wrow0, L.relu, L.head, L.out_buf < 0 ? -1 : p.buf_ld[L.out_buf]};
         v.insert(v.end(), row, row + 16);
     }

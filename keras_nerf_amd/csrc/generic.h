@@ -5,6 +5,11 @@
 // constructor and CLI accept (train_single.py:30-36) runs here: one MFMA GEMM launch per Dense layer over row-major bf16
 // activations in HBM, same numerics contract as the fused path (bf16 matmul operands, fp32 accumulate, fp32 bias and
 // activation), same compositing / sampling / Adam kernels around it.  This path is about coverage, not peak speed.
+//
+// Head (round 2): sigma, features, rgb_features and rgb are evaluated as ONE GEMM on a composed [K][4] matrix, exactly as
+// on the fused path (layout.h "collapsed head") -- the identity holds for every shape because the
+// reference never puts an activation on features / rgb_features (mlp.py:21-24).  The four Keras layers stay in Plan::layers
+// for their parameter offsets; they own no buffer and no packed weights any more.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
@@ -38,8 +43,13 @@ struct Plan {
     std::vector<int> buf_ld;             // activation buffers (bf16, [Mp][ld])
     std::vector<int> dz_ld;              // dZ buffers (bf16, [Mp][ld])
     std::vector<int> concat_after;       // per trunk layer: 1 if [h ; xyz_enc] follows it
-    int buf_encx, buf_encd, buf_fcat, buf_f2, buf_trunk;
-    int dz_c, dz_head, dz_r;
+    int buf_encx, buf_encd, buf_trunk;
+    // collapsed head: the trunk buffer carries the dir encoding behind its own columns ([h ; (xyz_enc) ; dir_enc]) and is
+    // the head GEMM's input; its ld is the head's K
+    int head_K, head_dir_col0;           // columns of the trunk buffer / first dir column
+    int trunk_real;                      // rows of the sigma / features kernels: units (+ xyz_dim when a concat follows the last layer)
+    size_t head_wt_off, head_wd_off;     // packed bf16 [32][head_K] (forward) and [head_K][32] (dgrad)
+    int dz_head;                         // dZ buffer [Mp][32]: columns r, g, b, sigma
     size_t packed_elems;                 // bf16 elements of the packed-weight arena
     size_t act_elems_per_row, dz_elems_per_row;
 };
@@ -52,23 +62,33 @@ struct Workspace {             // per context, grow-only; Mp = padded sample cou
     size_t mp = 0;
     unsigned short* act = nullptr;     // all activation buffers, buffer b at act + off_b * mp
     unsigned short* dz = nullptr;
-    float* zs = nullptr;               // [Mp][32] sigma pre-activation
-    float* zc = nullptr;               // [Mp][32] rgb pre-activation
+    float* zs = nullptr;               // (unused since the head collapse; kept so that callers' allocation code stays valid)
+    float* zc = nullptr;               // [Mp][32] head pre-activations: columns r, g, b, sigma
 };
 
 struct NetDev {                // per net
-    unsigned short* packed = nullptr;  // packed bf16 weights (Wt and Wd of every layer)
+    unsigned short* packed = nullptr;  // packed bf16 weights (Wt and Wd of every trunk layer and of the composed head)
+    float* head = nullptr;             // head_floats(plan) fp32: composed head matrix [head_K][4] in buffer-column order, bias [4],
+                                       //   then scratch P [units + dir_dim][3] and Q [units][3]
+    float* gaux = nullptr;             // aux_floats(plan) fp32: head sums M [head_K][4], s [4] accumulated by the head wgrad
 };
+size_t head_floats(const Plan& p);
+size_t aux_floats(const Plan& p);
 
 // All functions enqueue on `s` and return the first HIP error.
-hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* packed, hipStream_t s);
+// composes the head (net.head) and re-packs every bf16 weight matrix (net.packed) from the flat fp32 parameters
+hipError_t pack_weights(const Plan& p, const float* w_flat, const NetDev& net, hipStream_t s);
+// net.gaux (head sums of the backward passes since the last call) -> += gradients of sigma / features / rgb_features / rgb
+// in grad_flat; gaux is zeroed
+hipError_t expand_head(const Plan& p, const NetDev& net, const float* w_flat, float* grad_flat, hipStream_t s);
 // forward over n = R*S samples: fills raw [n][4] (rgb after sigmoid, sigma after relu); keeps activations for backward
 hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
                    const float* t, long long n, int S, float* raw, hipStream_t s);
 // the same on inputs that are already positional encodings: xyz_enc [n][3+6*lx], dir_enc [n][3+6*ld] (fp32)
 hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* xyz_enc,
                            const float* dir_enc, long long n, float* raw, hipStream_t s);
-// backward from draw [n][4] (dL/d rgb, dL/d sigma): accumulates into grad_flat (fp32 atomics)
+// backward from draw [n][4] (dL/d rgb, dL/d sigma): trunk gradients accumulate into grad_flat (fp32 atomics), the head's
+// sums into net.gaux (expand_head turns them into gradients)
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
                     float* grad_flat, hipStream_t s);
 size_t padded_rows(long long n);

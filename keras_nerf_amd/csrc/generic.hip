@@ -358,20 +358,21 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     return launch_gemm_nt<1>(g, nt, s);
 }
 // ---- heads ----------------------------------------------------------------------------------------------------------
-// raw[m] = (sigmoid(zc[m][0..2]), relu(zs[m][0]))   (mlp.py:44-49)
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ zc, long long n, float* __restrict__ raw) {
+// raw[m] = (sigmoid(z[m][0..2]), relu(z[m][3])) from the head GEMM's pre-activations   (mlp.py:42-49)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ z, long long n, float* __restrict__ raw) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= n) return;
     float4 v;
-    v.x = 1.f / (1.f + expf(-zc[m * 32 + 0]));
-    v.y = 1.f / (1.f + expf(-zc[m * 32 + 1]));
-    v.z = 1.f / (1.f + expf(-zc[m * 32 + 2]));
-    v.w = fmaxf(zs[m * 32], 0.f);
+    v.x = 1.f / (1.f + expf(-z[m * 32 + 0]));
+    v.y = 1.f / (1.f + expf(-z[m * 32 + 1]));
+    v.z = 1.f / (1.f + expf(-z[m * 32 + 2]));
+    v.w = fmaxf(z[m * 32 + 3], 0.f);
     reinterpret_cast<float4*>(raw)[m] = v;
 }
-// dZ_rgb = d_rgb * y (1 - y) (sigmoid), dZ_sigma = d_sigma * [sigma > 0] (relu); rows >= n and padding columns are zero
+// dZ_head [Mp][32]: columns 0..2 = d_rgb * y (1 - y) (sigmoid), column 3 = d_sigma * [sigma > 0] (relu); rows >= n and the
+// padding columns are zero
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ draw, long long n, long long mp,
-                                                      u16* __restrict__ dzc, u16* __restrict__ dzs, int ld_s) {
+                                                      u16* __restrict__ dzh) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= mp) return;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -383,9 +384,119 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         g[2] = dy.z * y.z * (1.f - y.z);
         g[3] = y.w > 0.f ? dy.w : 0.f;
     }
-    u16* rc = dzc + (size_t)m * 32;
-    u16* rs = dzs + (size_t)m * ld_s;
-    for (int c = 0; c < 32; ++c) { rc[c] = c < 3 ? to_bf16(g[c]) : 0; rs[c] = c == 0 ? to_bf16(g[3]) : 0; }
+    u16* r = dzh + (size_t)m * 32;
+    for (int c = 0; c < 32; ++c) r[c] = c < 4 ? to_bf16(g[c]) : 0;
+}
+
+// ---- collapsed head (layout.h / DESIGN.md section 2.0) for any shape --------------------------------------------------
+// Offsets of the four head tensors in the flat parameters and the geometry of the head's input buffer.
+struct HeadGeom {
+    int ws, bs, wf, bf, wr, br, wc, bc;      // kernel / bias offsets of sigma, features, rgb_features, rgb
+    int U, u2, dir_dim, xyz_dim, Tr;         // units, units/2, encodings, rows of the sigma/features kernels
+    int up, K, dir_col0;                     // padded units, columns of the head buffer, first dir column
+    int cat_last;                            // 1: [h ; xyz_enc] precedes the dir columns
+};
+// kernel row of sigma/features for buffer column c, or -1 (padding / dir column)
+__device__ __forceinline__ int head_trunk_row(const HeadGeom& g, int c) {
+    if (c < g.up) return c < g.U ? c : -1;
+    if (g.cat_last && c < g.dir_col0) return (c - g.up) < g.xyz_dim ? g.U + (c - g.up) : -1;
+    return -1;
+}
+__device__ __forceinline__ int head_col_of_trunk_row(const HeadGeom& g, int i) { return i < g.U ? i : g.up + (i - g.U); }
+
+// head[c][0..2] = (W_f (W_r1 W_c))[row(c)] or (W_r2 W_c)[c - dir_col0], head[c][3] = w_s[row(c)] or 0; bias behind it;
+// scratch P = W_r W_c [U + dir_dim][3] behind that (kept for expand_head: the weights do not change in between).
+__global__ __launch_bounds__(1024) void head_compose_kernel(const float* __restrict__ w, float* __restrict__ head, HeadGeom g) {
+    float* H = head;
+    float* hb = head + (size_t)g.K * 4;
+    float* P = hb + 4;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < g.U + g.dir_dim; r += 1024) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float* wr = w + g.wr + (size_t)r * g.u2;
+        for (int k = 0; k < g.u2; ++k) { const float v = wr[k]; a0 += v * w[g.wc + k * 3]; a1 += v * w[g.wc + k * 3 + 1]; a2 += v * w[g.wc + k * 3 + 2]; }
+        P[r * 3] = a0; P[r * 3 + 1] = a1; P[r * 3 + 2] = a2;
+    }
+    __syncthreads();
+    for (int c = tid; c < g.K; c += 1024) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int i = head_trunk_row(g, c);
+        if (i >= 0) {
+            const float* wf = w + g.wf + (size_t)i * g.U;
+            for (int j = 0; j < g.U; ++j) { const float v = wf[j]; a0 += v * P[j * 3]; a1 += v * P[j * 3 + 1]; a2 += v * P[j * 3 + 2]; }
+            a3 = w[g.ws + i];
+        } else if (c >= g.dir_col0 && c - g.dir_col0 < g.dir_dim) {
+            const int m = g.U + (c - g.dir_col0);
+            a0 = P[m * 3]; a1 = P[m * 3 + 1]; a2 = P[m * 3 + 2];
+        }
+        H[c * 4] = a0; H[c * 4 + 1] = a1; H[c * 4 + 2] = a2; H[c * 4 + 3] = a3;
+    }
+    if (tid < 3) {
+        float c = w[g.bc + tid];
+        for (int j = 0; j < g.U; ++j) c += w[g.bf + j] * P[j * 3 + tid];
+        for (int k = 0; k < g.u2; ++k) c += w[g.br + k] * w[g.wc + k * 3 + tid];
+        hb[tid] = c;
+    }
+    if (tid == 3) hb[3] = w[g.bs];
+}
+
+// gaux = M [K][4] (buffer-column order), s [4].  Phase a (one workgroup): Q = W_f^T M1 + b_f (x) s into the scratch behind
+// P, then the rgb kernel / bias.  Phase b (grid): everything that is one short dot product per element.
+__global__ __launch_bounds__(1024) void head_expand_a_kernel(const float* __restrict__ w, const float* __restrict__ gaux, float* __restrict__ head,
+                                                            float* __restrict__ grad, HeadGeom g) {
+    const float* M = gaux;
+    const float* sv = gaux + (size_t)g.K * 4;
+    float* P = head + (size_t)g.K * 4 + 4;
+    float* Q = P + (size_t)(g.U + g.dir_dim) * 3;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < g.U; j += 1024) {
+        const float bf = w[g.bf + j];
+        float a0 = bf * sv[0], a1 = bf * sv[1], a2 = bf * sv[2];
+        for (int i = 0; i < g.Tr; ++i) {
+            const float v = w[g.wf + (size_t)i * g.U + j];
+            const float* m = M + (size_t)head_col_of_trunk_row(g, i) * 4;
+            a0 += v * m[0]; a1 += v * m[1]; a2 += v * m[2];
+        }
+        Q[j * 3] = a0; Q[j * 3 + 1] = a1; Q[j * 3 + 2] = a2;
+    }
+    __syncthreads();
+    for (int e = tid; e < g.u2 * 3; e += 1024) {          // rgb kernel [u2][3] += W_r1^T Q + W_r2^T M2 + b_r (x) s
+        const int k = e / 3, c = e % 3;
+        float a = w[g.br + k] * sv[c];
+        for (int j = 0; j < g.U; ++j) a += w[g.wr + (size_t)j * g.u2 + k] * Q[j * 3 + c];
+        for (int m = 0; m < g.dir_dim; ++m) a += w[g.wr + (size_t)(g.U + m) * g.u2 + k] * M[(size_t)(g.dir_col0 + m) * 4 + c];
+        grad[g.wc + e] += a;
+    }
+    if (tid < 3) grad[g.bc + tid] += sv[tid];
+    if (tid == 3) grad[g.bs] += sv[3];
+}
+__global__ __launch_bounds__(256) void head_expand_b_kernel(const float* __restrict__ w, const float* __restrict__ gaux, const float* __restrict__ head,
+                                                           float* __restrict__ grad, HeadGeom g) {
+    const float* M = gaux;
+    const float* sv = gaux + (size_t)g.K * 4;
+    const float* P = head + (size_t)g.K * 4 + 4;
+    const float* Q = P + (size_t)(g.U + g.dir_dim) * 3;
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n_f = (long long)g.Tr * g.U, n_r = (long long)(g.U + g.dir_dim) * g.u2;
+    if (e < n_f) {                                        // features kernel [Tr][U] += M1 P1^T
+        const int i = (int)(e / g.U), j = (int)(e % g.U);
+        const float* m = M + (size_t)head_col_of_trunk_row(g, i) * 4;
+        grad[g.wf + e] += m[0] * P[j * 3] + m[1] * P[j * 3 + 1] + m[2] * P[j * 3 + 2];
+        return;
+    }
+    e -= n_f;
+    if (e < g.U) { grad[g.bf + e] += sv[0] * P[e * 3] + sv[1] * P[e * 3 + 1] + sv[2] * P[e * 3 + 2]; return; }
+    e -= g.U;
+    if (e < n_r) {                                        // rgb_features kernel [U + dir][u2] += [Q ; M2] W_c^T
+        const int r = (int)(e / g.u2), k = (int)(e % g.u2);
+        const float* v = r < g.U ? Q + (size_t)r * 3 : M + (size_t)(g.dir_col0 + r - g.U) * 4;
+        grad[g.wr + e] += v[0] * w[g.wc + k * 3] + v[1] * w[g.wc + k * 3 + 1] + v[2] * w[g.wc + k * 3 + 2];
+        return;
+    }
+    e -= n_r;
+    if (e < g.u2) { grad[g.br + e] += sv[0] * w[g.wc + e * 3] + sv[1] * w[g.wc + e * 3 + 1] + sv[2] * w[g.wc + e * 3 + 2]; return; }
+    e -= g.u2;
+    if (e < g.Tr) grad[g.ws + e] += M[(size_t)head_col_of_trunk_row(g, (int)e) * 4 + 3];   // sigma kernel [Tr][1]
 }
 
 // ---- weight packing -------------------------------------------------------------------------------------------------
@@ -718,9 +829,12 @@ Plan build_plan(int n_layers, int units, int skip, int lx, int ld) {
         p.layers.push_back(L);
         return p.layers.back();
     };
+    bool cat_last = false;
     for (int i = 0; i < n_layers; ++i) {
         const bool cat = (i % skip == 0) && i > 0;                 // mlp.py:36-38
-        const int out = new_buf(p.up + (cat ? p.kxp : 0));
+        const bool last = i == n_layers - 1;                        // the trunk output doubles as the head's input: + dir columns
+        if (last) { cat_last = cat; p.head_dir_col0 = p.up + (cat ? p.kxp : 0); }
+        const int out = new_buf(p.up + (cat ? p.kxp : 0) + (last ? p.kdp : 0));
         add_layer(units, out, 0, -1, 1, new_dz(p.up), 0);
         p.concat_after.push_back(cat ? 1 : 0);
         prev = out;
@@ -729,27 +843,26 @@ Plan build_plan(int n_layers, int units, int skip, int lx, int ld) {
         else { n_seg = 1; fan_in = units; }
     }
     p.buf_trunk = prev;
-    p.dz_head = new_dz(p.up + 32);
-    p.dz_r = new_dz(p.u2p);
-    p.dz_c = new_dz(32);
-    // sigma and features read the trunk; their dgrad weights share one matrix Wd_head [trunk_ld][up + 32] = [features | sigma]
-    const int Ktr = p.buf_ld[p.buf_trunk];
-    {
-        Layer& Ls = add_layer(1, -1, 0, 0, 0, p.dz_head, p.up);
-        packed -= (size_t)Ktr * Ls.np;                 // give back the private Wd, use the shared one
-        const size_t shared = packed; packed += (size_t)Ktr * (p.up + 32);
-        Ls.wd_off = shared; Ls.wd_ld = p.up + 32; Ls.wd_col0 = p.up;
-        p.buf_fcat = new_buf(p.up + p.kdp);
-        Layer& Lf = add_layer(units, p.buf_fcat, 0, -1, 0, p.dz_head, 0);
-        packed -= (size_t)Ktr * Lf.np;
-        Lf.wd_off = shared; Lf.wd_ld = p.up + 32; Lf.wd_col0 = 0;
-    }
-    prev = p.buf_fcat; fan_in = units + p.dir_dim; n_seg = 2;
-    segs[0] = {0, units, 0}; segs[1] = {p.up, p.dir_dim, units};
-    p.buf_f2 = new_buf(p.u2p);
-    add_layer(u2, p.buf_f2, 0, -1, 0, p.dz_r, 0);
-    prev = p.buf_f2; fan_in = u2; n_seg = 1; segs[0] = {0, u2, 0};
-    add_layer(3, -1, 0, 1, 0, p.dz_c, 0);
+    p.head_K = p.buf_ld[p.buf_trunk];
+    p.trunk_real = units + (cat_last ? p.xyz_dim : 0);
+    p.dz_head = new_dz(32);
+    p.head_wt_off = packed; packed += (size_t)32 * p.head_K;
+    p.head_wd_off = packed; packed += (size_t)p.head_K * 32;
+    // the four head layers in Keras order (mlp.py:19-27): parameter offsets and shapes only -- they are evaluated together as the
+    // composed head and own neither buffers nor packed weights
+    auto add_head_layer = [&](int k_real, int n_real, int head, int nseg, Seg s0, Seg s1) {
+        Layer L{};
+        L.k_real = k_real; L.n_real = n_real;
+        L.w_off = off; L.b_off = off + k_real * n_real; off += k_real * n_real + n_real;
+        L.n_seg = nseg; L.seg[0] = s0; L.seg[1] = s1;
+        L.in_buf = p.buf_trunk; L.out_buf = -1; L.head = head; L.relu = 0; L.np = r32(n_real); L.dz_buf = p.dz_head;
+        p.layers.push_back(L);
+    };
+    const Seg t0 = {0, units, 0}, t1 = {p.up, p.xyz_dim, units}, none = {0, 0, 0};
+    add_head_layer(p.trunk_real, 1, 0, cat_last ? 2 : 1, t0, cat_last ? t1 : none);            // sigma
+    add_head_layer(p.trunk_real, units, -1, cat_last ? 2 : 1, t0, cat_last ? t1 : none);        // features
+    add_head_layer(units + p.dir_dim, u2, -1, 2, Seg{0, units, 0}, Seg{p.up, p.dir_dim, units}); // rgb_features: [features ; dir_enc]
+    add_head_layer(u2, 3, 1, 1, Seg{0, u2, 0}, none);                                            // rgb
     p.n_params = off;
     p.packed_elems = packed;
     p.act_elems_per_row = 0; for (int v : p.buf_ld) p.act_elems_per_row += v;
@@ -773,8 +886,25 @@ u16* dz_buf(const Plan& p, const Workspace& ws, int b) {
 #define GENCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 }  // namespace
 
-hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* packed, hipStream_t s) {
-    for (const Layer& L : p.layers) {
+namespace {
+HeadGeom head_geom(const Plan& p) {
+    const int nl = p.n_layers;
+    const Layer &Ls = p.layers[nl], &Lf = p.layers[nl + 1], &Lr = p.layers[nl + 2], &Lc = p.layers[nl + 3];
+    HeadGeom g{};
+    g.ws = Ls.w_off; g.bs = Ls.b_off; g.wf = Lf.w_off; g.bf = Lf.b_off; g.wr = Lr.w_off; g.br = Lr.b_off; g.wc = Lc.w_off; g.bc = Lc.b_off;
+    g.U = p.units; g.u2 = p.units / 2; g.dir_dim = p.dir_dim; g.xyz_dim = p.xyz_dim; g.Tr = p.trunk_real;
+    g.up = p.up; g.K = p.head_K; g.dir_col0 = p.head_dir_col0; g.cat_last = p.trunk_real > p.units ? 1 : 0;
+    return g;
+}
+}  // namespace
+
+size_t head_floats(const Plan& p) { return (size_t)p.head_K * 4 + 4 + (size_t)(p.units + p.dir_dim) * 3 + (size_t)p.units * 3; }
+size_t aux_floats(const Plan& p) { return (size_t)p.head_K * 4 + 4; }
+
+hipError_t pack_weights(const Plan& p, const float* w_flat, const NetDev& net, hipStream_t s) {
+    unsigned short* packed = net.packed;
+    for (int li = 0; li < p.n_layers; ++li) {
+        const Layer& L = p.layers[li];
         PackArgs a{};
         a.w = w_flat; a.w_off = L.w_off; a.n_real = L.n_real; a.K = p.buf_ld[L.in_buf]; a.np = L.np;
         a.n_seg = L.n_seg; a.seg[0] = L.seg[0]; a.seg[1] = L.seg[1];
@@ -783,7 +913,25 @@ hipError_t pack_weights(const Plan& p, const float* w_flat, unsigned short* pack
         a.dst = packed + L.wd_off; a.transpose = 1; a.ldd = L.wd_ld; a.col0 = L.wd_col0;
         hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long long)a.K * a.np)), dim3(256), 0, s, a);
     }
+    // the composed head: fp32 [head_K][4] in buffer-column order, then its two bf16 packings
+    hipLaunchKernelGGL(head_compose_kernel, dim3(1), dim3(1024), 0, s, w_flat, net.head, head_geom(p));
+    PackArgs a{};
+    a.w = net.head; a.w_off = 0; a.n_real = 4; a.K = p.head_K; a.np = 32; a.n_seg = 1; a.seg[0] = Seg{0, p.head_K, 0};
+    a.dst = packed + p.head_wt_off; a.transpose = 0; a.ldd = a.K; a.col0 = 0;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long long)a.K * a.np)), dim3(256), 0, s, a);
+    a.dst = packed + p.head_wd_off; a.transpose = 1; a.ldd = 32; a.col0 = 0;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long long)a.K * a.np)), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+hipError_t expand_head(const Plan& p, const NetDev& net, const float* w_flat, float* grad_flat, hipStream_t s) {
+    const HeadGeom g = head_geom(p);
+    hipLaunchKernelGGL(head_expand_a_kernel, dim3(1), dim3(1024), 0, s, w_flat, net.gaux, net.head, grad_flat, g);
+    const long long total = (long long)g.Tr * g.U + g.U + (long long)(g.U + g.dir_dim) * g.u2 + g.u2 + g.Tr;
+    hipLaunchKernelGGL(head_expand_b_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w_flat, net.gaux, net.head, grad_flat, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(net.gaux, 0, aux_floats(p) * sizeof(float), s);
 }
 
 namespace {
@@ -791,28 +939,34 @@ namespace {
 hipError_t run_layers(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, long long n, long long mp, float* raw, hipStream_t s) {
     u16* ex = act_buf(p, ws, p.buf_encx);
     u16* ed = act_buf(p, ws, p.buf_encd);
-    for (size_t li = 0; li < p.layers.size(); ++li) {
+    for (int li = 0; li < p.n_layers; ++li) {
         const Layer& L = p.layers[li];
         GemmArgs g{};
         g.A = act_buf(p, ws, L.in_buf); g.lda = p.buf_ld[L.in_buf];
         g.Bt = net.packed + L.wt_off; g.ldb = g.lda;
         g.M = mp; g.N = L.np; g.K = g.lda;
         g.bias = w_flat + L.b_off; g.n_real = L.n_real; g.relu = L.relu;
-        if (L.out_buf >= 0) { g.Cb = act_buf(p, ws, L.out_buf) + L.out_col0; g.ldc = p.buf_ld[L.out_buf]; }
-        else { g.Cf = L.head == 0 ? ws.zs : ws.zc; g.ldcf = 32; }
+        g.Cb = act_buf(p, ws, L.out_buf) + L.out_col0; g.ldc = p.buf_ld[L.out_buf];
         GENCHK(launch_gemm(g, s));
-        if ((int)li < p.n_layers && p.concat_after[li]) {
+        if (p.concat_after[li]) {
             hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kxp / 8))), dim3(256), 0, s, ex, p.kxp,
                                act_buf(p, ws, L.out_buf) + p.up, p.buf_ld[L.out_buf], mp, p.kxp);
             GENCHK(hipGetLastError());
         }
-        if (L.out_buf == p.buf_fcat) {
-            hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kdp / 8))), dim3(256), 0, s, ed, p.kdp,
-                               act_buf(p, ws, p.buf_fcat) + p.up, p.buf_ld[p.buf_fcat], mp, p.kdp);
-            GENCHK(hipGetLastError());
-        }
     }
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ws.zs, ws.zc, n, raw);
+    // head: [h ; (xyz_enc) ; dir_enc] . H -> (r, g, b, sigma) pre-activations, one GEMM on the composed matrix (generic.h)
+    u16* trunk = act_buf(p, ws, p.buf_trunk);
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kdp / 8))), dim3(256), 0, s, ed, p.kdp, trunk + p.head_dir_col0, p.head_K, mp, p.kdp);
+    GENCHK(hipGetLastError());
+    {
+        GemmArgs g{};
+        g.A = trunk; g.lda = p.head_K; g.Bt = net.packed + p.head_wt_off; g.ldb = p.head_K;
+        g.M = mp; g.N = 32; g.K = p.head_K;
+        g.bias = net.head + (size_t)p.head_K * 4; g.n_real = 4; g.relu = 0;
+        g.Cf = ws.zc; g.ldcf = 32;
+        GENCHK(launch_gemm(g, s));
+    }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ws.zc, n, raw);
     return hipGetLastError();
 }
 }  // namespace
@@ -842,14 +996,8 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
     const long long mp = (long long)padded_rows(n);
     if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
     const int nl = p.n_layers;
-    const Layer& Lsig = p.layers[nl];
-    const Layer& Lrf = p.layers[nl + 2];
-    const Layer& Lrgb = p.layers[nl + 3];
-    u16* dzc = dz_buf(p, ws, p.dz_c);
     u16* dzh = dz_buf(p, ws, p.dz_head);
-    u16* dzr = dz_buf(p, ws, p.dz_r);
-    const int ldh = p.up + 32;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, raw, draw, n, mp, dzc, dzh + p.up, ldh);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, raw, draw, n, mp, dzh);
     GENCHK(hipGetLastError());
     auto dgrad = [&](const u16* A, int lda, int K, const u16* Wd, int ldb, int N, const u16* aux, int ldaux, u16* C, int ldc) {
         GemmArgs g{};
@@ -857,14 +1005,11 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         g.aux = aux; g.ldaux = ldaux; g.Cb = C; g.ldc = ldc;
         return launch_gemm(g, s);
     };
-    // d f2 = dZ_rgb . W_rgb^T (rgb_features is linear: dZ_rf = d f2)
-    GENCHK(dgrad(dzc, 32, 32, net.packed + Lrgb.wd_off, Lrgb.wd_ld, p.u2p, nullptr, 0, dzr, p.u2p));
-    // d features = (dZ_rf . W_rf^T)[:, :units]   (features is linear; dir_enc is a constant)
-    GENCHK(dgrad(dzr, p.u2p, p.u2p, net.packed + Lrf.wd_off, Lrf.wd_ld, p.up, nullptr, 0, dzh, ldh));
-    // d trunk = [dZ_features | dZ_sigma] . [W_features | W_sigma]^T, masked by the last trunk layer's relu
+    // d trunk = dZ_head . H^T (the same product W_f (W_r1 (W_c dz_rgb)) + w_s dz_sigma the tape forms), masked by the last
+    // trunk layer's relu; only the h columns carry a gradient (xyz_enc and dir_enc are constants)
     {
         const Layer& Ll = p.layers[nl - 1];
-        GENCHK(dgrad(dzh, ldh, ldh, net.packed + Lsig.wd_off, Lsig.wd_ld, p.up, act_buf(p, ws, Ll.out_buf), p.buf_ld[Ll.out_buf],
+        GENCHK(dgrad(dzh, 32, 32, net.packed + p.head_wd_off, 32, p.up, act_buf(p, ws, Ll.out_buf), p.buf_ld[Ll.out_buf],
                      dz_buf(p, ws, Ll.dz_buf), p.up));
     }
     for (int i = nl - 2; i >= 0; --i) {
@@ -873,13 +1018,22 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         GENCHK(dgrad(dz_buf(p, ws, Ln.dz_buf), p.up, p.up, net.packed + Ln.wd_off, Ln.wd_ld, p.up, act_buf(p, ws, Li.out_buf),
                      p.buf_ld[Li.out_buf], dz_buf(p, ws, Li.dz_buf), p.up));
     }
-    for (const Layer& L : p.layers) {
+    for (int li = 0; li < nl; ++li) {
+        const Layer& L = p.layers[li];
         WgradArgs w{};
         w.X = act_buf(p, ws, L.in_buf); w.ldx = p.buf_ld[L.in_buf];
         w.Z = dz_buf(p, ws, L.dz_buf) + L.dz_col0; w.ldz = p.dz_ld[L.dz_buf];
         w.steps = mp / 32; w.grad = grad_flat; w.w_off = L.w_off; w.b_off = L.b_off; w.n_real = L.n_real;
         w.n_seg = L.n_seg; w.seg[0] = L.seg[0]; w.seg[1] = L.seg[1];
         GENCHK(launch_wgrad(w, w.ldx, L.np, s));
+    }
+    {   // head sums M = [h ; (xyz) ; dir]^T dZ_head [head_K][4] and s = column sums, into the aux buffer (expand_head)
+        WgradArgs w{};
+        w.X = act_buf(p, ws, p.buf_trunk); w.ldx = p.head_K;
+        w.Z = dzh; w.ldz = 32;
+        w.steps = mp / 32; w.grad = net.gaux; w.w_off = 0; w.b_off = p.head_K * 4; w.n_real = 4;
+        w.n_seg = 1; w.seg[0] = Seg{0, p.head_K, 0};
+        GENCHK(launch_wgrad(w, w.ldx, 32, s));
     }
     return hipSuccess;
 }

@@ -66,7 +66,7 @@ constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPa
 int repack(knerf_ctx* ctx, int n, hipStream_t s) {
     Net& N = ctx->net[n];
     if (ctx->generic) {
-        HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n].packed, s));
+        HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n], s));
         return KNERF_OK;
     }
     HIPCHK(launch_head_compose(N.w, s));          // the composed head behind the parameters (layout.h), then the bf16 streams
@@ -191,7 +191,10 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
 // the wgrad head jobs leave sums in ctx->aux; this turns them into the gradients of features / rgb_features / rgb of both
 // nets (optim.hip head_expand).  Linear in the sums, so once per batch of chunks is the same as once per chunk.
 int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
-    if (ctx->generic) return KNERF_OK;
+    if (ctx->generic) {
+        for (int n = 0; n < 2; ++n) HIPCHK(gen::expand_head(ctx->gplan, ctx->gnet[n], ctx->net[n].w, ctx->net[n].g, s));
+        return KNERF_OK;
+    }
     for (int n = 0; n < 2; ++n) HIPCHK(launch_head_expand(ctx->net[n].w, ctx->net[n].aux, ctx->net[n].g, s));
     return KNERF_OK;
 }
@@ -295,6 +298,10 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         if (ctx->generic) {
             CREATECHK(hipMalloc(&ctx->gnet[n].packed, ctx->gplan.packed_elems * sizeof(unsigned short)));
             CREATECHK(hipMemset(ctx->gnet[n].packed, 0, ctx->gplan.packed_elems * sizeof(unsigned short)));
+            CREATECHK(hipMalloc(&ctx->gnet[n].head, gen::head_floats(ctx->gplan) * sizeof(float)));
+            CREATECHK(hipMemset(ctx->gnet[n].head, 0, gen::head_floats(ctx->gplan) * sizeof(float)));
+            CREATECHK(hipMalloc(&ctx->gnet[n].gaux, gen::aux_floats(ctx->gplan) * sizeof(float)));
+            CREATECHK(hipMemset(ctx->gnet[n].gaux, 0, gen::aux_floats(ctx->gplan) * sizeof(float)));
         }
         CREATECHK(hipMalloc(&N.fwd_stream, kFwdStreamBytes));
         CREATECHK(hipMalloc(&N.bwd_stream, kBwdStreamBytes));
@@ -320,7 +327,8 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
     free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
-    free_dev(ctx->gnet[0].packed); free_dev(ctx->gnet[1].packed);
+    for (int n = 0; n < 2; ++n) { free_dev(ctx->gnet[n].packed); free_dev(ctx->gnet[n].head); free_dev(ctx->gnet[n].gaux); }
+    free_dev(ctx->call_net.head);
     free_dev(ctx->call_ws.act); free_dev(ctx->call_ws.zs); free_dev(ctx->call_ws.zc); free_dev(ctx->call_net.packed); free_dev(ctx->call_raw);
     delete ctx;
     return KNERF_OK;
@@ -380,6 +388,7 @@ int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, 
         const knerf_config& c = ctx->cfg;
         ctx->call_plan = gen::build_plan(c.n_layers, c.dense_units, c.skip_layer, c.pos_emb_xyz, c.pos_emb_dir);
         HIPCHK(hipMalloc(&ctx->call_net.packed, ctx->call_plan.packed_elems * sizeof(unsigned short)));
+        HIPCHK(hipMalloc(&ctx->call_net.head, gen::head_floats(ctx->call_plan) * sizeof(float)));
         ctx->call_plan_ok = true;
     }
     const gen::Plan& p = ctx->call_plan;
@@ -396,7 +405,7 @@ int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, 
         HIPCHK(hipMalloc(&w.zc, mp * 32 * sizeof(float)));
         w.mp = mp;
     }
-    HIPCHK(gen::pack_weights(p, ctx->net[net].w, ctx->call_net.packed, s));       // the weights may have changed since the last call
+    HIPCHK(gen::pack_weights(p, ctx->net[net].w, ctx->call_net, s));       // the weights may have changed since the last call
     HIPCHK(gen::forward_encoded(p, w, ctx->call_net, ctx->net[net].w, xyz_enc, dir_enc, (long long)n, raw, s));
     return KNERF_OK;
 }
@@ -516,6 +525,8 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream) {
     if (!ctx) return KNERF_ERR_INVALID;
     HIPCHK(hipMemsetAsync(ctx->grads, 0, 2 * (size_t)ctx->n_params * sizeof(float), (hipStream_t)stream));
     HIPCHK(hipMemsetAsync(ctx->aux, 0, 2 * (size_t)kAuxCount * sizeof(float), (hipStream_t)stream));
+    if (ctx->generic)
+        for (int n = 0; n < 2; ++n) HIPCHK(hipMemsetAsync(ctx->gnet[n].gaux, 0, gen::aux_floats(ctx->gplan) * sizeof(float), (hipStream_t)stream));
     return KNERF_OK;
 }
 

@@ -263,8 +263,8 @@ def fine_points(t_coarse, w_coarse, u, oob="zero"):
 # ``emulate_bf16`` values (a TEST AID, not reference behaviour -- the reference computes in fp32):
 #   False    fp32 (or fp64) throughout: the reference's arithmetic
 #   True     every Dense layer as written in mlp.py, matmul operands rounded to bf16, fp32 accumulate, fp32 bias and
-#            activation: the arithmetic of the general-shape HIP kernels (csrc/generic.hip)
-#   FUSED    the arithmetic of the fused default-shape kernels (csrc/mlp_fwd.hip ...): as True for the trunk; the three
+#            activation (no kernel computes exactly this any more; kept as the layer-by-layer bf16 yardstick)
+#   FUSED    the arithmetic of the HIP kernels (csrc/mlp_fwd.hip ... and csrc/generic.hip): as True for the trunk; the three
 #            linear layers behind it and the sigma head evaluated as ONE affine map of (h7, dir_enc) with a composed
 #            [283,4] matrix (see head_compose), and their gradients recovered from the sums M = [h7;dir]^T dz_rgb, s
 FUSED = "fused"
@@ -284,15 +284,18 @@ def _mm(a, w, emulate_bf16):
 def head_compose(params, cfg: NerfConfig):
     """mlp.py:21-27,42-48: features and rgb_features are LINEAR Dense layers, so
         rgb_pre = h7 (W_f W_r1 W_c) + dir_enc (W_r2 W_c) + ((b_f W_r1 + b_r) W_c + b_c),   sigma_pre = h7 w_s + b_s
-    (W_r1 = first dense_units rows of the rgb_features kernel, W_r2 = its dir rows).  Returns H [units+dir_dim, 4]
-    (columns r, g, b, sigma; the dir rows of the sigma column are zero) and the bias [4], in the dtype of the params."""
+    (W_r1 = first dense_units rows of the rgb_features kernel, W_r2 = its dir rows).  h7 is the trunk output, dense_units
+    wide -- or [h, xyz_enc] when the skip concat follows the LAST trunk layer (mlp.py:36-38), which the general-shape kernels
+    support.  Returns H [trunk_width + dir_dim, 4] (columns r, g, b, sigma; the dir rows of the sigma column are zero) and the
+    bias [4], in the dtype of the params."""
     n, U = cfg.n_layers, cfg.dense_units
     ks, bs, kf, bf, kr, br, kc, bc = params[2 * n:2 * n + 8]
+    Tr = kf.shape[0]
     P = kr @ kc                                        # [U + dir_dim, 3]
-    H = np.zeros((U + cfg.dir_dim, 4), ks.dtype)
-    H[:U, :3] = kf @ P[:U]
-    H[U:, :3] = P[U:]
-    H[:U, 3] = ks[:, 0]
+    H = np.zeros((Tr + cfg.dir_dim, 4), ks.dtype)
+    H[:Tr, :3] = kf @ P[:U]
+    H[Tr:, :3] = P[U:]
+    H[:Tr, 3] = ks[:, 0]
     hb = np.concatenate([bf @ P[:U] + br @ kc + bc, bs])
     return H, hb.astype(ks.dtype)
 
@@ -385,19 +388,20 @@ def mlp_backward(params, cache, drgb, dsigma, cfg: NerfConfig):
         # sums); the six head gradients by the chain rule through the three linear layers, in fp32 on the master weights
         U = cfg.dense_units
         kf, bf_, kr, br, kc = params[2 * n + 2], params[2 * n + 3], params[2 * n + 4], params[2 * n + 5], params[2 * n + 6]
+        Tr = kf.shape[0]                                             # trunk width: U, or U + xyz_dim behind a final skip concat
         dzs = dsigma * (cache["sigma"] > 0).astype(dsigma.dtype)
         dz4 = np.concatenate([dzc, dzs], axis=-1)
         hd = np.concatenate([cache["trunk"], cache["dd"]], axis=-1)
-        M4 = mmT(hd, dz4)                                            # [U + dir_dim, 4]
+        M4 = mmT(hd, dz4)                                            # [Tr + dir_dim, 4]
         s4 = _rb(dz4).sum(0)
-        M1, M2, s3 = M4[:U, :3], M4[U:, :3], s4[:3]
+        M1, M2, s3 = M4[:Tr, :3], M4[Tr:, :3], s4[:3]
         P1 = kr[:U] @ kc
         Q = kf.T @ M1 + np.outer(bf_, s3)                            # = sum_s features[s]^T dz_rgb[s]
         g_kc = kr[:U].T @ Q + kr[U:].T @ M2 + np.outer(br, s3); g_bc = s3
         g_kr = np.concatenate([Q, M2], axis=0) @ kc.T; g_br = s3 @ kc.T
         g_kf = M1 @ P1.T; g_bf = s3 @ P1.T
-        g_ks, g_bs = M4[:U, 3:4], s4[3:4]
-        dh = mmW(dz4, cache["H"][:U])
+        g_ks, g_bs = M4[:Tr, 3:4], s4[3:4]
+        dh = mmW(dz4, cache["H"][:Tr])
         grads_trunk = [None] * (2 * n)
         for i in reversed(range(n)):
             if i % cfg.skip_layer == 0 and i > 0:

@@ -135,9 +135,10 @@ def test_general_shape_layer_program_matches_the_keras_layer_list():
                 assert in_ld == r32(fi), name
             assert relu == (1 if name.startswith("layer_") else 0)
             assert head == {"sigma": 0, "rgb": 1}.get(name, -1)
-            # a layer's output buffer is widened by the padded xyz encoding exactly when the concat follows it (mlp.py:36-38)
+            # a layer's output buffer is widened by the padded xyz encoding exactly when the concat follows it (mlp.py:36-38);
+            # the last trunk layer's buffer also carries the dir encoding: it is the input of the composed head (generic.h)
             if name.startswith("layer_"):
                 li = int(name.split("_")[1])
                 cat = li % sk == 0 and li > 0
-                assert out_ld == r32(u) + (r32(xyz) if cat else 0), name
+                assert out_ld == r32(u) + (r32(xyz) if cat else 0) + (r32(dr) if li == nl - 1 else 0), name
         assert off == lib.knerf_param_count_for(C.byref(cfg))

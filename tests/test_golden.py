@@ -118,7 +118,7 @@ def test_hip_general_shape_path_against_small_golden():
                 g = ctx.grads_view().cpu().numpy()[:ctx.param_count].copy()
                 ctx.apply_adam()
                 m, _, _, (gc, _gf) = O.train_step(cpe, fpe, oc, of_, a5[0].astype(np.float32), a5[1], a5[2], a5[3], a5[4], cfg, 8, True,
-                                                  "zero", emulate_bf16=True)
+                                                  "zero", emulate_bf16=O.FUSED)
                 assert abs(float(loss[0]) - float(z[f"f32_step{step}_losses"][0])) < 3e-2      # fp32 fixture, bf16 operands
                 assert abs(float(loss[0]) - m["coarse_loss"]) < 1e-3                            # same rounding: tight
                 if step == 0:

@@ -63,7 +63,7 @@ def test_generic_shape_images_losses_and_gradients(name):
     fp32_tol = {"wide_enc": 0.25, "tiny32": 1.0, "no_encoding": 1.0, "deep_wide": 0.3}.get(name, 0.1)
     # 12 layers of x1.5-gain weights amplify the fp32 summation-order differences of the emulation itself (deep_wide: 1.1e-2)
     emu_tol = 3e-2 if name == "deep_wide" else 1e-2
-    for emu, tol in ((True, emu_tol), (False, fp32_tol)):
+    for emu, tol in ((O.FUSED, emu_tol), (False, fp32_tol)):
         rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=emu)
         rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=emu)
         ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
@@ -92,7 +92,7 @@ def test_generic_ragged_chunk_and_stale_workspace():
     ctx.train_chunk(o, d, t, img, u, loss=loss)
     g = ctx.grads_view().cpu().numpy()
     n = ctx.param_count
-    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=True)
+    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
     ec = per_tensor_err(g[:n], O.flatten_params(gc), cfg)
     log_stats("generic_ragged", coarse_worst=ec[0])
     assert ec[0] < 4e-2, ec
@@ -115,7 +115,7 @@ def test_generic_adam_steps_follow_oracle():
             sl = slice(c * R, (c + 1) * R)
             ctx.train_chunk(o[sl], d[sl], t[sl], img[sl], u[sl], inv_chunks=R / P["N"], loss=loss, ray_offset=c * R)
         ctx.apply_adam()
-        m, _, _, _ = O.train_step(cp, fp, oc, of_, P["img"], P["o"], P["d"], P["t"], P["u"], cfg, R, True, "zero", emulate_bf16=True)
+        m, _, _, _ = O.train_step(cp, fp, oc, of_, P["img"], P["o"], P["d"], P["t"], P["u"], cfg, R, True, "zero", emulate_bf16=O.FUSED)
         lg = loss.cpu().numpy()
         assert abs(lg[0] - m["coarse_loss"]) < 3e-3 and abs(lg[1] - m["fine_loss"]) < 3e-3
     for w, ref, init in ((ctx.get_weights(0), O.flatten_params(cp), O.flatten_params(P["cp"])),

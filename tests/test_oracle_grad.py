@@ -104,7 +104,12 @@ def test_collapsed_head_is_the_same_function_and_the_same_gradients(monkeypatch)
     mode).  With the bf16 rounding switched off that must be the layer-by-layer computation to fp64 rounding: outputs, all
     24 gradients, every tensor."""
     monkeypatch.setattr(O, "_rb", lambda x: np.asarray(x))
-    cfg = O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=4, pos_emb_dir=2, n_layers=4, dense_units=32, skip_layer=2)
+    for cfg in (O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=4, pos_emb_dir=2, n_layers=4, dense_units=32, skip_layer=2),
+                O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=3, pos_emb_dir=1, n_layers=3, dense_units=16, skip_layer=1)):   # concat after the LAST layer
+        _check_collapsed_head(cfg)
+
+
+def _check_collapsed_head(cfg):
     rng = np.random.default_rng(5)
     params = [(p * 2).astype(np.float64) for p in O.init_params(cfg, 3)]
     for b in params[1::2]:
