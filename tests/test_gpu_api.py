@@ -125,6 +125,10 @@ def test_nerf_utils_ops_match_oracle():
     np.testing.assert_array_equal(s.cpu().numpy(), O.fine_hierarchical_sampling_chunk(mids, ww, u, "zero"))
     s2 = U.fine_hierarchical_sampling(mids, ww, 64)
     assert s2.shape == (1024, 64)                                                    # test_nerf_utils.py:65-76
+    # the non-chunk twin (utils.py:136-174) on [B,H,W,.] inputs: same values as the chunk form, bit for bit
+    s3 = U.fine_hierarchical_sampling(mids.reshape(2, 16, 32, 31), ww.reshape(2, 16, 32, 32), 64, u=u)
+    assert s3.shape == (2, 16, 32, 64)
+    np.testing.assert_array_equal(s3.cpu().numpy().reshape(1024, 64), O.fine_hierarchical_sampling_chunk(mids, ww, u, "zero"))
 
 
 def test_rays_generator_like_reference_test():

@@ -179,3 +179,18 @@ def test_data_parallel_batches_are_disjoint_slices_of_the_global_batches():
     ds = [RayImageDataset([f"img{i}" for i in range(n)], [np.eye(4)] * n, None, None, b, seed=5, rank=r, world=world) for r in range(world)]
     assert [len(d) for d in ds] == [3, 3, 3]
     assert len(RayImageDataset(["x"] * n, [np.eye(4)] * n, None, None, b, seed=5)) == 11     # outside a process group: world 1
+
+
+def test_reference_import_names_resolve_to_this_implementation():
+    """`keras_nerf.*` (the reference's package name, train_single.py:8-12 / inference.py:8-11) is an alias package of
+    re-exports, so scripts written against the reference import this implementation without an import swap."""
+    import importlib
+    pairs = {"keras_nerf.model.nerf.nerf": ["NeRF"], "keras_nerf.model.nerf.utils": ["NeRFUtils"], "keras_nerf.model.nerf.mlp": ["NeRFMLP"],
+             "keras_nerf.model.nerf.callback": ["NeRFTrainMonitor"], "keras_nerf.data.rays": ["RaysGenerator"],
+             "keras_nerf.data.utils": ["pose_spherical", "get_focal_from_fov"], "keras_nerf.data.loader": ["DatasetLoader"],
+             "keras_nerf.data.image": ["ImageLoader"]}
+    for mod, names in pairs.items():
+        a = importlib.import_module(mod)
+        b = importlib.import_module(mod.replace("keras_nerf.", "keras_nerf_amd.", 1))
+        for n in names:
+            assert getattr(a, n) is getattr(b, n), (mod, n)
