@@ -206,7 +206,7 @@ constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
 constexpr int kDzHead = 128, kDzBlocks = 130;
 constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
 // Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
-// own tile at about the same time, so a stride that is a large power of two times a small odd number (156 KiB =
+// own tile at about the same time, so a stride that is a large power of two times a small odd number (e.g. 156 KiB =
 // 2^12 * 39) concentrates those writes on a few memory channels; an odd number of 256-B units spreads them.
 #ifndef KNERF_TILE_SKEW
 #define KNERF_TILE_SKEW 256
