@@ -94,6 +94,62 @@ def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
     assert cw.std() > 1e-3 and fw.std() > 1e-3
 
 
+def test_cfg2_train_batch_at_bench_size_against_oracle():
+    """BASELINE configs[1] (the benched workload): 2 x 128 x 128 rays in 8 chunks of 4096 through knerf_train_batch.  The images
+    the training pass returns, for 256 rays sampled from all chunks, against the oracle (coarse on the given t-values, fine on
+    the pass's own merged t-values, recovered bit-exactly from its coarse weights); the step's losses are the MSE of those images;
+    the gradients are finite and every tensor of both nets received one."""
+    from keras_nerf_amd.data.rays import RaysGenerator
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    wh, B, R = 128, 2, 4096
+    cfg = O.NerfConfig()
+    cp, fp = problem_weights()
+    nerf = NeRF(seed=0)
+    nerf.compile("adam", "mse", batch_size=B, image_height=wh, image_width=wh, ray_chunks=R, white_background=True)
+    assert nerf.sequential_chunks == 8
+    nerf.coarse.set_flat_weights(O.flatten_params(cp)); nerf.fine.set_flat_weights(O.flatten_params(fp))
+    ctx = nerf._ctx
+    rg = RaysGenerator(get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, cfg.n_coarse, seed=21)
+    o, d, t = rg(np.stack([pose_spherical(15.0, -30.0, 4.0), pose_spherical(190.0, -30.0, 4.0)]))
+    N = B * wh * wh
+    o, d, t = o.reshape(N, 3).contiguous(), d.reshape(N, 3).contiguous(), t.reshape(N, -1).contiguous()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    tgt = torch.rand((N, 3), device="cuda", generator=gen); u = torch.rand((N, cfg.n_fine), device="cuda", generator=gen)
+    loss = torch.zeros(2, device="cuda"); ci = torch.empty((N, 3), device="cuda"); fi = torch.empty((N, 3), device="cuda")
+    ctx.zero_grads()
+    ctx.train_batch(o, d, t, tgt, u, seed=0, ray_chunks=R, loss=loss, c_image=ci, f_image=fi)
+    g = ctx.grads_view().cpu().numpy()
+    assert np.isfinite(g).all()
+    off = 0
+    for net in range(2):
+        for name, fin, fout in O.layer_shapes(cfg):
+            for n_el in (fin * fout, fout):
+                assert np.abs(g[off:off + n_el]).max() > 0, (net, name)
+                off += n_el
+    assert abs(float(((ci - tgt) ** 2).mean()) - float(loss[0])) < 1e-5 and abs(float(((fi - tgt) ** 2).mean()) - float(loss[1])) < 1e-5
+    # the forward-only path on the same rays and u gives the same images (training and rendering share the kernels' arithmetic)
+    buf = dict(c_image=torch.empty((N, 3), device="cuda"), c_weights=torch.empty((N, 64), device="cuda"),
+               f_image=torch.empty((N, 3), device="cuda"), t_fine=torch.empty((N, 192), device="cuda"))
+    ctx.render_batch(o, d, t, u, 0, R, out=buf)
+    assert torch.equal(buf["c_image"], ci) and torch.equal(buf["f_image"], fi)
+    idx = np.sort(np.random.default_rng(4).choice(N, 256, replace=False))
+    assert len(set(idx // R)) == 8
+    s = lambda x: x.cpu().numpy()[idx]
+    so, sd, st, su = s(o), s(d), s(t), s(u)
+    rc = O.predict_and_render_chunk_single(cp, so, sd, st, cfg, True, emulate_bf16=O.FUSED)
+    tfine = s(buf["t_fine"])
+    np.testing.assert_array_equal(tfine, O.fine_points(st, s(buf["c_weights"]), su, "zero"))
+    rf = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True, emulate_bf16=O.FUSED)
+    rf32 = O.predict_and_render_chunk_single(fp, so, sd, tfine, cfg, True)
+    log_stats("cfg2_train_batch_images", c_img=np.abs(s(ci) - rc["image"]).max(), f_img=np.abs(s(fi) - rf["image"]).max(),
+              f_img_fp32=np.abs(s(fi) - rf32["image"]).max())
+    np.testing.assert_allclose(s(ci), rc["image"], atol=1e-2); np.testing.assert_allclose(s(fi), rf["image"], atol=1e-2)
+    assert np.abs(s(fi) - rf32["image"]).max() < 2e-2
+    ctx.apply_adam()
+    assert ctx.step == 1
+
+
 def test_cfg3_400x400_ten_chunks_of_16000():
     from keras_nerf_amd.data.rays import RaysGenerator
     from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
