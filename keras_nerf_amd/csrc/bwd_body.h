@@ -16,13 +16,34 @@ namespace knerf {
 
 // store schedule: 2 dZ blocks per out tile of every stage (the dz_head block is stored BEFORE the ring's prologue, i.e. it
 // is older than every LDS-DMA and never counted)
+#ifndef KNERF_STORE_BURST
+#define KNERF_STORE_BURST 2      // dZ blocks written per burst (see mlp_fwd.hip)
+#endif
+constexpr int kBwdBurstTiles = KNERF_STORE_BURST / 2;
+#if KNERF_STORE_BURST == 2
 constexpr StoreSched<8> kBwdStores = {{{0, 1, 8, 2, 0, 0}, {8, 16, 8, 2, 0, 0}, {136, 16, 8, 2, 0, 0}, {264, 16, 8, 2, 0, 0},
                                        {392, 16, 8, 2, 0, 0}, {520, 16, 8, 2, 0, 0}, {648, 16, 8, 2, 0, 0}, {776, 16, 8, 2, 0, 0}}, 0};
+constexpr int kBwdStoreStages = 8;
+#else
+constexpr int kBwdParts = 8 / kBwdBurstTiles;
+constexpr int kBwdStoreStages = 8 * kBwdParts;
+constexpr StoreSched<kBwdStoreStages> make_bwd_burst_sched() {
+    StoreSched<kBwdStoreStages> s{};
+    for (int st = 0; st < 8; ++st)
+        for (int p = 0; p < kBwdParts; ++p) {
+            const int b0 = st == 0 ? 0 : 8 + 128 * (st - 1), nks = st == 0 ? 1 : 16;
+            s.st[st * kBwdParts + p] = StoreStage{b0 + p * kBwdBurstTiles * nks, nks, kBwdBurstTiles, 0, 2 * kBwdBurstTiles, 0};
+        }
+    s.initial = 0;
+    return s;
+}
+constexpr StoreSched<kBwdStoreStages> kBwdStores = make_bwd_burst_sched();
+#endif
 #ifdef KNERF_CONSERVATIVE_WAIT
 constexpr StoreSched<1> kNoStoresB = {{{0, 1, 0, 0, 0, 0}}, 0};
 struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<1, kBwdBlocks>(kNoStoresB); };
 #else
-struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<8, kBwdBlocks>(kBwdStores); };
+struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<kBwdStoreStages, kBwdBlocks>(kBwdStores); };
 #endif
 
 // dgrad chain of the 8 sample tiles (8 waves x 32 samples) of workgroup tile `wg_tile`
@@ -79,8 +100,13 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
 #ifndef KNERF_ABLATE_MASK      // timing experiment only
             apply_mask_packed(out[2 * ot], out[2 * ot + 1], mk[layer][ot >> 1] >> ((ot & 1) * 8));
 #endif
-            store_block(dz, 16 * layer + 2 * ot, lane, out[2 * ot]);
-            store_block(dz, 16 * layer + 2 * ot + 1, lane, out[2 * ot + 1]);
+            if ((ot + 1) % kBwdBurstTiles == 0) {        // bursts of kBwdBurstTiles out tiles (the layer's dZ stays in registers anyway)
+#pragma unroll
+                for (int q = ot + 1 - kBwdBurstTiles; q <= ot; ++q) {
+                    store_block(dz, 16 * layer + 2 * q, lane, out[2 * q]);
+                    store_block(dz, 16 * layer + 2 * q + 1, lane, out[2 * q + 1]);
+                }
+            }
         };
     };
     // B0: dz_head (r, g, b, sigma) -> dh7 -> dz7 (y)

@@ -51,11 +51,35 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
 
 // store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile and one mask block per trunk layer, the
 // 2 dir blocks right behind layer_7 (counted as that stage's end-of-stage stores); the head stage stores nothing
+#ifndef KNERF_STORE_BURST
+#define KNERF_STORE_BURST 2      // saved blocks written per burst: 2 = behind every out tile; 4 / 8 / 16 = every 2nd / 4th / 8th tile
+#endif
+constexpr int kBurstTiles = KNERF_STORE_BURST / 2;          // out tiles per burst
+// StoreSched models a burst as a pseudo-stage of kBurstTiles out tiles whose stores all come at its end
+#if KNERF_STORE_BURST == 2
 constexpr StoreSched<9> kFwdStores = {{{0, 4, 8, 2, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
                                        {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 3, 0},
                                        {960, 18, 1, 0, 0, 0}}, 4};
+constexpr int kFwdStoreStages = 9;
+#else
+constexpr int kParts = 8 / kBurstTiles;                      // bursts per trunk stage
+constexpr int kFwdStoreStages = 8 * kParts + 1;
+constexpr StoreSched<kFwdStoreStages> make_fwd_burst_sched() {
+    StoreSched<kFwdStoreStages> s{};
+    const int b0[8] = {0, 32, 160, 288, 416, 544, 704, 832}, nks[8] = {4, 16, 16, 16, 16, 20, 16, 16};
+    for (int l = 0; l < 8; ++l)
+        for (int p = 0; p < kParts; ++p) {
+            const int extra = p == kParts - 1 ? (l == 7 ? 3 : 1) : 0;      // mask block (+ the 2 dir blocks behind layer_7)
+            s.st[l * kParts + p] = StoreStage{b0[l] + p * kBurstTiles * nks[l], nks[l], kBurstTiles, 0, 2 * kBurstTiles + extra, 0};
+        }
+    s.st[8 * kParts] = StoreStage{960, 18, 1, 0, 0, 0};
+    s.initial = 4;
+    return s;
+}
+constexpr StoreSched<kFwdStoreStages> kFwdStores = make_fwd_burst_sched();
+#endif
 constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
-struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<9, kFwdBlocks>(kFwdStores); };
+struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<kFwdStoreStages, kFwdBlocks>(kFwdStores); };
 struct FwdWaitPlain { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<1, kFwdBlocks>(kNoStores); };
 
 // NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries
@@ -117,8 +141,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
             out[2 * ot] = relu_packed(out[2 * ot]);
             out[2 * ot + 1] = relu_packed(out[2 * ot + 1]);
             if (SAVE) {
-                store_block(act, act_h(layer) + 2 * ot, lane, out[2 * ot]);
-                store_block(act, act_h(layer) + 2 * ot + 1, lane, out[2 * ot + 1]);
+                // the layer's output stays in registers until the next layer has read it, so the blocks of kBurstTiles out
+                // tiles can leave together: longer contiguous bursts per wave (2 KiB x kBurstTiles) for the same registers
+                if ((ot + 1) % kBurstTiles == 0) {
+#pragma unroll
+                    for (int q = ot + 1 - kBurstTiles; q <= ot; ++q) {
+                        store_block(act, act_h(layer) + 2 * q, lane, out[2 * q]);
+                        store_block(act, act_h(layer) + 2 * q + 1, lane, out[2 * q + 1]);
+                    }
+                }
                 // mask word of tile ot in byte lanes: even tile -> bits 0-7 / 16-23, odd tile -> bits 8-15 / 24-31
                 const unsigned m = relu_mask_bits(out[2 * ot], out[2 * ot + 1]);
                 if (ot & 1) mbits[ot >> 1] |= m << 8; else mbits[ot >> 1] = m;
