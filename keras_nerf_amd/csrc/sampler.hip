@@ -50,13 +50,18 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
     float* wl = all + Nc;            // scratch: the fine half of `all` is not written until the cdf exists
     for (int i = lane; i < Nc; i += 64) { const float tv = tc[i]; tt[i] = tv; all[i] = tv; wl[i] = __fadd_rn(wc[i], 1e-5f); }
     __builtin_amdgcn_wave_barrier();
-    // total and cdf = [0, cumsum(pdf)] strictly left to right (the oracle's declared order; every lane computes the
-    // same values, lane 0 stores them): the knot positions decide searchsorted and the denom<1e-5 branch bit for bit
+    // total and cdf = [0, cumsum(pdf)] strictly left to right (the oracle's declared order): the knot positions decide
+    // searchsorted and the denom<1e-5 branch bit for bit.  The two running sums are serial by definition (every lane carries
+    // the same chain); the Nc divisions are not -- lane i forms pdf_i = w_i / total once, in parallel.
     float tot = 0.f;
     for (int i = 0; i < Nc; ++i) tot = __fadd_rn(tot, wl[i]);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < Nc; i += 64) wl[i] = __fdiv_rn(wl[i], tot);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     float acc = 0.f;
     for (int i = 0; i < Nc; ++i) {
-        acc = __fadd_rn(acc, __fdiv_rn(wl[i], tot));
+        acc = __fadd_rn(acc, wl[i]);
         if (lane == 0) cdf[i + 1] = acc;
     }
     if (lane == 0) cdf[0] = 0.f;
@@ -89,14 +94,34 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 
-    // rank sort (stable): Na values, each lane ranks ceil(Na/64) of them against all
+    // merge: the output is the ascending sequence of the Na values (ties are indistinguishable in it).  The coarse half is
+    // already ascending (rays.py:116-127: jitter below half a bin), so an element's rank is its rank inside its own half plus
+    // the number of elements of the other half that precede it: a binary search over the coarse t for a fine sample, one pass
+    // over the Nf fine samples for everybody.  Ties: coarse before fine, fine by index (the stable order of concat).
+    // Falls back to ranking against all Na values when the coarse t of this ray are not sorted.
     float* out = a.t_out + (size_t)ray * Na;
+    bool sorted = true;
+    for (int i = lane; i + 1 < Nc; i += 64) sorted = sorted && (all[i] <= all[i + 1]);
+    sorted = __builtin_amdgcn_ballot_w64(!sorted) == 0;
+    const float* fine = all + Nc;
     for (int e = lane; e < Na; e += 64) {
         const float v = all[e];
         int rank = 0;
-        for (int k = 0; k < Na; ++k) {
-            const float o = all[k];
-            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+        if (!sorted) {
+            for (int k = 0; k < Na; ++k) {
+                const float o = all[k];
+                rank += (o < v || (o == v && k < e)) ? 1 : 0;
+            }
+        } else if (e < Nc) {
+            // equal coarse values keep their index order, so e itself counts the coarse elements in front; fine samples precede only when smaller
+            rank = e;
+            for (int k = 0; k < Nf; ++k) rank += fine[k] < v ? 1 : 0;
+        } else {
+            int lo = 0, hi = Nc;                             // coarse elements <= v come first
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (all[mid] <= v) lo = mid + 1; else hi = mid; }
+            rank = lo;
+            const int je = e - Nc;
+            for (int k = 0; k < Nf; ++k) { const float o = fine[k]; rank += (o < v || (o == v && k < je)) ? 1 : 0; }
         }
         out[rank] = v;
     }
