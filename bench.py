@@ -340,6 +340,9 @@ def main():
         roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
         roofline["step_executed_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP_EXEC / (elapsed / args.steps) / 1e12
         roofline["step_executed_frac_of_mfma_peak"] = roofline["step_executed_tflops"] / MFMA_PEAK_TFLOPS
+        roofline["executed_note"] = ("all 12 Dense layers of both MLPs are trained (24 gradient tensors each); the three activation-free "
+                                     "layers behind the trunk are evaluated as one composed 283x4 stage, an exact identity of the "
+                                     "reference network (DESIGN.md 2.0), hence executed < algorithmic FLOPs")
         # whole-step HBM view: saved activations, relu masks and dZ written once and read back once
         step_bytes = n_rays * samples_per_ray / 32 * STEP_KIB_PER_TILE * 1024
         roofline["bytes_per_ray_sample"] = STEP_KIB_PER_TILE * 1024 / 32
