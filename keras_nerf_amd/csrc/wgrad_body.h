@@ -204,7 +204,11 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 const int d = dst[row * NCOLS + 32 * wo + c];
+#ifdef KNERF_WGRAD_ABLATE_FLUSH      // timing experiment only: what the atomic flush costs
+                asm volatile("" ::"v"(acc[n][i]), "v"(d));
+#else
                 if (d >= 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][i]);
+#endif
             }
         } else if (it == NI) {
             const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
