@@ -104,8 +104,8 @@ hipError_t launch_step_status(const int* flag, int* host_status, hipStream_t str
 // collapsed head (layout.h): w = one net's extended weight buffer (kExtParamCount floats).  compose writes the head matrix
 // and bias behind the parameters; expand turns the wgrad head job's aux sums into the gradients of features, rgb_features
 // and rgb (added to grad, aux zeroed).
-hipError_t launch_head_compose(float* w, hipStream_t stream);
-hipError_t launch_head_expand(const float* w, float* aux, float* grad, hipStream_t stream);
+hipError_t launch_head_compose(float* w0, float* w1 /* may be null */, hipStream_t stream);   // one workgroup per net
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, hipStream_t stream);
 
 struct RayGenArgs {
     const float* c2w;       // [B,4,4] row-major (device)

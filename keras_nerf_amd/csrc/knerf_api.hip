@@ -63,13 +63,14 @@ int fail(knerf_ctx* c, int code, const std::string& msg) {
 constexpr size_t kFwdStreamBytes = (size_t)((kFwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
 constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
 
-int repack(knerf_ctx* ctx, int n, hipStream_t s) {
+// compose = false: the caller has already composed the heads of both nets in one launch (knerf_apply_adam)
+int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
     Net& N = ctx->net[n];
     if (ctx->generic) {
         HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n], s));
         return KNERF_OK;
     }
-    HIPCHK(launch_head_compose(N.w, s));          // the composed head behind the parameters (layout.h), then the bf16 streams
+    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
     HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)kFwdBlocks * 512, s));
     HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)kBwdBlocks * 512, s));
     HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)kFwdBiasTiles * 32, s));
@@ -195,7 +196,7 @@ int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
         for (int n = 0; n < 2; ++n) HIPCHK(gen::expand_head(ctx->gplan, ctx->gnet[n], ctx->net[n].w, ctx->net[n].g, s));
         return KNERF_OK;
     }
-    for (int n = 0; n < 2; ++n) HIPCHK(launch_head_expand(ctx->net[n].w, ctx->net[n].aux, ctx->net[n].g, s));
+    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, s));
     return KNERF_OK;
 }
 
@@ -503,8 +504,10 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = ctx->n_params;
         a.lr_t = lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
-        if (int r = repack(ctx, n, s)) return r;
     }
+    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, s));      // both nets' heads in one launch
+    for (int n = 0; n < 2; ++n)
+        if (int r = repack(ctx, n, s, false)) return r;
     HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, s));
     return KNERF_OK;
 }

@@ -87,7 +87,8 @@ static_assert(kBc + 3 == kParamCount, "head tensor offsets");
 
 // H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < 256);  H[256+m][0..2] = (W_r2 W_c)[m], H[256+m][3] = 0 (m < 27);
 // bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP.
-__global__ __launch_bounds__(256) void head_compose_kernel(float* w) {
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1) {
+    float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
     __shared__ float P[283][3];          // W_r W_c : rows 0..255 = W_r1 W_c, 256..282 = W_r2 W_c
     __shared__ float wc[128][3];
     const int tid = threadIdx.x;
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w) {
     }
     if (tid == 3) w[kHeadBiasOff + 3] = w[kBs];
 }
-hipError_t launch_head_compose(float* w, hipStream_t stream) {
-    hipLaunchKernelGGL(head_compose_kernel, dim3(1), dim3(256), 0, stream, w);
+hipError_t launch_head_compose(float* w0, float* w1, hipStream_t stream) {
+    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1);
     return hipGetLastError();
 }
 
@@ -132,7 +133,9 @@ hipError_t launch_head_compose(float* w, hipStream_t stream) {
 //   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
 // -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
 // evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void head_expand_kernel(const float* w, float* aux, float* grad) {
+struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; };
+__global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
+    const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
     __shared__ float M[283][3], s_[3], P1[256][3], Q[256][3], wc[128][3];
     const int tid = threadIdx.x;
     for (int i = tid; i < 283 * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(const float* w, float
     }
     if (tid < 3) grad[kBc + tid] += s_[tid];
 }
-hipError_t launch_head_expand(const float* w, float* aux, float* grad, hipStream_t stream) {
-    hipLaunchKernelGGL(head_expand_kernel, dim3(1), dim3(1024), 0, stream, w, aux, grad);
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, hipStream_t stream) {
+    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}};
+    hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }
 
