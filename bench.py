@@ -197,8 +197,9 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                           "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}), flush=True)
 
 
-# per 32-sample tile, KiB (csrc/layout.h): saved activations, dZ, relu masks; wgrad re-reads the 4 enc blocks for layer_5
-ACT_KIB, DZ_KIB, MASK_KIB, WGRAD_REREAD_KIB = 134, 130, 8, 4
+# per 32-sample tile, KiB (csrc/layout.h): saved activations (h0 is recomputed, not saved), dZ, relu masks; wgrad reads the 4 enc
+# blocks three times (layer_0, layer_1's h0 recomputation, layer_5)
+ACT_KIB, DZ_KIB, MASK_KIB, WGRAD_REREAD_KIB = 118, 130, 8, 8
 LAYOUT_TAG = f"act{ACT_KIB}_dz{DZ_KIB}"
 WGRAD_KIB_PER_TILE = ACT_KIB + DZ_KIB + WGRAD_REREAD_KIB
 # whole step, per 32-sample tile: fwd writes act + masks, dgrad reads masks + raw/draw and writes dZ, wgrad reads act + dZ;

@@ -54,6 +54,8 @@ struct WgradArgs {
     const char* dz;         // [tiles][kDzBlocks][1 KiB]
     float* grad;            // flat fp32 gradient accumulator of this net (kParamCount)
     float* aux;             // head accumulator of this net (layout.h kAuxCount): destinations >= kAuxBase land here
+    const char* fwd_stream; // this net's packed forward A-fragments and bias tiles: the layer_1 job recomputes h0 from them
+    const float* bias;
     const int* dst;         // concatenated per-job destination tables: [(32*n_it + 1) rows][32*n_ot cols] index or -1
     const void* plan;       // device array of WgradPlan, one per workgroup
     long long n_tiles;

@@ -29,7 +29,9 @@ std::string g_create_error;
 std::vector<int32_t> build_wgrad_plan(int n_wg) {
     // r02 stamps (gpurun_out/r2b/stamps.json): 1180 / 2080 / 2590 / 1530 cycles per tile for layer_0 / 256x256 / layer_5 / head;
     // head swept 100..200 (1.40 / 1.20 / 1.13 / 1.12 ms per fine launch at 100 / 130 / 160 / 200)
-    int cost[kWgradJobs] = {116, 204, 204, 204, 204, 254, 204, 204, 175};
+    // layer_1 recomputes h0 (wgrad_l1_recompute, 20 KiB tiles but 22 MFMAs and an LDS exchange per tile): swept 160 / 204 / 240 /
+    // 280 -> 1.27 / 1.08 / 1.056 / 1.064 ms per fine launch
+    int cost[kWgradJobs] = {116, 240, 204, 204, 204, 254, 204, 204, 175};
     if (const char* e = std::getenv("KNERF_WGRAD_COSTS")) {
         int j = 0;
         for (const char* p = e; *p && j < kWgradJobs; ++j) { cost[j] = std::atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
@@ -180,6 +182,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         ba.n_samples = fa.n_samples; ba.net = fa.net;
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
+        wa.fwd_stream = ctx->net[net].fwd_stream; wa.bias = ctx->net[net].bias;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
         wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];

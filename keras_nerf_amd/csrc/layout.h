@@ -196,13 +196,15 @@ inline void build_bwd(PackTables& pt) {
 // stores its 8 bf16 at byte offset saved_off(b, h, s) = (2*(s ^ 4*(b&1)) + h) * 16: the two feature halves of a
 // sample are adjacent (32 B per sample) and odd blocks rotate their sample quads, which makes the wgrad kernel's
 // ds_read_b64_tr_b16 transposed reads bank-conflict free while the store stays one coalesced 1 KiB write.
-// forward "act" run (134 blocks):  h0 h1 h2 h3 h4 enc h5 h6 h7 dir
+// forward "act" run (118 blocks):  h1 h2 h3 h4 enc h5 h6 h7 dir   -- h0 is NOT saved: layer_0 has only 64 input slots, so the
+//   layer_1 wgrad job recomputes h0 = relu(W_0 enc + b_0) from the 4 enc blocks (4 MFMAs per wave and tile) instead of reading
+//   16 blocks that the forward would have had to write (wgrad_body.h wgrad_l1_recompute)
 // backward "dz" run  (130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero)
 // so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5, head: act[h7..dir] x dz_head.
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
-constexpr int kActH0 = 0, kActH4 = 64, kActEnc = 80, kActH5 = 84, kActH7 = 116, kActDir = 132, kActBlocks = 134;
-constexpr int act_h(int l) { return l <= 4 ? 16 * l : 84 + 16 * (l - 5); }
+constexpr int kActH1 = 0, kActH4 = 48, kActEnc = 64, kActH5 = 68, kActH7 = 100, kActDir = 116, kActBlocks = 118;
+constexpr int act_h(int l) { return l <= 4 ? 16 * (l - 1) : 68 + 16 * (l - 5); }      // l = 1..7 (h0 is not saved)
 constexpr int kDzHead = 128, kDzBlocks = 130;
 constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
 // Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
@@ -228,7 +230,8 @@ inline WgradJob wgrad_job(int j) {
         case 0: return {kActEnc, 2, 0, 8, L0};
         case 5: return {kActH4, 10, 16 * 5, 8, L5};             // [h4 ; enc]
         case 8: return {kActH7, 9, kDzHead, 1, -1};             // [h7 ; dir] x (r,g,b,sigma)
-        default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 1-4, 6, 7
+        case 1: return {kActEnc, 8, 16, 8, L1};                 // h0 recomputed from enc; the table rows are h0 features
+        default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 2-4, 6, 7
     }
 }
 // in_row of job jb for tile-row index tr (0..32*n_it-1) in *natural tr-read order*: the transposed read un-permutes

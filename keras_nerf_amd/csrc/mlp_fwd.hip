@@ -49,7 +49,7 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
 }
 
-// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile and one mask block per trunk layer, the
+// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile (none for layer_0) and one mask block per trunk layer, the
 // 2 dir blocks right behind layer_7 (counted as that stage's end-of-stage stores); the head stage stores nothing
 #ifndef KNERF_STORE_BURST
 #define KNERF_STORE_BURST 2      // saved blocks written per burst: 2 = behind every out tile; 4 / 8 / 16 = every 2nd / 4th / 8th tile
@@ -57,7 +57,7 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
 constexpr int kBurstTiles = KNERF_STORE_BURST / 2;          // out tiles per burst
 // StoreSched models a burst as a pseudo-stage of kBurstTiles out tiles whose stores all come at its end
 #if KNERF_STORE_BURST == 2
-constexpr StoreSched<9> kFwdStores = {{{0, 4, 8, 2, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
+constexpr StoreSched<9> kFwdStores = {{{0, 4, 8, 0, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
                                        {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 3, 0},
                                        {960, 18, 1, 0, 0, 0}}, 4};
 constexpr int kFwdStoreStages = 9;
@@ -70,7 +70,7 @@ constexpr StoreSched<kFwdStoreStages> make_fwd_burst_sched() {
     for (int l = 0; l < 8; ++l)
         for (int p = 0; p < kParts; ++p) {
             const int extra = p == kParts - 1 ? (l == 7 ? 3 : 1) : 0;      // mask block (+ the 2 dir blocks behind layer_7)
-            s.st[l * kParts + p] = StoreStage{b0[l] + p * kBurstTiles * nks[l], nks[l], kBurstTiles, 0, 2 * kBurstTiles + extra, 0};
+            s.st[l * kParts + p] = StoreStage{b0[l] + p * kBurstTiles * nks[l], nks[l], kBurstTiles, 0, (l == 0 ? 0 : 2 * kBurstTiles) + extra, 0};
         }
     s.st[8 * kParts] = StoreStage{960, 18, 1, 0, 0, 0};
     s.initial = 4;
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
             if (SAVE) {
                 // the layer's output stays in registers until the next layer has read it, so the blocks of kBurstTiles out
                 // tiles can leave together: longer contiguous bursts per wave (2 KiB x kBurstTiles) for the same registers
-                if ((ot + 1) % kBurstTiles == 0) {
+                // (h0 is not saved at all: the layer_1 wgrad job recomputes it from enc, layout.h)
+                if (layer > 0 && (ot + 1) % kBurstTiles == 0) {
 #pragma unroll
                     for (int q = ot + 1 - kBurstTiles; q <= ot; ++q) {
                         store_block(act, act_h(layer) + 2 * q, lane, out[2 * q]);

@@ -217,11 +217,146 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     }
 }
 
+// layer_1 with h0 RECOMPUTED.  h0 = relu(W_0 enc + b_0) has only 64 input slots, so the forward does not save it (16 KiB per
+// tile less to write there and to read here): this job stages enc (4 blocks) + dz1 (16 blocks) per tile, every wave recomputes
+// ONE 32-feature tile of h0 for the tile's 32 samples with 4 MFMAs in the orientation D[sample][feature] = enc . W_0 -- whose
+// result already has lane = feature, registers = samples, i.e. it IS an A operand of the weight-gradient product, with the
+// sample order sigma(hh, j) = (j&3) + 8(j>>2) + 4hh (+16 kk) -- and publishes its two fragments in LDS; after a barrier all
+// waves read the 16 fragments and accumulate dW_1 = h0^T dz1 as before.  The dz1 fragments are read with the SAME sample
+// permutation (only the per-lane offsets of the transposed reads change; the bank pattern stays conflict-free: 32 q + 128
+// (h ^ par) covers the 64 banks in two passes).  W_0's fragments are the forward stream's own layer_0 blocks: an A fragment of
+// W^T and a B fragment of W hold the same registers (layout.h: the 32x32x16 operand maps are symmetric).
+__device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const ContigSeq seq, char* smem) {
+    constexpr int NI = 8, BLK_IN = 4, BLK_DZ = 16;
+    constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
+    constexpr int G_IN = 1, G_DZ = 2, G = G_IN + G_DZ;
+    constexpr int NS = 6;
+    constexpr int kXch = 2 * 16 * 1024;                      // h0 fragments of two tiles (the one being consumed, the next one): [parity][it][kk][1 KiB]
+    static_assert(NS * TILE_BYTES + kXch + kWgScratch <= 160 * 1024, "LDS budget");
+    constexpr int job = 1, NACC = NI + 1, NCOLS = 256;
+
+    const long long cnt = seq.count();
+    if (cnt <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave;                                     // output strip (32 columns of dW_1) AND the h0 tile this wave recomputes
+    const unsigned smem_base = lds_addr(smem);
+    char* xch = smem + NS * TILE_BYTES;
+    const unsigned scratch = smem_base + NS * TILE_BYTES + kXch + wave * 1024;
+
+    // W_0 fragments of h0 tile `wave` (forward stream blocks 4*wave .. 4*wave+3) and its bias column
+    bf16x8 w0[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w0[ks] = *reinterpret_cast<const bf16x8*>(a.fwd_stream + (size_t)(4 * wave + ks) * 1024 + lane * 16);
+    const float b0 = a.bias[wave * 32 + (lane & 31)];
+
+    // transposed reads of dz1 in the permuted sample order: samples 4 (h ^ par) + 8 r + q of the 16-sample group kk
+    int lane_off[2];
+    int enc_off;                                             // this lane's 16 bytes of an (even) saved block; odd blocks: ^ 128
+    {
+        const int grp = lane >> 4, par = grp & 1, h = grp >> 1, il = lane & 15, q = il >> 2, p = il & 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            lane_off[r] = par * 1024 + (2 * (4 * (h ^ par) + 8 * r + q) + (p & 1)) * 16 + (p >> 1) * 8;
+        enc_off = (2 * (lane & 31) + (lane >> 5)) * 16;      // saved_off(b even, h, s); odd b: s ^ 4  <=>  byte offset ^ 128
+    }
+    auto issue = [&](long long i, int slot) {
+        const long long t = seq.tile(i < cnt ? i : cnt - 1);
+        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)kActEnc * 1024 + lane * 16;
+        const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)16 * 1024 + lane * 16;
+        const unsigned dst = smem_base + slot * TILE_BYTES;
+        const bool ok = wave < BLK_IN;
+        glds16(src_in + (ok ? wave : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch));
+#pragma unroll
+        for (int r = 0; r < G_DZ; ++r) {
+            const int b = r * kWgWaves + wave;
+            glds16(src_dz + b * 1024, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024));
+        }
+    };
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    static_assert((kActEnc & 1) == 0, "enc block parity");
+
+    // my tile of h0 for the sample tile staged in `reg`: acc = b_0, += enc(ks) . W_0(ks), relu, bf16 (the forward's own order of
+    // operations, mlp_fwd.hip), published as the two A-operand fragments of h0 tile `wave`
+    auto recompute = [&](const char* reg, int parity) {
+        f32x16 h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = b0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 e = *reinterpret_cast<const bf16x8*>(reg + ks * 1024 + (enc_off ^ ((ks & 1) << 7)));
+            h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e, w0[ks], h, 0, 0, 0);
+        }
+        bf16x8 lo, hi;
+        pack_acc(h, lo, hi);
+        char* x = xch + parity * (kXch / 2) + wave * 2048 + lane * 16;
+        *reinterpret_cast<bf16x8*>(x) = relu_packed(lo);
+        *reinterpret_cast<bf16x8*>(x + 1024) = relu_packed(hi);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");       // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    recompute(smem, 0);
+    int slot = 0;
+    // One barrier per tile: iteration i consumes tile i (its h0 fragments were written during iteration i-1) and recomputes
+    // h0 of tile i+1 into the other half of the exchange buffer, so tile i+1 must have landed too (one tile less in flight).
+    for (long long i = 0; i < cnt; ++i) {
+        // tiles <= i+1 landed (mine) and my h0 fragments of tile i are written (lgkmcnt: the ds_writes of the recompute) ...
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 3)) : "memory");
+        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 and h0(i-1) are free
+        int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
+        issue(i + NS - 1, nslot);
+        const char* dz_reg = smem + slot * TILE_BYTES + BLK_IN * 1024;
+        const char* xr = xch + (int)(i & 1) * (kXch / 2);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
+            bf16x8 afr[NACC];
+#pragma unroll
+            for (int n = 0; n < NI; ++n) afr[n] = *reinterpret_cast<const bf16x8*>(xr + (n * 2 + kk) * 1024 + lane * 16);
+            afr[NI] = ones;
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        recompute(smem + slot * TILE_BYTES, (int)((i + 1) & 1));               // past the end: the clamped re-read of the last tile, unused
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int* dst = a.dst + a.job_off[job];
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        if (n < NI) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * n + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int d = dst[row * NCOLS + 32 * wo + c];
+#ifdef KNERF_WGRAD_ABLATE_FLUSH
+                asm volatile("" ::"v"(acc[n][i]), "v"(d));
+#else
+                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
+#endif
+            }
+        } else {
+            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
+            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
+        }
+    }
+}
+
 // one job of the plan over the given tile range
 __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const ContigSeq& seq, char* smem) {
     switch (job) {
         case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, seq, smem); break;
-        case 1: wgrad_job_body<8, 8>(a, 1, act_h(0), 16 * 1, seq, smem); break;
+        case 1: wgrad_l1_recompute(a, seq, smem); break;                                  // h0 recomputed from enc
         case 2: wgrad_job_body<8, 8>(a, 2, act_h(1), 16 * 2, seq, smem); break;
         case 3: wgrad_job_body<8, 8>(a, 3, act_h(2), 16 * 3, seq, smem); break;
         case 4: wgrad_job_body<8, 8>(a, 4, act_h(3), 16 * 4, seq, smem); break;

@@ -107,8 +107,8 @@ def forward_chain(fwd_tab, bias_tab, flat, p, d):
 # backward: dgrad chain + saved blocks + wgrad (transposed LDS reads), mirroring mlp_bwd.hip / wgrad.hip
 # ---------------------------------------------------------------------------------------------------------------
 BWD_STAGES = [(0, 1, 8)] + [(8 + 128 * i, 16, 8) for i in range(7)]
-ACT_H = lambda l: 16 * l if l <= 4 else 84 + 16 * (l - 5)
-K_ACT_ENC, K_ACT_H7, K_ACT_DIR, K_ACT_BLOCKS = 80, 116, 132, 134
+ACT_H = lambda l: 16 * (l - 1) if l <= 4 else 68 + 16 * (l - 5)      # l = 1..7: h0 is not saved (recomputed by the layer_1 wgrad job)
+K_ACT_ENC, K_ACT_H7, K_ACT_DIR, K_ACT_BLOCKS = 64, 100, 116, 118
 K_DZ_HEAD, K_DZ_BLOCKS = 128, 130
 
 
@@ -123,13 +123,13 @@ def saved_block_image(frag, blk):
 
 
 def act_run(saved):
-    """forward_chain's saved dict -> [134*512] memory image of one tile's act run"""
+    """forward_chain's saved dict -> [118*512] memory image of one tile's act run (h1..h4, enc, h5..h7, dir)"""
     run = np.zeros(K_ACT_BLOCKS * 512, np.float32)
 
     def put(b0, frags):
         for i, f in enumerate(frags):
             run[(b0 + i) * 512:(b0 + i + 1) * 512] = saved_block_image(f, b0 + i)
-    for l in range(8):
+    for l in range(1, 8):
         put(ACT_H(l), saved["h"][l])
     put(K_ACT_ENC, saved["enc"]); put(K_ACT_DIR, saved["dirc"])
     return run
@@ -180,20 +180,48 @@ def tr_read(img, addr):
     return out
 
 
-def tr_frag(region, pair, kk):
+def tr_frag(region, pair, kk, permuted=False):
+    """permuted: the sample order sigma(hh, j) = (j&3) + 8(j>>2) + 4hh of an accumulator tile used as an operand
+    (wgrad_body.h wgrad_l1_recompute) instead of 8 hh + j"""
     lane_off = np.zeros((2, 64), np.int64)
     for l in range(64):
         grp, il = l >> 4, l & 15
         par, h, q, p = grp & 1, grp >> 1, il >> 2, il & 3
         for r in range(2):
-            lane_off[r, l] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8
+            spos = 4 * (h ^ par) + 8 * r + q if permuted else 8 * h + 4 * (r ^ par) + q
+            lane_off[r, l] = par * 1024 + (2 * spos + (p & 1)) * 16 + (p >> 1) * 8
     base = pair * 2048 + kk * 512
     return np.concatenate([tr_read(region, base + lane_off[0]), tr_read(region, base + lane_off[1])], axis=1)
 
 
-WGRAD_JOBS = {0: (K_ACT_ENC, 2, 0, 8), 5: (64, 10, 80, 8), 8: (K_ACT_H7, 9, K_DZ_HEAD, 1)}
-for _j in (1, 2, 3, 4, 6, 7):
+WGRAD_JOBS = {0: (K_ACT_ENC, 2, 0, 8), 1: (K_ACT_ENC, 8, 16, 8), 5: (48, 10, 80, 8), 8: (K_ACT_H7, 9, K_DZ_HEAD, 1)}
+for _j in (2, 3, 4, 6, 7):
     WGRAD_JOBS[_j] = (ACT_H(_j - 1), 8, 16 * _j, 8)
+
+
+def saved_block_frag(img, blk):
+    """inverse of saved_block_image: 512 bf16 in memory order -> [64,8] fragment (what a lane reads back with its saved_off)"""
+    frag = np.zeros((64, 8), np.float32)
+    for l in range(64):
+        s, h = l & 31, l >> 5
+        off = (2 * (s ^ ((blk & 1) << 2)) + h) * 16
+        frag[l] = img[off // 2: off // 2 + 8]
+    return frag
+
+
+def recompute_h0_frags(enc_img, fwd_frags, bias_tab, w_ext):
+    """wgrad_l1_recompute: per h0 feature tile, D[sample][feature] = bias + sum_ks enc(ks) . W_0(tile, ks) with enc as the A
+    operand; relu, bf16; registers 0..7 / 8..15 are the two A-operand fragments (lane = feature, samples in sigma order)"""
+    enc = [saved_block_frag(enc_img[q * 512:(q + 1) * 512], K_ACT_ENC + q) for q in range(4)]
+    b = np.where(bias_tab >= 0, w_ext[np.maximum(bias_tab, 0)], np.float32(0)).astype(np.float32).reshape(-1, 32)
+    out = []
+    for it in range(8):
+        acc = np.tile(b[it][R_][:, None], (1, 16)).astype(np.float32)          # every row of a column holds that feature's bias
+        for ks in range(4):
+            acc = mfma(enc[ks], fwd_frags[4 * it + ks], acc)
+        lo, hi = pack_acc(np.maximum(acc, 0))
+        out.append((lo, hi))
+    return out
 
 
 def head_expand(w_ext, aux, grad):
@@ -213,10 +241,11 @@ def head_expand(w_ext, aux, grad):
     return grad
 
 
-def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext):
+def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext, fwd_tab=None, bias_tab=None):
     """Mirror of wgrad_kernel over a list of tiles + head_expand: returns the flat gradient.  Destinations >= n_params
-    address the head accumulator (csrc/layout.h kAuxBase)."""
+    address the head accumulator (csrc/layout.h kAuxBase).  Job 1 recomputes h0 from enc (fwd_tab / bias_tab needed)."""
     grad = np.zeros(n_params + AUX_COUNT, np.float64)
+    fwd_frags = gather_blocks(fwd_tab, w_ext) if fwd_tab is not None else None
     ones = np.ones((64, 8), np.float32)
     for jb, (ab, n_it, db, n_ot) in WGRAD_JOBS.items():
         dst = dst_tab[job_off[jb]:job_off[jb + 1]].reshape(n_it * 32 + 1, n_ot * 32)
@@ -224,11 +253,17 @@ def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext):
         for act, dz in zip(act_runs, dz_runs):
             in_reg = act[ab * 512:(ab + 2 * n_it) * 512]
             dz_reg = dz[db * 512:(db + 2 * n_ot) * 512]
+            h0 = recompute_h0_frags(act[ab * 512:(ab + 4) * 512], fwd_frags, bias_tab, w_ext) if jb == 1 else None
             for kk in range(2):
                 for ot in range(n_ot):
-                    b = tr_frag(dz_reg, ot, kk)
+                    b = tr_frag(dz_reg, ot, kk, permuted=(jb == 1))
                     for it in range(n_it + 1):
-                        a = tr_frag(in_reg, it, kk) if it < n_it else ones
+                        if it == n_it:
+                            a = ones
+                        elif jb == 1:
+                            a = h0[it][kk]
+                        else:
+                            a = tr_frag(in_reg, it, kk)
                         acc[(it, ot)] = mfma(a, b, acc[(it, ot)])
         for (it, ot), A in acc.items():
             for l in range(64):

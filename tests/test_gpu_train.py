@@ -59,7 +59,7 @@ def test_train_chunk_gradients_and_losses():
     _rf, _lf, _gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=O.FUSED)
     np.savez(os.path.join(OUT, "train_debug.npz"), g=g, gc=O.flatten_params(_gc), gf=O.flatten_params(_gf),
              draw=debug_buffer(ctx, 4).view(torch.float32).cpu().numpy()[:P["N"] * 192 * 4],
-             act=debug_buffer(ctx, 0).cpu().numpy()[:2 * 134 * 1024], mask=debug_buffer(ctx, 1).cpu().numpy()[:2 * 8 * 1024],
+             act=debug_buffer(ctx, 0).cpu().numpy()[:2 * 118 * 1024], mask=debug_buffer(ctx, 1).cpu().numpy()[:2 * 8 * 1024],
              dz=debug_buffer(ctx, 2).cpu().numpy()[:2 * 130 * 1024],
              raw=debug_buffer(ctx, 3).view(torch.float32).cpu().numpy()[:P["N"] * 192 * 4], t_fine=t_fine)
     for emu, tol in ((O.FUSED, 2.5e-2), (False, 8e-2)):

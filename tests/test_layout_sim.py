@@ -75,7 +75,7 @@ def test_backward_chain_and_wgrad_match_oracle(setup):
         dzs.append(M.backward_chain(bwd, flat, rgb, sigma, drgb, dsig, saved["masks"]))
         xs.append(pt); ds.append(d); drgbs.append(drgb); dsigs.append(dsig)
     n_par = O.param_count(cfg)
-    grad = M.wgrad(acts, dzs, dst_tab, job_off, n_par, flat)
+    grad = M.wgrad(acts, dzs, dst_tab, job_off, n_par, flat, fwd, bias)
     xyz = O.positional_encoding(np.concatenate(xs), 10)[None]
     dire = O.positional_encoding(np.concatenate(ds), 4)[None]
     _, _, cache = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=O.FUSED, want_cache=True)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from keras_nerf_amd import debug as _lib
 lib = _lib.load()
-wgs, blocks, stride = 3072, 134, 134 * 1024 + 256      # the forward's saved-activation run (csrc/layout.h kActBlocks)
+wgs, blocks, stride = 3072, 118, 118 * 1024 + 256      # the forward's saved-activation run (csrc/layout.h kActBlocks)
 buf = torch.empty(wgs * 8 * stride, dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 byts = wgs * 8 * blocks * 1024
