@@ -197,13 +197,15 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                           "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}), flush=True)
 
 
-# per 32-sample tile, KiB (csrc/layout.h): saved activations (h0 is recomputed, not saved), dZ, relu masks; wgrad reads the 4 enc
-# blocks three times (layer_0, layer_1's h0 recomputation, layer_5)
-ACT_KIB, DZ_KIB, MASK_KIB, WGRAD_REREAD_KIB = 118, 130, 8, 8
+# per 32-sample tile, KiB (csrc/layout.h): saved activations (h0 is recomputed, not saved), dZ WRITTEN (the run has 130 blocks;
+# the 16 of dz7 are never written: wgrad recomputes them from the dz_head block and the layer-7 mask block), relu masks.
+# wgrad reads the 4 enc blocks three times (layer_0, layer_1's h0 recomputation, layer_5), the dz_head block twice (head job,
+# layer_7's recomputation) and one mask block.
+ACT_KIB, DZ_KIB, MASK_KIB, WGRAD_REREAD_KIB = 118, 114, 8, 10
 LAYOUT_TAG = f"act{ACT_KIB}_dz{DZ_KIB}"
 WGRAD_KIB_PER_TILE = ACT_KIB + DZ_KIB + WGRAD_REREAD_KIB
-# whole step, per 32-sample tile: fwd writes act + masks, dgrad reads masks + raw/draw and writes dZ, wgrad reads act + dZ;
-# raw/draw/t: 32 samples x (16 B written + 16 B read) x 2 + t
+# whole step, per 32-sample tile: fwd writes act + masks, dgrad reads masks + raw/draw and writes dZ, wgrad reads act + dZ (+ its
+# re-reads); raw/draw/t: 32 samples x (16 B written + 16 B read) x 2 + t
 STEP_KIB_PER_TILE = 2 * (ACT_KIB + DZ_KIB + MASK_KIB) + WGRAD_REREAD_KIB + 2.5
 
 

@@ -14,14 +14,14 @@
 
 namespace knerf {
 
-// store schedule: 2 dZ blocks per out tile of every stage (the dz_head block is stored BEFORE the ring's prologue, i.e. it
-// is older than every LDS-DMA and never counted)
+// store schedule: 2 dZ blocks per out tile of every stage but the first (dz7 is recomputed by wgrad, not stored; the dz_head
+// block is stored BEFORE the ring's prologue, i.e. it is older than every LDS-DMA and never counted)
 #ifndef KNERF_STORE_BURST
 #define KNERF_STORE_BURST 2      // dZ blocks written per burst (see mlp_fwd.hip)
 #endif
 constexpr int kBwdBurstTiles = KNERF_STORE_BURST / 2;
 #if KNERF_STORE_BURST == 2
-constexpr StoreSched<8> kBwdStores = {{{0, 1, 8, 2, 0, 0}, {8, 16, 8, 2, 0, 0}, {136, 16, 8, 2, 0, 0}, {264, 16, 8, 2, 0, 0},
+constexpr StoreSched<8> kBwdStores = {{{0, 1, 8, 0, 0, 0}, {8, 16, 8, 2, 0, 0}, {136, 16, 8, 2, 0, 0}, {264, 16, 8, 2, 0, 0},
                                        {392, 16, 8, 2, 0, 0}, {520, 16, 8, 2, 0, 0}, {648, 16, 8, 2, 0, 0}, {776, 16, 8, 2, 0, 0}}, 0};
 constexpr int kBwdStoreStages = 8;
 #else
@@ -32,7 +32,7 @@ constexpr StoreSched<kBwdStoreStages> make_bwd_burst_sched() {
     for (int st = 0; st < 8; ++st)
         for (int p = 0; p < kBwdParts; ++p) {
             const int b0 = st == 0 ? 0 : 8 + 128 * (st - 1), nks = st == 0 ? 1 : 16;
-            s.st[st * kBwdParts + p] = StoreStage{b0 + p * kBwdBurstTiles * nks, nks, kBwdBurstTiles, 0, 2 * kBwdBurstTiles, 0};
+            s.st[st * kBwdParts + p] = StoreStage{b0 + p * kBwdBurstTiles * nks, nks, kBwdBurstTiles, 0, st == 0 ? 0 : 2 * kBwdBurstTiles, 0};
         }
     s.initial = 0;
     return s;
@@ -100,7 +100,9 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
 #ifndef KNERF_ABLATE_MASK      // timing experiment only
             apply_mask_packed(out[2 * ot], out[2 * ot + 1], mk[layer][ot >> 1] >> ((ot & 1) * 8));
 #endif
-            if ((ot + 1) % kBwdBurstTiles == 0) {        // bursts of kBwdBurstTiles out tiles (the layer's dZ stays in registers anyway)
+            // dz7 is not written: it is mask7 * (H dz_head) with only 4 input channels, which the layer_7 wgrad job recomputes from
+            // the dz_head block and the mask block (wgrad_body.h wgrad_l7_recompute)
+            if (layer != 7 && (ot + 1) % kBwdBurstTiles == 0) {        // bursts of kBwdBurstTiles out tiles (the layer's dZ stays in registers anyway)
 #pragma unroll
                 for (int q = ot + 1 - kBwdBurstTiles; q <= ot; ++q) {
                     store_block(dz, 16 * layer + 2 * q, lane, out[2 * q]);

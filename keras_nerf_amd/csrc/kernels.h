@@ -56,6 +56,8 @@ struct WgradArgs {
     float* aux;             // head accumulator of this net (layout.h kAuxCount): destinations >= kAuxBase land here
     const char* fwd_stream; // this net's packed forward A-fragments and bias tiles: the layer_1 job recomputes h0 from them
     const float* bias;
+    const char* bwd_stream; // this net's packed dgrad A-fragments and the forward's relu masks: the layer_7 job recomputes dz7
+    const char* mask;       //   = mask7 * (H dz_head) from them
     const int* dst;         // concatenated per-job destination tables: [(32*n_it + 1) rows][32*n_ot cols] index or -1
     const void* plan;       // device array of WgradPlan, one per workgroup
     long long n_tiles;

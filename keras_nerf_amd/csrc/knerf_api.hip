@@ -31,7 +31,10 @@ std::vector<int32_t> build_wgrad_plan(int n_wg) {
     // head swept 100..200 (1.40 / 1.20 / 1.13 / 1.12 ms per fine launch at 100 / 130 / 160 / 200)
     // layer_1 recomputes h0 (wgrad_l1_recompute, 20 KiB tiles but 22 MFMAs and an LDS exchange per tile): swept 160 / 204 / 240 /
     // 280 -> 1.27 / 1.08 / 1.056 / 1.064 ms per fine launch
-    int cost[kWgradJobs] = {116, 240, 204, 204, 204, 254, 204, 204, 175};
+    // layer_7 recomputes dz7 (wgrad_l7_recompute, 18 KiB tiles): 204 -> 240; with the copies issued behind the first half's MFMAs
+    // the plain jobs gained most, tools/tune_costs.py (coordinate search on the box) moved the others up: coarse + fine launch
+    // 1.439 -> 1.382 ms
+    int cost[kWgradJobs] = {128, 264, 204, 204, 204, 267, 204, 240, 193};
     if (const char* e = std::getenv("KNERF_WGRAD_COSTS")) {
         int j = 0;
         for (const char* p = e; *p && j < kWgradJobs; ++j) { cost[j] = std::atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
@@ -182,7 +185,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         ba.n_samples = fa.n_samples; ba.net = fa.net;
         WgradArgs wa{};
         wa.act = ctx->act; wa.dz = ctx->dz; wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
-        wa.fwd_stream = ctx->net[net].fwd_stream; wa.bias = ctx->net[net].bias;
+        wa.fwd_stream = ctx->net[net].fwd_stream; wa.bias = ctx->net[net].bias; wa.bwd_stream = ctx->net[net].bwd_stream; wa.mask = ctx->mask;
         wa.n_tiles = (long long)tiles_for(fa.n_samples);
         wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
         for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];

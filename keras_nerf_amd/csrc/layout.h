@@ -199,7 +199,9 @@ inline void build_bwd(PackTables& pt) {
 // forward "act" run (118 blocks):  h1 h2 h3 h4 enc h5 h6 h7 dir   -- h0 is NOT saved: layer_0 has only 64 input slots, so the
 //   layer_1 wgrad job recomputes h0 = relu(W_0 enc + b_0) from the 4 enc blocks (4 MFMAs per wave and tile) instead of reading
 //   16 blocks that the forward would have had to write (wgrad_body.h wgrad_l1_recompute)
-// backward "dz" run  (130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero)
+// backward "dz" run  (130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero);
+//   the 16 blocks of dz7 are RESERVED BUT NEVER WRITTEN: dz7 = mask7 * (H dz_head) has 4 input channels, so the layer_7 wgrad
+//   job recomputes its 32-column strip with one MFMA per wave and tile (wgrad_body.h wgrad_l7_recompute)
 // so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5, head: act[h7..dir] x dz_head.
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }

@@ -27,13 +27,23 @@ constexpr int kWgScratch = kWgWaves * 1024;   // landing zone of padding LDS-DMA
 
 // LDS-DMA of 16 B per lane, invisible to hipcc's wait-count pass (the builtin form makes it drain vmcnt(0) before
 // every transposed LDS read).  lds_dst = wave-uniform LDS byte address; completion is counted by hand (vmcnt).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
 #ifndef KNERF_WGRAD_LOAD_POLICY
 #define KNERF_WGRAD_LOAD_POLICY "nt"     // once-read streams (measured -2.5 %)
 #endif
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the same copy without the compiler-level memory fence: for a copy issued in the middle of a tile's products, whose LDS reads
+// (of other slots) may move across it.  Ordering against the reads of its own slot comes from the s_waitcnt/s_barrier pair.
+__device__ __forceinline__ void glds16_nofence(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " KNERF_WGRAD_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst));
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst, bool late) {
+    if (late) glds16_nofence(gsrc, lds_dst); else glds16(gsrc, lds_dst);
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
@@ -115,7 +125,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     }
 
     // stage sample tile number i (clamped at the end: a harmless re-read keeps the vmcnt arithmetic uniform) into `slot`
-    auto issue = [&](long long i, int slot) {
+    auto issue = [&](long long i, int slot, bool late = false) {
         const long long t = seq.tile(i < cnt ? i : cnt - 1);
         const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)act_blk * 1024 + lane * 16;
         const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)dz_blk * 1024 + lane * 16;
@@ -124,13 +134,13 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
-            glds16(src_in + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch));
+            glds16(src_in + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
         }
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_DZ;
-            glds16(src_dz + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch));
+            glds16(src_dz + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch), late);
         }
     };
     f32x16 acc[NACC];
@@ -154,28 +164,51 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
         STAMP(s2);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
+#ifdef KNERF_WGRAD_EARLY_ISSUE     // A/B knob: the older order (copies issued right behind the barrier)
         issue(i + NS - 1, nslot);
+#endif
         STAMP(s3);
         const char* in_reg = smem + slot * TILE_BYTES;
         const char* dz_reg = in_reg + BLK_IN * 1024;
 #ifdef KNERF_WGRAD_ABLATE_COMPUTE     // timing experiment only: pure streaming
         if (cnt < 0)
 #endif
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
-            // branch-free rows: a wave whose row index is the bias row (it == NI) swaps in the all-ones tile, rows past
-            // it compute on a clamped (valid) tile and are dropped at the flush -- no control flow between the
-            // transposed reads, so they issue back to back
-            bf16x8 afr[NACC];
+        {
+        // branch-free rows: a wave whose row index is the bias row (it == NI) swaps in the all-ones tile, rows past
+        // it compute on a clamped (valid) tile and are dropped at the flush -- no control flow between the
+        // transposed reads, so they issue back to back
+        auto read_k = [&](int kk, bf16x8& b, bf16x8 (&afr)[NACC]) {
+            b = tr_frag(dz_reg, wo, kk, lane_off);
 #pragma unroll
             for (int n = 0; n < NACC; ++n) {
                 const int it = wi + n * WI;
                 afr[n] = tr_frag(in_reg, it < NI ? it : NI - 1, kk, lane_off);
                 if (WI * NACC > NI && it >= NI) afr[n] = ones;
             }
+        };
+#ifndef KNERF_WGRAD_EARLY_ISSUE
+        // Order inside a tile: both halves' fragments are requested first, the copies of tile i+NS-1 are issued behind the first
+        // half's MFMAs (all eight waves queue their copies at once -- about 500 cycles of the CU's address path per 32 KiB tile --
+        // and a wave stalls on its own: with products already queued the matrix pipe works through that stall), then the rest.
+        constexpr bool kBoth = NACC <= 9;      // register budget: 16 NACC accumulators + 2 x 4 (NACC + 1) operands
+        bf16x8 b0, b1, afr0[NACC], afr1[NACC];
+        read_k(0, b0, afr0);
+        if (kBoth) read_k(1, b1, afr1);
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr0[n], b0, acc[n], 0, 0, 0);
+        issue(i + NS - 1, nslot, true);
+        if (!kBoth) read_k(1, b1, afr1);
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr1[n], b1, acc[n], 0, 0, 0);
+#else
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 b, afr[NACC];
+            read_k(kk, b, afr);
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
+        }
+#endif
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
 #ifdef KNERF_WGRAD_STAMPS
@@ -260,17 +293,17 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
             lane_off[r] = par * 1024 + (2 * (4 * (h ^ par) + 8 * r + q) + (p & 1)) * 16 + (p >> 1) * 8;
         enc_off = (2 * (lane & 31) + (lane >> 5)) * 16;      // saved_off(b even, h, s); odd b: s ^ 4  <=>  byte offset ^ 128
     }
-    auto issue = [&](long long i, int slot) {
+    auto issue = [&](long long i, int slot, bool late = false) {
         const long long t = seq.tile(i < cnt ? i : cnt - 1);
         const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)kActEnc * 1024 + lane * 16;
         const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)16 * 1024 + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
         const bool ok = wave < BLK_IN;
-        glds16(src_in + (ok ? wave : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch));
+        glds16(src_in + (ok ? wave : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
-            glds16(src_dz + b * 1024, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024));
+            glds16(src_dz + b * 1024, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024), late);
         }
     };
     f32x16 acc[NACC];
@@ -311,7 +344,6 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 3)) : "memory");
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 and h0(i-1) are free
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
-        issue(i + NS - 1, nslot);
         const char* dz_reg = smem + slot * TILE_BYTES + BLK_IN * 1024;
         const char* xr = xch + (int)(i & 1) * (kXch / 2);
 #pragma unroll
@@ -323,6 +355,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
             afr[NI] = ones;
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
+            if (kk == 0) issue(i + NS - 1, nslot, true);      // behind the first half's MFMAs (see wgrad_job_body)
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
         recompute(smem + slot * TILE_BYTES, (int)((i + 1) & 1));               // past the end: the clamped re-read of the last tile, unused
@@ -332,6 +365,145 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
 
     const int* dst = a.dst + a.job_off[job];
     const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        if (n < NI) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * n + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int d = dst[row * NCOLS + 32 * wo + c];
+#ifdef KNERF_WGRAD_ABLATE_FLUSH
+                asm volatile("" ::"v"(acc[n][i]), "v"(d));
+#else
+                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
+#endif
+            }
+        } else {
+            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
+            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
+        }
+    }
+}
+
+// layer_7 with dz7 RECOMPUTED.  dz7 = mask7 * (H dz_head) has only 4 input channels (the collapsed head, layout.h), so the dgrad
+// kernel does not write it: this job stages h6 (16 blocks), the dz_head block and the layer-7 mask block per tile (18 KiB); every
+// wave recomputes the 32 columns of dz7 that its output strip needs with ONE MFMA in the orientation D[sample][feature] =
+// dz_head . H^T (lane = feature, registers = samples: a B operand of the weight-gradient product as it stands, in the
+// accumulator's sample order), clears the entries whose forward activation was not positive (one 32-bit LDS read of the mask
+// block per accumulator register) and rounds to bf16 exactly as the dgrad chain does.  The h6 fragments are read with the same
+// sample permutation as in wgrad_l1_recompute.  H's fragment is the dgrad stream's own block `wo` (stage B0).
+// The recompute of tile i+1 runs inside tile i's MFMA sequence (its VALU selects and conversions issue between MFMAs), so
+// the strip is a register operand by the time the tile's own products start.
+__device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const ContigSeq seq, char* smem) {
+    constexpr int NI = 8, BLK_IN = 16, BLK_X = 2;           // x: [0] dz_head block, [1] mask7 block
+    constexpr int TILE_BYTES = (BLK_IN + BLK_X) * 1024;
+    constexpr int G = 3;                                     // 2 h6 copies + 1 (dz_head / mask / padding) per wave and tile
+    constexpr int NS = 8;                                    // 18 KiB tiles: eight slots, six tiles in flight behind the two in use
+    static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
+    constexpr int job = 7, NACC = NI + 1, NCOLS = 256;
+
+    const long long cnt = seq.count();
+    if (cnt <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave;
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned scratch = smem_base + NS * TILE_BYTES + wave * 1024;
+
+    const bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(a.bwd_stream + (size_t)wo * 1024 + lane * 16);   // H[feature 32 wo + (lane&31)][channel 8h+j]
+    int lane_off[2];
+    int zoff;                   // this lane's 16 bytes of the (even) dz_head block: lane = (sample, half)
+    int moff, mbit;             // mask word of (feature column of this lane, sample 0) and the bit inside it
+    {
+        const int grp = lane >> 4, par = grp & 1, h = grp >> 1, il = lane & 15, q = il >> 2, p = il & 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            lane_off[r] = par * 1024 + (2 * (4 * (h ^ par) + 8 * r + q) + (p & 1)) * 16 + (p >> 1) * 8;
+        zoff = (2 * (lane & 31) + (lane >> 5)) * 16;
+        // forward (mlp_fwd.hip relu_epi): the lane of sample s and half hf = (c >> 2) & 1 holds feature 32 ot + c of out tile ot in
+        // accumulator register i = (c & 3) + 4 (c >> 3); its mask bit sits in word ot >> 1 at (ot & 1) * 8 + (i >> 1) + 16 (i & 1)
+        const int c = lane & 31, hf = (c >> 2) & 1, i = (c & 3) + 4 * (c >> 3);
+        moff = hf * 32 * 16 + (wo >> 1) * 4;
+        mbit = (wo & 1) * 8 + (i >> 1) + 16 * (i & 1);
+    }
+    static_assert((kDzHead & 1) == 0, "dz_head block parity");
+    auto issue = [&](long long i, int slot, bool late = false) {
+        const long long t = seq.tile(i < cnt ? i : cnt - 1);
+        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)act_h(6) * 1024 + lane * 16;
+        const unsigned dst = smem_base + slot * TILE_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int b = r * kWgWaves + wave;
+            glds16(src_in + b * 1024, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
+        }
+        const char* src_x = wave == 1 ? a.mask + (size_t)t * kMaskTileBytes + 7 * 1024 + lane * 16
+                                      : a.dz + (size_t)t * kDzTileBytes + (size_t)kDzHead * 1024 + lane * 16;
+        glds16(src_x, __builtin_amdgcn_readfirstlane(wave < 2 ? dst + (BLK_IN + wave) * 1024 : scratch), late);
+    };
+    const int hh = lane >> 5;
+    // my strip of dz7 for one tile's 32 samples, in two steps so that the loop can put the second one behind MFMAs of the
+    // current tile: (1) the MFMA and the mask words, (2) select + round
+    auto dz7_mfma = [&](const char* x_reg, f32x16& dzf, unsigned (&mw)[16]) {
+        const bf16x8 z = *reinterpret_cast<const bf16x8*>(x_reg + zoff);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int smp = (r & 3) + 8 * (r >> 2) + 4 * hh;             // sample row of accumulator register r
+            mw[r] = *reinterpret_cast<const unsigned*>(x_reg + 1024 + smp * 16 + moff);
+        }
+        dzf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z, hfrag, zero_acc(), 0, 0, 0);
+    };
+    auto dz7_pack = [&](f32x16& dzf, const unsigned (&mw)[16], bf16x8 (&bfr)[2]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dzf[r] = ((mw[r] >> mbit) & 1u) ? dzf[r] : 0.f;
+        pack_acc(dzf, bfr[0], bfr[1]);
+    };
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[n] = zero_acc();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    asm volatile("" ::"v"(hfrag));   // the wait for this global load is pinned here: inside the loop it would be a vmcnt(0) that drains the LDS-DMA pipeline every tile
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    bf16x8 bnext[2];
+    {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile 0 landed
+        __builtin_amdgcn_s_barrier();
+        f32x16 dzf; unsigned mw[16];
+        dz7_mfma(smem + BLK_IN * 1024, dzf, mw);
+        dz7_pack(dzf, mw, bnext);
+    }
+    int slot = 0;
+    for (long long i = 0; i < cnt; ++i) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 3)) : "memory");   // tile i+1 landed (mine) ...
+        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
+        int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
+        const char* in_reg = smem + slot * TILE_BYTES;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        bf16x8 bfr[2] = {bnext[0], bnext[1]};
+        f32x16 dzf; unsigned mw[16];
+        dz7_mfma(smem + slot * TILE_BYTES + BLK_IN * 1024, dzf, mw);           // tile i+1 (past the end: the clamped re-read, unused)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 afr[NACC];
+#pragma unroll
+            for (int n = 0; n < NI; ++n) afr[n] = tr_frag(in_reg, n, kk, lane_off);
+            afr[NI] = ones;
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], bfr[kk], acc[n], 0, 0, 0);
+            if (kk == 0) {
+                issue(i + NS - 1, nslot, true);                // behind the first half's MFMAs (see wgrad_job_body)
+                dz7_pack(dzf, mw, bnext);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int* dst = a.dst + a.job_off[job];
+    const int c = lane & 31;
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (n < NI) {
@@ -362,7 +534,7 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, cons
         case 4: wgrad_job_body<8, 8>(a, 4, act_h(3), 16 * 4, seq, smem); break;
         case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, seq, smem); break;
         case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, seq, smem); break;
-        case 7: wgrad_job_body<8, 8>(a, 7, act_h(6), 16 * 7, seq, smem); break;
+        case 7: wgrad_l7_recompute(a, seq, smem); break;                                  // dz7 recomputed from dz_head and the mask
         case 8: wgrad_job_body<9, 1>(a, 8, kActH7, kDzHead, seq, smem); break;      // head: [h7 ; dir] x (r, g, b, sigma)
         default: break;
     }

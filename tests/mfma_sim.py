@@ -135,6 +135,33 @@ def act_run(saved):
     return run
 
 
+def mask_block_words(mask_tiles):
+    """one layer's relu mask block as the forward stores it (mlp_fwd.hip relu_epi): [64 lanes][4 words]; out tile ot, accumulator
+    register i of lane l -> word ot >> 1, bit (ot & 1) * 8 + (i >> 1) + 16 * (i & 1)"""
+    w = np.zeros((64, 4), np.uint32)
+    for ot, m in enumerate(mask_tiles):
+        for i in range(16):
+            bit = (ot & 1) * 8 + (i >> 1) + 16 * (i & 1)
+            w[:, ot >> 1] |= (m[:, i].astype(np.uint32) << np.uint32(bit))
+    return w
+
+
+def recompute_dz7_frags(zhead_img, bwd_frags, mask_words, wo):
+    """wgrad_l7_recompute: D[sample][feature strip wo] = dz_head . H^T (dz_head as the A operand, the dgrad stream's block wo as B),
+    masked per (feature, sample) from the forward's mask block, bf16: the two B-operand fragments of output strip wo"""
+    z = saved_block_frag(zhead_img, K_DZ_HEAD)
+    acc = mfma(z, bwd_frags[wo], np.zeros((64, 16), np.float32))
+    for l in range(64):
+        c, hh = l & 31, l >> 5
+        hf, i = (c >> 2) & 1, (c & 3) + 4 * (c >> 3)
+        bit = (wo & 1) * 8 + (i >> 1) + 16 * (i & 1)
+        for r in range(16):
+            smp = (r & 3) + 8 * (r >> 2) + 4 * hh
+            if not (int(mask_words[smp + 32 * hf, wo >> 1]) >> bit) & 1:
+                acc[l, r] = 0.0
+    return pack_acc(acc)
+
+
 def backward_chain(bwd_tab, flat, rgb, sigma, drgb, dsigma, masks):
     """Mirror of mlp_bwd_kernel for one wave.  Returns the dz run memory image [130*512]."""
     frags = gather_blocks(bwd_tab, flat)
@@ -161,7 +188,7 @@ def backward_chain(bwd_tab, flat, rgb, sigma, drgb, dsigma, masks):
             lo, hi = pack_acc(acc)
             outs += [lo, hi]
         return outs
-    dz = stage(0, [zhead], masks[7]); put(16 * 7, dz)
+    dz = stage(0, [zhead], masks[7])                 # dz7 stays in registers: it is not written (the layer_7 wgrad job recomputes it)
     for st in range(1, 8):
         layer = 6 - (st - 1)
         dz = stage(st, dz, masks[layer]); put(16 * layer, dz)
@@ -241,29 +268,32 @@ def head_expand(w_ext, aux, grad):
     return grad
 
 
-def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext, fwd_tab=None, bias_tab=None):
+def wgrad(act_runs, dz_runs, dst_tab, job_off, n_params, w_ext, fwd_tab=None, bias_tab=None, bwd_tab=None, mask7_words=None):
     """Mirror of wgrad_kernel over a list of tiles + head_expand: returns the flat gradient.  Destinations >= n_params
-    address the head accumulator (csrc/layout.h kAuxBase).  Job 1 recomputes h0 from enc (fwd_tab / bias_tab needed)."""
+    address the head accumulator (csrc/layout.h kAuxBase).  Job 1 recomputes h0 from enc (fwd_tab / bias_tab needed), job 7
+    recomputes dz7 from dz_head and the layer-7 mask block (bwd_tab / mask7_words: one [64,4] word array per tile)."""
     grad = np.zeros(n_params + AUX_COUNT, np.float64)
     fwd_frags = gather_blocks(fwd_tab, w_ext) if fwd_tab is not None else None
+    bwd_frags = gather_blocks(bwd_tab, w_ext) if bwd_tab is not None else None
     ones = np.ones((64, 8), np.float32)
     for jb, (ab, n_it, db, n_ot) in WGRAD_JOBS.items():
         dst = dst_tab[job_off[jb]:job_off[jb + 1]].reshape(n_it * 32 + 1, n_ot * 32)
         acc = {(it, ot): np.zeros((64, 16), np.float32) for it in range(n_it + 1) for ot in range(n_ot)}
-        for act, dz in zip(act_runs, dz_runs):
+        for ti, (act, dz) in enumerate(zip(act_runs, dz_runs)):
             in_reg = act[ab * 512:(ab + 2 * n_it) * 512]
             dz_reg = dz[db * 512:(db + 2 * n_ot) * 512]
             h0 = recompute_h0_frags(act[ab * 512:(ab + 4) * 512], fwd_frags, bias_tab, w_ext) if jb == 1 else None
+            dz7 = [recompute_dz7_frags(dz[K_DZ_HEAD * 512:(K_DZ_HEAD + 1) * 512], bwd_frags, mask7_words[ti], ot) for ot in range(8)] if jb == 7 else None
             for kk in range(2):
                 for ot in range(n_ot):
-                    b = tr_frag(dz_reg, ot, kk, permuted=(jb == 1))
+                    b = dz7[ot][kk] if jb == 7 else tr_frag(dz_reg, ot, kk, permuted=(jb == 1))
                     for it in range(n_it + 1):
                         if it == n_it:
                             a = ones
                         elif jb == 1:
                             a = h0[it][kk]
                         else:
-                            a = tr_frag(in_reg, it, kk)
+                            a = tr_frag(in_reg, it, kk, permuted=(jb == 7))
                         acc[(it, ot)] = mfma(a, b, acc[(it, ot)])
         for (it, ot), A in acc.items():
             for l in range(64):

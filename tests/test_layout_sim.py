@@ -65,17 +65,17 @@ def test_backward_chain_and_wgrad_match_oracle(setup):
     fwd, bias, bwd = D.debug_table(0), D.debug_table(1), D.debug_table(2)
     dst_tab, job_off = D.debug_table(3), D.debug_table(4)
     rng = np.random.default_rng(8)
-    acts, dzs, xs, ds, drgbs, dsigs = [], [], [], [], [], []
+    acts, dzs, xs, ds, drgbs, dsigs, m7 = [], [], [], [], [], [], []
     for tile in range(2):
         pt = (p + rng.normal(0, 0.3, p.shape)).astype(np.float32)
         rgb, sigma, saved = M.forward_chain(fwd, bias, flat, pt, d)
         drgb = rng.normal(0, 1, (32, 3)).astype(np.float32)
         dsig = rng.normal(0, 1, (32,)).astype(np.float32)
-        acts.append(M.act_run(saved))
+        acts.append(M.act_run(saved)); m7.append(M.mask_block_words(saved["masks"][7]))
         dzs.append(M.backward_chain(bwd, flat, rgb, sigma, drgb, dsig, saved["masks"]))
         xs.append(pt); ds.append(d); drgbs.append(drgb); dsigs.append(dsig)
     n_par = O.param_count(cfg)
-    grad = M.wgrad(acts, dzs, dst_tab, job_off, n_par, flat, fwd, bias)
+    grad = M.wgrad(acts, dzs, dst_tab, job_off, n_par, flat, fwd, bias, bwd, m7)
     xyz = O.positional_encoding(np.concatenate(xs), 10)[None]
     dire = O.positional_encoding(np.concatenate(ds), 4)[None]
     _, _, cache = O.mlp_forward(params, xyz, dire, cfg, emulate_bf16=O.FUSED, want_cache=True)

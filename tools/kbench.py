@@ -78,6 +78,6 @@ for k, (ms, n) in res.items():
     fl = FWD if "fwd" in k else DG if "bwd" in k else WG if "wgrad" in k else 0
     out[k] = {"ms": round(avg, 4), "TFLOPs": round(fl * S / (avg * 1e-3) / 1e12, 1) if fl else None}
     if "wgrad" in k:
-        out[k]["TBs"] = round(S / 32 * 256 * 1024 / (avg * 1e-3) / 1e12, 2)
+        out[k]["TBs"] = round(S / 32 * 242 * 1024 / (avg * 1e-3) / 1e12, 2)
 tot = sum(v["ms"] for k, v in out.items() if k.startswith("train_"))
 print(json.dumps({"tag": args.tag, "rays": R, "train_chunk_ms": round(tot, 3), "Mrs_per_s": round(R * 256 / tot / 1e3, 1), "kernels": out}))
