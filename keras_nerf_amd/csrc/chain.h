@@ -136,7 +136,27 @@ struct Ring {
         const char* p = lds + ((b / kPageBlocks) % kSlots) * kPageBytes + (b % kPageBlocks) * 1024 + lane * 16;
         return *reinterpret_cast<const bf16x8*>(p);
     }
+#ifndef KNERF_COMPILER_FRAGS
+    // The same read as an instruction hipcc does not track (the default; -DKNERF_COMPILER_FRAGS restores the plain load): with
+    // the compiler's own bookkeeping every use of a prefetched fragment waits for lgkmcnt(0), i.e. also for the kPrefetch-1
+    // younger reads behind it -- counted waits: inference chain -4 %, training forward / dgrad -3 % (r02 A/B, two runs each).
+    // B is a compile-time block index; the 16-bit offset field covers three slots, `hi` selects the upper three.
+    template <int B>
+    __device__ __forceinline__ bf16x8 frag_asm(unsigned lane_lo, unsigned lane_hi) const {
+        constexpr int slot = (B / kPageBlocks) % kSlots;
+        constexpr int off = (slot % 3) * kPageBytes + (B % kPageBlocks) * 1024;
+        static_assert(kSlots <= 6 && off < 65536, "ds offset field");
+        bf16x8 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(slot < 3 ? lane_lo : lane_hi), "n"(off));
+        return v;
+    }
+#endif
 };
+#ifndef KNERF_COMPILER_FRAGS
+// the fragment becomes usable once at most N younger LDS operations are outstanding (LDS returns in order)
+template <int N>
+__device__ __forceinline__ void frag_wait(bf16x8& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
+#endif
 
 // bias tile -> accumulator init.  LDS holds fp32 [tile][32]; reg i of lane-half h is row (i&3) + 8*(i>>2) + 4h.
 __device__ __forceinline__ f32x16 bias_acc(const float* bias_lds, int tile, int h) {
@@ -220,10 +240,17 @@ __device__ __forceinline__ void apply_mask_packed(bf16x8& lo, bf16x8& hi, unsign
 constexpr int kPrefetch = KNERF_PREFETCH;
 struct Prefetch {
     bf16x8 a[kPrefetch];
+    unsigned lane_lo, lane_hi;          // LDS byte address of this lane's 16 bytes in slot 0 / slot 3
     template <int NBLOCKS>
     __device__ __forceinline__ void start(const Ring& ring, int lane) {
+#ifndef KNERF_COMPILER_FRAGS
+        lane_lo = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring.lds + lane * 16;
+        lane_hi = lane_lo + 3 * kPageBytes;
+        static_for<kPrefetch>([&](auto i_) { constexpr int i = decltype(i_)::value; a[i] = ring.template frag_asm<(i < NBLOCKS ? i : 0)>(lane_lo, lane_hi); });
+#else
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) a[i] = ring.frag(i < NBLOCKS ? i : 0, lane);
+#endif
     }
 };
 
@@ -259,7 +286,15 @@ __device__ __forceinline__ void dense_stage(const Ring& ring, Prefetch& pf, int 
                 if (grp == 1) ring.template sync<W::tab.n[b / 8]>(b / kPageBlocks - 1);
             }
             bf16x8 cur = pf.a[b % kPrefetch];
+#ifndef KNERF_COMPILER_FRAGS
+            {   // younger fragment reads behind block b's: kPrefetch-1, fewer at the end of the stream
+                constexpr int younger = NBLOCKS - 1 - b < kPrefetch - 1 ? NBLOCKS - 1 - b : kPrefetch - 1;
+                frag_wait<younger>(cur);
+            }
+            if constexpr (b + kPrefetch < NBLOCKS) pf.a[b % kPrefetch] = ring.template frag_asm<b + kPrefetch>(pf.lane_lo, pf.lane_hi);
+#else
             if constexpr (b + kPrefetch < NBLOCKS) pf.a[b % kPrefetch] = ring.frag(b + kPrefetch, lane);
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, in(ks), acc, 0, 0, 0);
         });
         epi(ot, acc);
