@@ -69,6 +69,23 @@ struct WgradPlan {          // one entry per workgroup, built on the host (knerf
 
 // 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
 // region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
+// Flush of one 32x32 accumulator tile: element i of lane (c, hh) goes to dst[(row0 + (i&3) + 8(i>>2)) * ncols + col] (an index into
+// the gradient buffer, >= kAuxBase: into the head sums, < 0: dropped).  The 16 table look-ups are requested together and the
+// atomics follow (element by element the look-up's latency was exposed 16 times per tile: 29 us per launch, 1030 atomics per wave).
+__device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, int row0, int ncols, int col, const f32x16& acc) {
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = __builtin_nontemporal_load(dst + (row0 + (i & 3) + 8 * (i >> 2)) * ncols + col);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#ifdef KNERF_WGRAD_ABLATE_FLUSH      // timing experiment only: what the atomic flush costs
+        asm volatile("" ::"v"(acc[i]), "v"(d[i]));
+#else
+        if (d[i] >= 0) atomicAdd(d[i] < kAuxBase ? a.grad + d[i] : a.aux + (d[i] - kAuxBase), acc[i]);
+#endif
+    }
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, const int (&lane_off)[2]) {
     const char* base = region + pair * 2048 + kk * 512;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[0]));
@@ -233,16 +250,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     for (int n = 0; n < NACC; ++n) {
         const int it = wi + n * WI;
         if (it < NI) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * it + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const int d = dst[row * NCOLS + 32 * wo + c];
-#ifdef KNERF_WGRAD_ABLATE_FLUSH      // timing experiment only: what the atomic flush costs
-                asm volatile("" ::"v"(acc[n][i]), "v"(d));
-#else
-                if (d >= 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][i]);
-#endif
-            }
+            flush_acc(a, dst, 32 * it + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else if (it == NI) {
             const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
             if (d >= 0 && hh == 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][0]);
@@ -368,16 +376,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (n < NI) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * n + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const int d = dst[row * NCOLS + 32 * wo + c];
-#ifdef KNERF_WGRAD_ABLATE_FLUSH
-                asm volatile("" ::"v"(acc[n][i]), "v"(d));
-#else
-                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
-#endif
-            }
+            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else {
             const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
             if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
@@ -507,16 +506,7 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (n < NI) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * n + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const int d = dst[row * NCOLS + 32 * wo + c];
-#ifdef KNERF_WGRAD_ABLATE_FLUSH
-                asm volatile("" ::"v"(acc[n][i]), "v"(d));
-#else
-                if (d >= 0) atomicAdd(a.grad + d, acc[n][i]);
-#endif
-            }
+            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else {
             const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
             if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
