@@ -67,8 +67,6 @@ struct WgradPlan {          // one entry per workgroup, built on the host (knerf
     int job, split, nsplit, pad;
 };
 
-// 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
-// region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
 // Flush of one 32x32 accumulator tile: element i of lane (c, hh) goes to dst[(row0 + (i&3) + 8(i>>2)) * ncols + col] (an index into
 // the gradient buffer, >= kAuxBase: into the head sums, < 0: dropped).  The 16 table look-ups are requested together and the
 // atomics follow (element by element the look-up's latency was exposed 16 times per tile: 29 us per launch, 1030 atomics per wave).
@@ -86,6 +84,8 @@ __device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, in
     }
 }
 
+// 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
+// region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
 __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, const int (&lane_off)[2]) {
     const char* base = region + pair * 2048 + kk * 512;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + lane_off[0]));
