@@ -112,56 +112,70 @@ struct GemmArgs {
     float* Cf; int ldcf;                 // fp32 output (may be null)
 };
 
-// epilogue shared by the two GEMM kernels: bias, relu, relu mask of the dgrad, bf16 / fp32 stores.  The launch-uniform
-// switches (fp32 or bf16 output, mask or not) are taken ONCE around the element loops and every address is a base pointer
-// plus a uniform multiple of the row pitch: left as per-element branches and 64-bit multiplies (what hipcc makes of the
-// straightforward loop) the epilogue costs more than the tile's 128 MFMAs.
+// epilogue shared by the two GEMM kernels: bias, relu, relu mask of the dgrad, bf16 / fp32 stores.
+// Column assignment: column r of the column block's tile t is output feature n0 + NT r + t (the kernels stage weight row
+// n0 + NT r + t at LDS row 32 t + r), NOT n0 + 32 t + r: lane r then holds NT CONSECUTIVE features of a sample row across its NT
+// accumulators, so a row's values leave as one 2 NT-byte store per lane -- for NT = 8 one instruction writes two whole 512-byte
+// rows, 16 store instructions per 32-row tile instead of 128 two-byte ones that each touch two rows (the epilogue used to issue as
+// many stores as the tile has MFMAs).  The launch-uniform switches (fp32 or bf16 output, mask or not) are taken ONCE around the loops.
+template <int NT> struct PackedRow;                    // NT bf16 values as one store
+template <> struct PackedRow<1> { typedef u16 type; };
+template <> struct PackedRow<2> { typedef unsigned int type; };
+template <> struct PackedRow<4> { typedef __attribute__((ext_vector_type(2))) unsigned int type; };
+template <> struct PackedRow<8> { typedef __attribute__((ext_vector_type(4))) unsigned int type; };
+template <int NT>
+__device__ __forceinline__ typename PackedRow<NT>::type pack_row(const float (&v)[NT]) {
+    u16 hw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) hw[t] = to_bf16(v[t]);
+    typename PackedRow<NT>::type out;
+    __builtin_memcpy(&out, hw, sizeof(out));
+    return out;
+}
 template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NT], long long m0, int n0, int r, int h) {
-    // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh
+    // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh; this lane's features: f0 .. f0 + NT - 1
     const size_t row0 = (size_t)(m0 + 4 * h);
+    const int f0 = n0 + NT * r;
+    float b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = (g.bias && f0 + t < g.n_real) ? g.bias[f0 + t] : 0.f;
     if (g.Cf) {                                   // fp32 head outputs (no mask, no relu)
+        float* p = g.Cf + row0 * g.ldcf + f0;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = n0 + 32 * t + r;
-            const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
-            float* p = g.Cf + row0 * g.ldcf + col;
+        for (int i = 0; i < 16; ++i) {
+            float* q = p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldcf;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldcf] = acc[t][i] + b;
+            for (int t = 0; t < NT; ++t) q[t] = acc[t][i] + b[t];
         }
     } else if (g.aux) {
-        // dgrad through the plain orientation (KNERF_GEN_DGRAD_PLAIN): the mask halfwords of tile t + 1 are requested
-        // while tile t is masked and stored
-        const u16* ax = g.aux + row0 * g.ldaux + n0 + r;
-        u16 mk[2][16];
+        // dgrad: dz = [saved post-relu activation > 0] * acc; the NT mask halfwords of a row are one load, the next row's
+        // requested while this one is masked and stored
+        typedef typename PackedRow<NT>::type P;
+        const u16* ax = g.aux + row0 * g.ldaux + f0;
+        u16* p = g.Cb + row0 * g.ldc + f0;
+        P mk[2];
+        mk[0] = *reinterpret_cast<const P*>(ax);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mk[0][i] = ax[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldaux];
+        for (int i = 0; i < 16; ++i) {
+            if (i + 1 < 16) mk[(i + 1) & 1] = *reinterpret_cast<const P*>(ax + (size_t)(((i + 1) & 3) + 8 * ((i + 1) >> 2)) * g.ldaux);
+            u16 mh[NT];
+            __builtin_memcpy(mh, &mk[i & 1], sizeof(P));
+            float v[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mk[(t + 1) & 1][i] = ax[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldaux + 32 * (t + 1)];
-            }
-            u16* p = g.Cb + row0 * g.ldc + n0 + 32 * t + r;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = (short)mk[t & 1][i] > 0 ? acc[t][i] : 0.f;
-                p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
-            }
+            for (int t = 0; t < NT; ++t) v[t] = (short)mh[t] > 0 ? acc[t][i] : 0.f;
+            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v);
         }
     } else {
+        typedef typename PackedRow<NT>::type P;
         const bool relu = g.relu != 0;
+        u16* p = g.Cb + row0 * g.ldc + f0;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = n0 + 32 * t + r;
-            const float b = (g.bias && col < g.n_real) ? g.bias[col] : 0.f;
-            u16* p = g.Cb + row0 * g.ldc + col;
+        for (int i = 0; i < 16; ++i) {
+            float v[NT];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = acc[t][i] + b;
-                v = relu ? fmaxf(v, 0.f) : v;
-                p[(size_t)((i & 3) + 8 * (i >> 2)) * g.ldc] = to_bf16(v);
-            }
+            for (int t = 0; t < NT; ++t) { v[t] = acc[t][i] + b[t]; v[t] = relu ? fmaxf(v[t], 0.f) : v[t]; }
+            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v);
         }
     }
 }
@@ -194,7 +208,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
             const int q = p * kGemmWaves * 64 + tid;
             const int row = q >> 3, cc = q & 7;
             const int k = kc * kGemmKC + cc * 8;
-            stage[p] = (row < NB && k < g.K) ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + row) * g.ldb + k) : uint4{0, 0, 0, 0};
+            // LDS row 32 t + r holds weight row n0 + NT r + t (column assignment of gemm_epilogue)
+            stage[p] = (row < NB && k < g.K) ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + NT * (row & 31) + (row >> 5)) * g.ldb + k) : uint4{0, 0, 0, 0};
         }
     };
     auto put_b = [&](int buf) {
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
     for (int q = tid; q < NB * gpr; q += kGemmWaves * 64) {
         const int row = q / gpr, cc = q % gpr;
         *reinterpret_cast<uint4*>(gsm + row * pitch + cc * 16) =
-            cc * 8 < g.K ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + row) * g.ldb + cc * 8) : uint4{0, 0, 0, 0};
+            cc * 8 < g.K ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + NT * (row & 31) + (row >> 5)) * g.ldb + cc * 8) : uint4{0, 0, 0, 0};   // gemm_epilogue's column assignment
     }
     __syncthreads();
     const long long n_tiles = g.M / 32;
