@@ -8,9 +8,16 @@ namespace knerf {
 template <int NET>
 __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef KNERF_WGRAD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wgrad_stamps[blockIdx.x * 8 + 6] = stamp();
+#endif
     const WgradPlan pl = reinterpret_cast<const WgradPlan*>(a.plan)[blockIdx.x];
     const ContigSeq seq{a.n_tiles * pl.split / pl.nsplit, a.n_tiles * (pl.split + 1) / pl.nsplit};
     wgrad_dispatch(a, pl.job, seq, smem);
+#ifdef KNERF_WGRAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wgrad_stamps[blockIdx.x * 8 + 7] = stamp() - g_wgrad_stamps[blockIdx.x * 8 + 7];
+#endif
 }
 
 #ifdef KNERF_WGRAD_STAMPS

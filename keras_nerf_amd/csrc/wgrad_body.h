@@ -234,9 +234,12 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 #endif
     }
 #ifdef KNERF_WGRAD_STAMPS
+    const unsigned long long t_loop_end = stamp();
     if (threadIdx.x == 0 && blockIdx.x < 1024) {
         unsigned long long* o = g_wgrad_stamps + blockIdx.x * 8;
         o[0] = c_wait; o[1] = c_bar; o[2] = c_issue; o[3] = c_comp; o[4] = (unsigned long long)cnt; o[5] = job;
+        o[6] = t_loop_end - (c_wait + c_bar + c_issue + c_comp) - o[6];     // entry (stored by wgrad_kernel) -> first iteration
+        o[7] = t_loop_end;                                                   // wgrad_kernel turns this into loop end -> exit
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

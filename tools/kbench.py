@@ -68,6 +68,8 @@ if hasattr(ctx.lib, "knerf_debug_wgrad_stamps"):
         tiles = r[:, 4].astype(float)
         per[int(j)] = {k: round(float((r[:, i] / tiles).mean()), 1) for i, k in enumerate(["wait", "barrier", "issue", "compute"])}
         per[int(j)]["tiles_per_wg"] = float(tiles.mean())
+        per[int(j)]["entry_to_loop"] = float(r[:, 6].astype(float).mean()); per[int(j)]["loop_end_to_exit"] = float(r[:, 7].astype(float).mean())
+        per[int(j)]["loop_total"] = float(r[:, 0:4].sum(1).astype(float).mean())
     print(json.dumps({"wgrad_cycles_per_tile_by_job": per}))
 out = {}
 for k, (ms, n) in res.items():
