@@ -73,6 +73,7 @@ struct knerf_ctx {
     float* call_raw = nullptr;
     // workspaces (grow-only)
     int ws_rays = 0; bool ws_train = false;
+    int ws_group = 1;                   // training workspaces hold this many chunks (knerf_train_batch: one wgrad launch per group)
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
     char *act = nullptr, *mask = nullptr, *dz = nullptr;
     size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
