@@ -37,7 +37,11 @@ typedef struct knerf_config {
     int32_t white_background;          /* compile(white_background=...) */
     int32_t oob_clamp;                 /* 0: out-of-range mid-point gather yields 0 (tf.gather on GPU); 1: clamp */
     float lr, beta1, beta2, epsilon;   /* 1e-3, 0.9, 0.999, 1e-7 */
+    int32_t flags;                     /* KNERF_FLAG_* */
 } knerf_config;
+
+/* run the default NeRFMLP shape through the general-shape kernels too (tests compare the two paths) */
+enum { KNERF_FLAG_FORCE_GENERIC = 1 };
 
 enum { KNERF_COARSE = 0, KNERF_FINE = 1 };
 
@@ -117,6 +121,25 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream);
  * wait == 0 reads the device-written status word as it stands (steps that have completed). */
 int knerf_poll_nonfinite(knerf_ctx* ctx, void* stream, int wait);
 int knerf_zero_grads(knerf_ctx* ctx, void* stream);
+
+/* Run-time options of a context (no environment variables are read by the library).  Names:
+ *   "deterministic"     0/1  weight gradients and losses without floating-point atomics: every workgroup writes its partial sums
+ *                            to its own slab and an ordered second pass adds them, so two runs of the same step are bit-identical
+ *                            (slower; the reference's TF ops give no such guarantee either -- this is a test/diagnosis mode).
+ *   "skip_dead_tiles"   0/1  the backward kernels skip every 32-sample tile whose dL/d(rgb, sigma) is EXACTLY zero for all samples
+ *                            (empty space with a closed ReLU gate on sigma, rays whose pixel error is exactly 0): such samples add
+ *                            exactly nothing to any of the 48 gradient tensors (utils.py:36-45, mlp.py:40), so the result is the
+ *                            same; applies to the default MLP shape when n_coarse and n_coarse + n_fine are multiples of 32.
+ *   "wgrad_group_max"   1..64, "wgrad_group_gb" >= 0: chunks per coarse weight-gradient launch of knerf_train_batch and the memory
+ *                            budget of the workspaces that takes (defaults 4 and 40 GB; 1 or 0 = one launch per chunk).
+ *   "wgrad_cost0".."wgrad_cost8": relative cost per sample tile of the nine weight-gradient jobs (workgroups are dealt out in that
+ *                            proportion; tuning sweeps).
+ * knerf_get_option also answers "skip_dead_tiles_active", "wgrad_group" (of the current workspaces) and "general_shape_path". */
+int knerf_set_option(knerf_ctx* ctx, const char* name, double value);
+int knerf_get_option(knerf_ctx* ctx, const char* name, double* value);
+/* running totals since the last reset: 32-sample tiles the dgrad launches found live / all tiles they covered (skip_dead_tiles
+ * on; both 0 otherwise).  Synchronises `stream`. */
+int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset);
 int knerf_step_count(const knerf_ctx* ctx);
 int knerf_set_step_count(knerf_ctx* ctx, int step);
 

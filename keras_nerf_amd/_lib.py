@@ -16,7 +16,10 @@ class KnerfConfig(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pos_emb_xyz", C.c_int32), ("pos_emb_dir", C.c_int32),
                 ("n_layers", C.c_int32), ("dense_units", C.c_int32), ("skip_layer", C.c_int32),
                 ("white_background", C.c_int32), ("oob_clamp", C.c_int32),
-                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float)]
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float), ("flags", C.c_int32)]
+
+
+FLAG_FORCE_GENERIC = 1
 
 
 _P = C.c_void_p
@@ -41,6 +44,9 @@ SIGNATURES = {
     "knerf_apply_adam": (C.c_int, [_P, _P]),
     "knerf_poll_nonfinite": (C.c_int, [_P, _P, C.c_int]),
     "knerf_zero_grads": (C.c_int, [_P, _P]),
+    "knerf_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "knerf_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
+    "knerf_tile_stats": (C.c_int, [_P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "knerf_ray_points": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "knerf_image_metrics": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

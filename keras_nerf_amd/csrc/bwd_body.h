@@ -54,16 +54,23 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: per-tile base pointers stay in SGPRs
     const int grp = wave >> 2;                                    // stagger group (chain.h): 0 = waves 0-3, 1 = waves 4-7
     const int col = lane & 31, h = lane >> 5;
-    const long long tile = wg_tile * kWaves + wave;
+    long long tile = wg_tile * kWaves + wave;
+    if (a.live) {
+        // dead-tile skipping (composite.hip tile flags -> compact_tiles): the grid covers every tile, workgroups past the live
+        // count leave at once; the last live workgroup's spare waves redo its last tile (identical stores)
+        const int n_live = *a.n_live;
+        if (wg_tile * kWaves >= n_live) return;
+        tile = a.live[tile < n_live ? tile : n_live - 1];
+    }
     long long g = tile * kTile + col;
     const bool valid = g < a.n_samples;
     if (!valid) g = a.n_samples - 1;
 
     // everything this wave reads with ordinary loads is fetched (and waited for) before the LDS-DMA ring starts
     u32x4 mk[8];
-    const char* maskp = a.mask + (size_t)tile * kMaskTileBytes + lane * 16;
+    const char* maskp = a.mask + mask_tile_off((size_t)tile) + lane * 16;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const u32x4*>(maskp + l * 1024);
+    for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const u32x4*>(maskp + l * kSavedBlockStride);
     const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[g];
     f32x4 dr = reinterpret_cast<const f32x4*>(a.draw)[g];
     if (!valid) dr = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -79,7 +86,7 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
         zhead[2] = (__bf16)(dr[2] * raw[2] * (1.f - raw[2]));
         zhead[3] = (__bf16)(raw[3] > 0.f ? dr[3] : 0.f);
     }
-    char* dz = a.dz + (size_t)tile * kDzTileBytes;
+    char* dz = a.dz + dz_tile_off((size_t)tile);
     store_block(dz, kDzHead, lane, zhead);     // block kDzHead+1 stays zero (the buffer is zero-initialised)
 
     asm volatile("" ::: "memory");            // the store above stays ahead of the first LDS-DMA in program order

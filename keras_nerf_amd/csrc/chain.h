@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <utility>
 
+#include "layout.h"
+
 namespace knerf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -323,7 +325,7 @@ __device__ __forceinline__ void store16_wt(char* base, unsigned off, const u32x4
 // `base` must be wave-uniform (it lives in SGPRs).
 __device__ __forceinline__ void store_block(char* base, int block, int lane, const bf16x8& v) {
     const int s = lane & 31, h = lane >> 5;
-    store16_wt(base, (unsigned)(block * 1024 + (2 * (s ^ ((block & 1) << 2)) + h) * 16), __builtin_bit_cast(u32x4, v));
+    store16_wt(base, (unsigned)(block * kSavedBlockStride + (2 * (s ^ ((block & 1) << 2)) + h) * 16), __builtin_bit_cast(u32x4, v));
 }
 
 }  // namespace knerf

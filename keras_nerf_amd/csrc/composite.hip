@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     // one atomic per block (4 rays) instead of one per ray: 4096 same-address atomics cost more than the kernel's work
     if (lane == 0) s_loss[wv] = l2 * a.loss_scale;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.loss, (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
+    if (threadIdx.x == 0) {
+        const float l4 = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        if (a.loss_partial) a.loss_partial[blockIdx.x] = l4;       // deterministic mode: summed in order by loss_reduce_kernel
+        else atomicAdd(a.loss, l4);
+    }
     const float gsum = (a.white & 1) ? (gi[0] + gi[1] + gi[2]) : 0.f;
     float dw[C], pr[C];
     float suffix = 0.f;            // lane-local exclusive suffix sums of dw*w, built right to left
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     float excls = __shfl_down(incs, 1, 64);
     if (lane == 63) excls = 0.f;
     f32x4* draw = reinterpret_cast<f32x4*>(a.draw) + (size_t)ray * S;
+    unsigned live = 0;             // bit k: this lane holds a sample of the ray's k-th 32-sample tile that the backward needs
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int i = lane * C + c;
@@ -123,9 +128,62 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
             const float Q = Ql[c] + excls;
             const float dalpha = dw[c] * T[c] - Q / x[c];
             const float dsig = dalpha * dl[c] * ex[c];
-            draw[i] = f32x4{w[c] * gi[0], w[c] * gi[1], w[c] * gi[2], dsig};
+            const f32x4 v = f32x4{w[c] * gi[0], w[c] * gi[1], w[c] * gi[2], dsig};
+            draw[i] = v;
+            // A sample is DEAD when the dgrad chain's input is exactly zero for it: dz_rgb = drgb * rgb (1 - rgb) with drgb == 0, and
+            // dz_sigma = [sigma > 0] dsigma with dsigma == 0 or the ReLU gate closed (sigma == 0).  Every dZ of the sample is then
+            // +-0 and it adds exactly nothing to any weight or bias gradient (mlp_bwd / wgrad skip whole tiles of such samples).
+            const bool dead = v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && (v[3] == 0.f || sg[c] == 0.f);
+            if (!dead) live |= 1u << (i >> 5);
         }
     }
+    if (a.tile_flags) {            // S % 32 == 0 (checked by the caller): tiles do not straddle rays, S / 32 <= 16 of them per ray
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) live |= __shfl_xor(live, o, 64);
+        const int nt = S >> 5;
+        if (lane < nt) a.tile_flags[(size_t)ray * nt + lane] = (live >> lane) & 1u;
+    }
+}
+
+// ---- dead-tile skipping: flags -> ascending list of live tiles.  One workgroup; a launch covers at most a few hundred thousand tiles.
+__global__ __launch_bounds__(1024) void compact_tiles_kernel(const int* flags, int n, int period, int real, int* list, int* count, long long* stats) {
+    __shared__ int s_cnt[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = i0 + per < n ? i0 + per : n;
+    auto is_live = [&](int i) { return (i % period) < real && flags[i] != 0; };
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += is_live(i) ? 1 : 0;
+    s_cnt[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {           // inclusive scan of the per-thread counts
+        const int v = tid >= o ? s_cnt[tid - o] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_cnt[tid] - c;
+    for (int i = i0; i < i1; ++i) if (is_live(i)) list[pos++] = i;
+    if (tid == 1023) {
+        *count = s_cnt[1023];
+        if (stats) { stats[0] += s_cnt[1023]; stats[1] += (long long)(n / period) * real + ((n % period) < real ? (n % period) : real); }
+    }
+}
+hipError_t launch_compact_tiles(const int* flags, int n, int period, int real, int* list, int* count, long long* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_tiles_kernel, dim3(1), dim3(1024), 0, stream, flags, n, period, real, list, count, stats);
+    return hipGetLastError();
+}
+
+// ---- deterministic mode: the chunk's loss terms added in a fixed order (one wavefront)
+__global__ __launch_bounds__(64) void loss_reduce_kernel(const float* partial, int n, float* loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *loss += s;
+}
+hipError_t launch_loss_reduce(const float* partial, int n, float* loss, hipStream_t stream) {
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, stream, partial, n, loss);
+    return hipGetLastError();
 }
 
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {

@@ -71,12 +71,32 @@ struct knerf_ctx {
     knerf::gen::Workspace call_ws;
     knerf::gen::NetDev call_net;
     float* call_raw = nullptr;
-    // workspaces (grow-only)
+    // run-time options (knerf_set_option)
+    bool deterministic = false;         // per-workgroup partial sums + ordered second pass instead of fp32 atomics (wgrad, loss)
+    bool skip_dead = false;             // dgrad / wgrad skip 32-sample tiles whose dL/d(rgb, sigma) is exactly zero
+    int wgrad_group_max = 4;            // chunks per coarse weight-gradient launch of knerf_train_batch (1 = one launch per chunk)
+    double wgrad_group_gb = 40.0;       // memory budget of those grouped workspaces
+    int wgrad_cost[knerf::kWgradJobs] = {128, 264, 204, 204, 204, 267, 204, 240, 193};   // workgroups per job ~ cost (build_wgrad_plan)
+    bool plan_dirty = false;
+    int group_cache_rays = 0, group_cache_chunks = 0, group_cache = 0;   // wgrad_group_for memo (hipMemGetInfo is a driver call)
+    // workspaces (grow-only).  Inference buffers (raw, w_c, t_f, img_tmp) follow the largest chunk seen by any call; the training
+    // buffers (draw, act, mask, dz, tile lists) follow the largest TRAINING chunk and group only, so that rendering with a larger
+    // ray_chunks does not re-size them.
     int ws_rays = 0; bool ws_train = false;
+    int ws_train_rays = 0;
     int ws_group = 1;                   // training workspaces hold this many chunks (knerf_train_batch: one wgrad launch per group)
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
     char *act = nullptr, *mask = nullptr, *dz = nullptr;
     size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
+    // dead-tile skipping: per-tile flags of the training workspaces (composite.hip), the compacted list and its length, running
+    // totals (live, all) of the tiles seen by the dgrad launches
+    int *tile_flags = nullptr, *tile_list = nullptr, *tile_count = nullptr;
+    long long* tile_stats = nullptr;
+    size_t ws_tiles = 0;
+    // deterministic mode: per-workgroup weight-gradient slabs, per-workgroup loss terms, plan offsets of the jobs
+    float *partial = nullptr, *loss_partial = nullptr;
+    int partial_plan = 0;
+    int* d_job_wg0 = nullptr;
     // optional per-kernel timing with HIP events on the caller's stream (knerf_profile_*)
     bool prof_on = false;
     struct ProfRec { int id; hipEvent_t e0, e1; };

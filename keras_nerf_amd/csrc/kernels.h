@@ -46,6 +46,8 @@ struct BwdArgs {
     char* dz;               // out: [tiles][kDzBlocks][1 KiB]
     long long n_samples;
     int net;                // 0 coarse / 1 fine: kernel instantiation name only
+    const int* live;        // dead-tile skipping: ascending list of the pass's live 32-sample tiles and its length (device), or null
+    const int* n_live;
 };
 hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 
@@ -64,8 +66,24 @@ struct WgradArgs {
     int n_plan;
     int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
     int job_off[10];        // offset of each job's table inside dst (kWgradJobs + 1)
+    float* partial;         // deterministic mode: [n_plan][kWgradPartialStride] per-workgroup sums instead of atomics (zero-filled by the caller), or null
+    const int* live;        // dead-tile skipping: ascending list of live tiles (relative to act / dz / mask) and its length (device), or null
+    const int* n_live;
+    int by_range;           // list mode: 0 = the live tiles are dealt out evenly over a job's workgroups; 1 = a workgroup takes the live
+                            //   tiles inside the range [n_tiles s/ns, n_tiles (s+1)/ns) it would own without skipping (same sums per
+                            //   workgroup as the non-skipping launch: the deterministic mode's bit-exactness check)
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
+// deterministic mode, after launch_wgrad: grad[dst] += sum over the job's workgroups (ascending split) of their partial slabs
+hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0 /* device: kWgradJobs+1 plan offsets */, hipStream_t stream);
+size_t wgrad_partial_floats(int n_plan);
+
+// dead-tile skipping: flags[i] (1 = some sample of tile i has a non-zero dL/d(rgb, sigma), written by the compositing kernel) ->
+// ascending list of the live tile indices among i in [0, n) with (i % period) < real, and their count; stats[0] += count,
+// stats[1] += number of real tiles (running totals for knerf_tile_stats), stats may be null
+hipError_t launch_compact_tiles(const int* flags, int n, int period, int real, int* list, int* count, long long* stats, hipStream_t stream);
+// deterministic mode: *loss += partial[0] + partial[1] + ... (fixed order)
+hipError_t launch_loss_reduce(const float* partial, int n, float* loss, hipStream_t stream);
 
 struct CompositeArgs {
     const float* raw;       // [R,S,4]
@@ -80,6 +98,8 @@ struct CompositeArgs {
     int white;
     float grad_scale;       // 2 / (3R) * inv_chunks  -> dL/dimage = grad_scale * (image - target)
     float loss_scale;       // inv_chunks / (3R)
+    int* tile_flags;        // training, S % 32 == 0 only: [R*S/32] 1 = the 32-sample tile has a sample with non-zero draw, 0 = dead; or null
+    float* loss_partial;    // deterministic mode: per-workgroup loss terms [ceil(R/4)] instead of one atomic per workgroup; or null
 };
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream);
 

@@ -25,8 +25,9 @@ std::string g_create_error;
 // Workgroups per wgrad job in proportion to the job's measured cost per sample tile (cycles per loop iteration from the
 // s_memtime stamps of a -DKNERF_WGRAD_STAMPS build, tools/kbench.py): the streaming jobs are HBM-bound, the small ones
 // (layer_0, head) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
-// KNERF_WGRAD_COSTS="c0,c1,...,c8" overrides the table (tuning sweeps in one gpurun call).
-std::vector<int32_t> build_wgrad_plan(int n_wg) {
+// knerf_set_option(ctx, "wgrad_cost<j>", c) overrides an entry (tuning sweeps in one gpurun call: tools/tune_costs.py).
+// job_wg0[j] = index of job j's first workgroup (kWgradJobs + 1 entries): the deterministic mode's second pass walks them in order.
+std::vector<int32_t> build_wgrad_plan(int n_wg, const int (&cost)[kWgradJobs], std::vector<int32_t>& job_wg0) {
     // r02 stamps (gpurun_out/r2b/stamps.json): 1180 / 2080 / 2590 / 1530 cycles per tile for layer_0 / 256x256 / layer_5 / head;
     // head swept 100..200 (1.40 / 1.20 / 1.13 / 1.12 ms per fine launch at 100 / 130 / 160 / 200)
     // layer_1 recomputes h0 (wgrad_l1_recompute, 20 KiB tiles but 22 MFMAs and an LDS exchange per tile): swept 160 / 204 / 240 /
@@ -34,19 +35,18 @@ std::vector<int32_t> build_wgrad_plan(int n_wg) {
     // layer_7 recomputes dz7 (wgrad_l7_recompute, 18 KiB tiles): 204 -> 240; with the copies issued behind the first half's MFMAs
     // the plain jobs gained most, tools/tune_costs.py (coordinate search on the box) moved the others up: coarse + fine launch
     // 1.439 -> 1.382 ms
-    int cost[kWgradJobs] = {128, 264, 204, 204, 204, 267, 204, 240, 193};
-    if (const char* e = std::getenv("KNERF_WGRAD_COSTS")) {
-        int j = 0;
-        for (const char* p = e; *p && j < kWgradJobs; ++j) { cost[j] = std::atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
-    }
+    // (the defaults live in knerf_ctx::wgrad_cost: 128, 264, 204, 204, 204, 267, 204, 240, 193)
     int total = 0;
-    for (int j = 0; j < kWgradJobs; ++j) total += cost[j];
+    for (int j = 0; j < kWgradJobs; ++j) total += cost[j] > 0 ? cost[j] : 0;
     std::vector<int32_t> plan;
+    job_wg0.assign(kWgradJobs + 1, 0);
     for (int j = 0; j < kWgradJobs; ++j) {
-        if (cost[j] <= 0) continue;
+        job_wg0[j] = (int32_t)plan.size() / 4;
+        if (cost[j] <= 0) continue;          // a sweep may switch a job off (its gradient is then missing: timing experiments only)
         int ns = (cost[j] * (n_wg - 4) + total / 2) / total; if (ns < 1) ns = 1;
         for (int s = 0; s < ns; ++s) { plan.push_back(j); plan.push_back(s); plan.push_back(ns); plan.push_back(0); }
     }
+    job_wg0[kWgradJobs] = (int32_t)plan.size() / 4;
     return plan;
 }
 
@@ -84,32 +84,48 @@ int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
 
 size_t tiles_for(long long n_samples) {
     size_t t = (size_t)((n_samples + kTile - 1) / kTile);
-    return (t + kWaves - 1) / kWaves * kWaves;   // whole workgroups
+    constexpr size_t q = kWaves > kSavedGroup ? kWaves : kSavedGroup;
+    return (t + q - 1) / q * q;                  // whole workgroups (and whole layout groups, layout.h)
+}
+
+// (re)build the wgrad plan from ctx->wgrad_cost and upload it with the jobs' workgroup offsets
+int upload_plan(knerf_ctx* ctx) {
+    std::vector<int32_t> job_wg0;
+    std::vector<int32_t> plan = build_wgrad_plan(ctx->n_cu, ctx->wgrad_cost, job_wg0);
+    if (ctx->tab.d_plan) { (void)hipFree(ctx->tab.d_plan); ctx->tab.d_plan = nullptr; }
+    if (ctx->d_job_wg0) { (void)hipFree(ctx->d_job_wg0); ctx->d_job_wg0 = nullptr; }
+    HIPCHK(hipMalloc(&ctx->tab.d_plan, plan.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(ctx->tab.d_plan, plan.data(), plan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&ctx->d_job_wg0, job_wg0.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(ctx->d_job_wg0, job_wg0.data(), job_wg0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->tab.n_plan = (int)plan.size() / 4;
+    ctx->plan_dirty = false;
+    return KNERF_OK;
 }
 
 template <class T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 // grow-only workspaces; the zero-fills are enqueued on the caller's stream `s`, the one the consuming kernels run on
-// (hipMalloc / hipFree themselves synchronise the device)
-// Training workspaces of the fused path (act / mask / dz): `group` coarse-pass regions followed by one fine-pass region, so that
-// one weight-gradient launch covers the coarse passes of a group of chunks (launch_wgrad_tiles below).
+// (hipMalloc / hipFree themselves synchronise the device).
+// Inference buffers (raw, w_c, t_f, img_tmp) follow the largest chunk of ANY call; the training workspaces of the fused path
+// (draw, act / mask / dz, tile flags and lists) follow the largest TRAINING chunk and group: `group` coarse-pass regions followed
+// by one fine-pass region, so that one weight-gradient launch covers the coarse passes of a group of chunks
+// (launch_wgrad_tiles below).  A render with a larger ray_chunks therefore never re-sizes the training regions.
 int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group = 1) {
-    if (n_rays <= ctx->ws_rays && (!train || ctx->ws_train) && (!train || group <= ctx->ws_group)) return KNERF_OK;
-    const int R = n_rays > ctx->ws_rays ? n_rays : ctx->ws_rays;
     const int Na = ctx->cfg.n_coarse + ctx->cfg.n_fine;
-    train = train || ctx->ws_train;
-    if (group < ctx->ws_group && n_rays <= ctx->ws_rays) group = ctx->ws_group;      // a larger chunk size starts from the group asked for: group x size is what costs memory
-    HIPCHK(hipStreamSynchronize(s));           // nothing enqueued earlier may still use the buffers that are freed below
-    free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
-    free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
-    ctx->ws_rays = 0;
-    const size_t ns = (size_t)R * Na;
-    ctx->raw_bytes = ns * 4 * sizeof(float);
-    HIPCHK(hipMalloc(&ctx->raw, ctx->raw_bytes));
-    HIPCHK(hipMalloc(&ctx->w_c, (size_t)R * ctx->cfg.n_coarse * sizeof(float)));
-    HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
-    HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
-    if (ctx->generic) {
+    if (ctx->generic) {          // general-shape path: one size for everything (its activations are forward buffers too)
+        if (n_rays <= ctx->ws_rays && (!train || ctx->ws_train)) return KNERF_OK;
+        const int R = n_rays > ctx->ws_rays ? n_rays : ctx->ws_rays;
+        train = train || ctx->ws_train;
+        HIPCHK(hipStreamSynchronize(s));           // nothing enqueued earlier may still use the buffers that are freed below
+        free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
+        ctx->ws_rays = 0;
+        const size_t ns = (size_t)R * Na;
+        ctx->raw_bytes = ns * 4 * sizeof(float);
+        HIPCHK(hipMalloc(&ctx->raw, ctx->raw_bytes));
+        HIPCHK(hipMalloc(&ctx->w_c, (size_t)R * ctx->cfg.n_coarse * sizeof(float)));
+        HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
+        HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
         gen::Workspace& g = ctx->gws;
         free_dev(g.act); free_dev(g.dz); free_dev(g.zs); free_dev(g.zc);
         g.mp = gen::padded_rows((long long)ns);
@@ -122,19 +138,51 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
             HIPCHK(hipMalloc(&g.dz, zb));
             HIPCHK(hipMemsetAsync(g.dz, 0, zb, s));
             HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
+            free_dev(ctx->loss_partial);
+            HIPCHK(hipMalloc(&ctx->loss_partial, ((size_t)R + 3) / 4 * sizeof(float)));
         }
-    } else if (train) {
+        ctx->ws_rays = R; ctx->ws_train = train; ctx->ws_train_rays = train ? R : 0; ctx->ws_group = 1;
+        return KNERF_OK;
+    }
+    const bool grow_base = n_rays > ctx->ws_rays;
+    const bool grow_train = train && (!ctx->ws_train || n_rays > ctx->ws_train_rays || group > ctx->ws_group);
+    if (!grow_base && !grow_train) return KNERF_OK;
+    HIPCHK(hipStreamSynchronize(s));               // nothing enqueued earlier may still use the buffers that are freed below
+    if (grow_base) {
+        free_dev(ctx->raw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
+        ctx->ws_rays = 0;
+        const size_t ns = (size_t)n_rays * Na;
+        ctx->raw_bytes = ns * 4 * sizeof(float);
+        HIPCHK(hipMalloc(&ctx->raw, ctx->raw_bytes));
+        HIPCHK(hipMalloc(&ctx->w_c, (size_t)n_rays * ctx->cfg.n_coarse * sizeof(float)));
+        HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
+        HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)n_rays * 8 * sizeof(float)));
+        ctx->ws_rays = n_rays;
+    }
+    if (grow_train) {
+        const int R = n_rays > ctx->ws_train_rays ? n_rays : ctx->ws_train_rays;
+        if (group < ctx->ws_group && n_rays <= ctx->ws_train_rays) group = ctx->ws_group;   // a larger chunk size starts from the group asked for: group x size is what costs memory
+        free_dev(ctx->draw); free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
+        free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->loss_partial);
+        ctx->ws_train = false; ctx->ws_train_rays = 0; ctx->ws_group = 1; ctx->group_cache = 0;
+        const size_t ns = (size_t)R * Na;
         // group 1: the coarse and the fine pass of a chunk share one region (each pass's weight gradients follow it at once)
         const size_t tiles = group == 1 ? tiles_for((long long)ns) : (size_t)group * tiles_for((long long)R * ctx->cfg.n_coarse) + tiles_for((long long)ns);
-        ctx->act_bytes = tiles * kActTileBytes; ctx->mask_bytes = tiles * kMaskTileBytes; ctx->dz_bytes = tiles * kDzTileBytes;
-        HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
+        ctx->act_bytes = saved_region_bytes(tiles, kActBlocks); ctx->mask_bytes = saved_region_bytes(tiles, kMaskBlocks);
+        ctx->dz_bytes = saved_region_bytes(tiles, kDzBlocks);
+        HIPCHK(hipMalloc(&ctx->draw, ns * 4 * sizeof(float)));
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
         HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
         HIPCHK(hipMemsetAsync(ctx->dz, 0, ctx->dz_bytes, s));     // block kDzHead+1 is never written and must read 0
         HIPCHK(hipMemsetAsync(ctx->act, 0, ctx->act_bytes, s));
+        HIPCHK(hipMalloc(&ctx->tile_flags, tiles * sizeof(int)));
+        HIPCHK(hipMemsetAsync(ctx->tile_flags, 0, tiles * sizeof(int), s));
+        HIPCHK(hipMalloc(&ctx->tile_list, tiles * sizeof(int)));
+        HIPCHK(hipMalloc(&ctx->loss_partial, ((size_t)R + 3) / 4 * sizeof(float)));
+        ctx->ws_tiles = tiles;
+        ctx->ws_train = true; ctx->ws_train_rays = R; ctx->ws_group = group;
     }
-    ctx->ws_rays = R; ctx->ws_train = train; ctx->ws_group = train ? group : ctx->ws_group;
     return KNERF_OK;
 }
 
@@ -159,18 +207,36 @@ int check_net(knerf_ctx* ctx, int net) {
     return KNERF_OK;
 }
 
-// forward (+ optional training half) of one net on given t-values; leaves raw/draw/act/dz in the workspace
-// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces
-int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles) {
+// dead-tile skipping applies to the fused path when 32-sample tiles do not straddle rays in either pass
+bool skipping(const knerf_ctx* ctx) {
+    return ctx->skip_dead && !ctx->generic && ctx->cfg.n_coarse % kTile == 0 && (ctx->cfg.n_coarse + ctx->cfg.n_fine) % kTile == 0;
+}
+
+// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces.  use_list: the
+// tiles are the ctx->tile_count[0] entries of ctx->tile_list (indices relative to tile0; the caller has just compacted them).
+int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, bool use_list) {
     WgradArgs wa{};
-    wa.act = ctx->act + tile0 * kActTileBytes; wa.dz = ctx->dz + tile0 * kDzTileBytes; wa.mask = ctx->mask + tile0 * kMaskTileBytes;
+    wa.act = ctx->act + act_tile_off(tile0); wa.dz = ctx->dz + dz_tile_off(tile0); wa.mask = ctx->mask + mask_tile_off(tile0);
     wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
     wa.fwd_stream = ctx->net[net].fwd_stream; wa.bias = ctx->net[net].bias; wa.bwd_stream = ctx->net[net].bwd_stream;
     wa.n_tiles = (long long)n_tiles;
     wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
     for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
+    if (use_list) { wa.live = ctx->tile_list; wa.n_live = ctx->tile_count; wa.by_range = ctx->deterministic ? 1 : 0; }
+    if (ctx->deterministic) {
+        // per-workgroup slabs (zeroed: a workgroup without tiles writes nothing) + the ordered second pass
+        if (!ctx->partial || ctx->partial_plan != ctx->tab.n_plan) {
+            HIPCHK(hipStreamSynchronize(s));
+            free_dev(ctx->partial);
+            HIPCHK(hipMalloc(&ctx->partial, wgrad_partial_floats(ctx->tab.n_plan) * sizeof(float)));
+            ctx->partial_plan = ctx->tab.n_plan;
+        }
+        HIPCHK(hipMemsetAsync(ctx->partial, 0, wgrad_partial_floats(ctx->tab.n_plan) * sizeof(float), s));
+        wa.partial = ctx->partial;
+    }
     ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F);
     HIPCHK(launch_wgrad(wa, s));
+    if (ctx->deterministic) HIPCHK(launch_wgrad_reduce(wa, ctx->d_job_wg0, s));
     return KNERF_OK;
 }
 
@@ -183,7 +249,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     FwdArgs fa{};
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
     fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw;
-    fa.act = ctx->act ? ctx->act + tile0 * kActTileBytes : nullptr; fa.mask = ctx->mask ? ctx->mask + tile0 * kMaskTileBytes : nullptr;
+    fa.act = ctx->act ? ctx->act + act_tile_off(tile0) : nullptr; fa.mask = ctx->mask ? ctx->mask + mask_tile_off(tile0) : nullptr;
     fa.n_samples = (long long)R * S; fa.S = S; fa.net = net == KNERF_COARSE ? 0 : 1;
     if (ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F);
@@ -197,16 +263,27 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     ca.draw = train ? ctx->draw : nullptr; ca.loss = loss; ca.R = R; ca.S = S; ca.white = ctx->cfg.white_background;
     ca.grad_scale = 2.0f / (3.0f * (float)R) * inv_chunks;
     ca.loss_scale = inv_chunks / (3.0f * (float)R);
-    { ProfScope ps(ctx, s, P_COMPOSITE); HIPCHK(launch_composite(ca, s)); }
+    const bool skip = train && skipping(ctx);
+    const size_t n_tiles = tiles_for(fa.n_samples);
+    if (skip) ca.tile_flags = ctx->tile_flags + tile0;
+    if (train && ctx->deterministic) ca.loss_partial = ctx->loss_partial;
+    {
+        ProfScope ps(ctx, s, P_COMPOSITE);
+        HIPCHK(launch_composite(ca, s));
+        if (ca.loss_partial) HIPCHK(launch_loss_reduce(ca.loss_partial, (R + 3) / 4, loss, s));
+        // the pass's live tiles (indices relative to tile0); the padding tiles behind the last real one count as dead
+        if (skip) HIPCHK(launch_compact_tiles(ca.tile_flags, (int)n_tiles, (int)n_tiles, (int)(fa.n_samples / kTile), ctx->tile_list, ctx->tile_count, ctx->tile_stats, s));
+    }
     if (train && ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
         HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s));
     } else if (train) {
         BwdArgs ba{};
-        ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + tile0 * kDzTileBytes;
+        ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + dz_tile_off(tile0);
         ba.n_samples = fa.n_samples; ba.net = fa.net;
+        if (skip) { ba.live = ctx->tile_list; ba.n_live = ctx->tile_count; }
         { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
-        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, tiles_for(fa.n_samples))) return r; }
+        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, skip)) return r; }
     }
     return KNERF_OK;
 }
@@ -246,11 +323,13 @@ int train_chunk_impl(knerf_ctx* ctx, hipStream_t s, const float* o, const float*
 // (KNERF_WGRAD_GROUP_GB, default 40; 0 = one launch per chunk) and a quarter of the free device memory
 int wgrad_group_for(knerf_ctx* ctx, int n_rays, int n_chunks) {
     if (ctx->generic || n_chunks <= 1) return 1;
-    double budget = 40.0;
-    if (const char* e = std::getenv("KNERF_WGRAD_GROUP_GB")) budget = std::atof(e);
-    if (budget <= 0) return 1;
+    if (ctx->group_cache > 0 && ctx->group_cache_rays == n_rays && ctx->group_cache_chunks == n_chunks) return ctx->group_cache;
+    auto memo = [&](int g) { ctx->group_cache_rays = n_rays; ctx->group_cache_chunks = n_chunks; ctx->group_cache = g; return g; };
+    const double budget = ctx->wgrad_group_gb;
+    if (budget <= 0 || ctx->wgrad_group_max <= 1) return memo(1);
     const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
-    const double per_chunk = (double)tiles_for((long long)n_rays * Nc) * (kActTileBytes + kMaskTileBytes + kDzTileBytes);   // one coarse region
+    const double per_chunk = (double)(saved_region_bytes(tiles_for((long long)n_rays * Nc), kActBlocks) + saved_region_bytes(tiles_for((long long)n_rays * Nc), kMaskBlocks) +
+                                      saved_region_bytes(tiles_for((long long)n_rays * Nc), kDzBlocks));   // one coarse region
     (void)Na;
     size_t free_b = 0, total_b = 0;
     double avail = budget * 1e9;
@@ -260,13 +339,12 @@ int wgrad_group_for(knerf_ctx* ctx, int n_rays, int n_chunks) {
         if (cap < avail) avail = cap;
     }
     int g = (int)(avail / per_chunk);
-    int g_max = 4;                                  // coarse launches of more than ~4 x 8192 tiles gain nothing more
-    if (const char* e = std::getenv("KNERF_WGRAD_GROUP_MAX")) { const int v = std::atoi(e); if (v > 0) g_max = v; }
+    const int g_max = ctx->wgrad_group_max;         // default 4: coarse launches of more than ~4 x 8192 tiles gain nothing more
     if (g > g_max) g = g_max;
     if (g > n_chunks) g = n_chunks;
-    if (g <= 1) return 1;
+    if (g <= 1) return memo(1);
     const int n_groups = (n_chunks + g - 1) / g;
-    return (n_chunks + n_groups - 1) / n_groups;      // the smallest group that needs no more launches
+    return memo((n_chunks + n_groups - 1) / n_groups);      // the smallest group that needs no more launches
 }
 
 }  // namespace
@@ -301,7 +379,7 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     ctx = new knerf_ctx();
     ctx->cfg = *cfg;
     ctx->generic = !gen::is_default_shape(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir) ||
-                   std::getenv("KNERF_FORCE_GENERIC") != nullptr;      // the override lets tests run the default shape through both paths
+                   (cfg->flags & KNERF_FLAG_FORCE_GENERIC) != 0;       // the flag lets tests run the default shape through both paths
     if (ctx->generic) {
         ctx->gplan = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
         ctx->n_params = ctx->gplan.n_params;
@@ -327,11 +405,12 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(up(ctx->tab.d_bias, ctx->tab.host.fwd_bias));
     CREATECHK(up(ctx->tab.d_bwd, ctx->tab.host.bwd));
     CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
-    {
-        std::vector<int32_t> plan = build_wgrad_plan(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-        ctx->tab.n_plan = (int)plan.size() / 4;
-        CREATECHK(up(ctx->tab.d_plan, plan));
-    }
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (int r = upload_plan(ctx)) { std::string m_ = ctx->err; knerf_destroy(ctx); return fail(nullptr, r, m_); }
+    CREATECHK(hipMalloc(&ctx->tile_count, 2 * sizeof(int)));
+    CREATECHK(hipMemset(ctx->tile_count, 0, 2 * sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->tile_stats, 2 * sizeof(long long)));
+    CREATECHK(hipMemset(ctx->tile_stats, 0, 2 * sizeof(long long)));
     CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * NP * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->aux, 2 * (size_t)kAuxCount * sizeof(float)));
@@ -340,7 +419,6 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(hipMemset(ctx->d_flag, 0, sizeof(int)));
     CREATECHK(hipHostMalloc(&ctx->h_status, 2 * sizeof(int), hipHostMallocDefault));   // written by the device (optim.hip step_status)
     ctx->h_status[0] = ctx->h_status[1] = 0;
-    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
     for (int n = 0; n < 2; ++n) {
         Net& N = ctx->net[n];
@@ -384,6 +462,8 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
+    free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->tile_count); free_dev(ctx->tile_stats);
+    free_dev(ctx->partial); free_dev(ctx->loss_partial); free_dev(ctx->d_job_wg0);
     free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
     for (int n = 0; n < 2; ++n) { free_dev(ctx->gnet[n].packed); free_dev(ctx->gnet[n].head); free_dev(ctx->gnet[n].gaux); }
     free_dev(ctx->call_net.head);
@@ -520,6 +600,7 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
     if (!ctx) return KNERF_ERR_INVALID;
     if (!o || !d || !t || !target || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "train_chunk: null/empty argument");
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
     if (int r = ensure_ws(ctx, n_rays, true, s)) return r;
     if (int r = train_chunk_impl(ctx, s, o, d, t, target, u, seed, ray_offset, n_rays, inv_chunks, loss, c_image, f_image)) return r;
     return expand_head_grads(ctx, s);
@@ -533,10 +614,12 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
         return fail(ctx, KNERF_ERR_INVALID, "train_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
     hipStream_t s = (hipStream_t)stream;
     const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
-    int G = ctx->ws_train && ctx->ws_rays >= ray_chunks && ctx->ws_group > 1 ? (ctx->ws_group < C ? ctx->ws_group : C) : wgrad_group_for(ctx, ray_chunks, C);
+    if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
+    int G = wgrad_group_for(ctx, ray_chunks, C);
     if (int r = ensure_ws(ctx, ray_chunks, true, s, G)) {
         if (G == 1) return r;
         G = 1;                                                      // the group did not fit: one chunk per wgrad launch
+        ctx->group_cache_rays = ray_chunks; ctx->group_cache_chunks = C; ctx->group_cache = 1;
         if (int r1 = ensure_ws(ctx, ray_chunks, true, s, 1)) return r1;
     }
     const size_t tc = tiles_for((long long)ray_chunks * Nc);
@@ -549,7 +632,9 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
                                      f_image ? f_image + r0 * 3 : nullptr, slot, G))
             return r;
         if (G > 1 && last) {                                        // the group's coarse weight gradients in one launch
-            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc)) return r;
+            const bool skip = skipping(ctx);
+            if (skip) HIPCHK(launch_compact_tiles(ctx->tile_flags, (int)((slot + 1) * tc), (int)tc, ray_chunks * Nc / kTile, ctx->tile_list, ctx->tile_count, nullptr, s));
+            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, skip)) return r;
         }
     }
     return expand_head_grads(ctx, s);
@@ -598,6 +683,54 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream) {
     HIPCHK(hipMemsetAsync(ctx->aux, 0, 2 * (size_t)kAuxCount * sizeof(float), (hipStream_t)stream));
     if (ctx->generic)
         for (int n = 0; n < 2; ++n) HIPCHK(hipMemsetAsync(ctx->gnet[n].gaux, 0, gen::aux_floats(ctx->gplan) * sizeof(float), (hipStream_t)stream));
+    return KNERF_OK;
+}
+
+int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
+    if (!ctx || !name) return KNERF_ERR_INVALID;
+    const std::string n(name);
+    if (n == "deterministic") {
+        if (ctx->generic && value != 0) return fail(ctx, KNERF_ERR_INVALID, "deterministic: implemented for the fused (default-shape) kernels only");
+        ctx->deterministic = value != 0;
+    } else if (n == "skip_dead_tiles") {
+        ctx->skip_dead = value != 0;               // ignored where it does not apply (general-shape path, sample counts not multiples of 32)
+    } else if (n == "wgrad_group_max") {
+        if (value < 1 || value > 64) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_max: 1..64");
+        ctx->wgrad_group_max = (int)value; ctx->group_cache = 0;
+    } else if (n == "wgrad_group_gb") {
+        if (value < 0) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_gb: >= 0");
+        ctx->wgrad_group_gb = value; ctx->group_cache = 0;
+    } else if (n.rfind("wgrad_cost", 0) == 0 && n.size() == 11 && n[10] >= '0' && n[10] < '0' + kWgradJobs) {
+        if (value < 0 || value > 1e6) return fail(ctx, KNERF_ERR_INVALID, "wgrad_cost: 0..1e6");
+        ctx->wgrad_cost[n[10] - '0'] = (int)value; ctx->plan_dirty = true;
+    } else {
+        return fail(ctx, KNERF_ERR_INVALID, "unknown option '" + n + "'");
+    }
+    return KNERF_OK;
+}
+
+int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
+    if (!ctx || !name || !value) return KNERF_ERR_INVALID;
+    const std::string n(name);
+    if (n == "deterministic") *value = ctx->deterministic;
+    else if (n == "skip_dead_tiles") *value = ctx->skip_dead;
+    else if (n == "skip_dead_tiles_active") *value = skipping(ctx);
+    else if (n == "wgrad_group_max") *value = ctx->wgrad_group_max;
+    else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
+    else if (n == "wgrad_group") *value = ctx->ws_train ? ctx->ws_group : 0;            // chunks per coarse wgrad launch of the current workspaces
+    else if (n == "general_shape_path") *value = ctx->generic;
+    else if (n.rfind("wgrad_cost", 0) == 0 && n.size() == 11 && n[10] >= '0' && n[10] < '0' + kWgradJobs) *value = ctx->wgrad_cost[n[10] - '0'];
+    else return fail(ctx, KNERF_ERR_INVALID, "unknown option '" + n + "'");
+    return KNERF_OK;
+}
+
+int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset) {
+    if (!ctx || !live || !total) return KNERF_ERR_INVALID;
+    long long h[2] = {0, 0};
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(h, ctx->tile_stats, sizeof(h), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(ctx->tile_stats, 0, sizeof(h)));
+    *live = h[0]; *total = h[1];
     return KNERF_OK;
 }
 

@@ -215,9 +215,29 @@ constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer 
 #ifndef KNERF_TILE_SKEW
 #define KNERF_TILE_SKEW 256
 #endif
-constexpr size_t kActTileBytes = (size_t)kActBlocks * 1024 + KNERF_TILE_SKEW;
+// KNERF_SAVED_GROUP = G (a power of two, default 1): G consecutive tiles form a group that is stored BLOCK-major -- block b of the
+// group's G tiles is one contiguous G KiB piece, so the 8 waves of a chain workgroup (G = 8) write 8 KiB per block instead of
+// eight 1 KiB pieces 118 KiB apart.  G = 1 is the tile-major layout described above.  (r03 A/B experiment)
+#ifndef KNERF_SAVED_GROUP
+#define KNERF_SAVED_GROUP 1
+#endif
+constexpr int kSavedGroup = KNERF_SAVED_GROUP;
+static_assert(kSavedGroup >= 1 && (kSavedGroup & (kSavedGroup - 1)) == 0, "KNERF_SAVED_GROUP must be a power of two");
+constexpr int kSavedBlockStride = kSavedGroup * 1024;        // bytes between consecutive blocks of one tile
+constexpr size_t kActTileBytes = (size_t)kActBlocks * 1024 + KNERF_TILE_SKEW;      // per-tile footprint at G = 1; G x blocks + skew per group
 constexpr size_t kDzTileBytes = (size_t)kDzBlocks * 1024 + KNERF_TILE_SKEW;
 constexpr size_t kMaskTileBytes = (size_t)kMaskBlocks * 1024 + KNERF_TILE_SKEW;
+constexpr size_t saved_group_bytes(int blocks) { return (size_t)kSavedGroup * blocks * 1024 + KNERF_TILE_SKEW; }
+// byte offset of block 0 of tile `tile` in a saved run of `blocks` blocks per tile
+constexpr size_t saved_tile_off(size_t tile, int blocks) {
+    return kSavedGroup == 1 ? tile * ((size_t)blocks * 1024 + KNERF_TILE_SKEW)
+                            : (tile / kSavedGroup) * saved_group_bytes(blocks) + (tile % kSavedGroup) * 1024;
+}
+constexpr size_t act_tile_off(size_t tile) { return saved_tile_off(tile, kActBlocks); }
+constexpr size_t dz_tile_off(size_t tile) { return saved_tile_off(tile, kDzBlocks); }
+constexpr size_t mask_tile_off(size_t tile) { return saved_tile_off(tile, kMaskBlocks); }
+// bytes of a region of `tiles` tiles (whole groups)
+constexpr size_t saved_region_bytes(size_t tiles, int blocks) { return (tiles + kSavedGroup - 1) / kSavedGroup * saved_group_bytes(blocks); }
 
 // wgrad jobs: dW[in_row][out_col] += sum_s act[s][in] * dz[s][out], db[out_col] += sum_s dz[s][out]
 struct WgradJob {

@@ -70,7 +70,17 @@ struct WgradPlan {          // one entry per workgroup, built on the host (knerf
 // Flush of one 32x32 accumulator tile: element i of lane (c, hh) goes to dst[(row0 + (i&3) + 8(i>>2)) * ncols + col] (an index into
 // the gradient buffer, >= kAuxBase: into the head sums, < 0: dropped).  The 16 table look-ups are requested together and the
 // atomics follow (element by element the look-up's latency was exposed 16 times per tile: 29 us per launch, 1030 atomics per wave).
+// Deterministic mode (a.partial != null, knerf_set_option "deterministic"): no atomics -- the workgroup's sums go to its own slab of
+// `partial` with plain stores (element index = the one the destination table is read at) and wgrad_reduce_kernel (wgrad.hip) adds
+// the slabs of a job in split order, so the gradient is bit-reproducible from run to run.
+constexpr int kWgradPartialStride = (10 * 32 + 1) * 256;     // floats per workgroup: the largest job table (layer_5)
 __device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, int row0, int ncols, int col, const f32x16& acc) {
+    if (a.partial) {
+        float* p = a.partial + (size_t)blockIdx.x * kWgradPartialStride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[(row0 + (i & 3) + 8 * (i >> 2)) * ncols + col] = acc[i];
+        return;
+    }
     int d[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = __builtin_nontemporal_load(dst + (row0 + (i & 3) + 8 * (i >> 2)) * ncols + col);
@@ -84,6 +94,16 @@ __device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, in
     }
 }
 
+// bias row (column sums of dz): element `idx` of the job's table, held by the half-0 lanes
+__device__ __forceinline__ void flush_bias(const WgradArgs& a, const int* dst, int idx, int hh, float v) {
+    if (a.partial) {
+        if (hh == 0) a.partial[(size_t)blockIdx.x * kWgradPartialStride + idx] = v;
+        return;
+    }
+    const int d = dst[idx];
+    if (d >= 0 && hh == 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), v);
+}
+
 // 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
 // region: two transposed reads.  lane_off[r] = per-lane byte offset of read r inside the pair's two blocks.
 __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, const int (&lane_off)[2]) {
@@ -95,16 +115,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// The job body walks a contiguous range [t0, t1) of sample tiles.
+// The job body walks a contiguous range [t0, t1) of sample tiles ...
 struct ContigSeq {
-    long long t0, t1;
-    __device__ __forceinline__ long long count() const { return t1 - t0; }
-    __device__ __forceinline__ long long tile(long long i) const { return t0 + i; }
+    int t0, t1;
+    __device__ __forceinline__ int count() const { return t1 - t0; }
+    __device__ __forceinline__ int tile(int i) const { return t0 + i; }
+};
+// ... or entries [i0, i1) of the ascending list of LIVE tiles (dead-tile skipping: composite.hip flags -> compact_tiles); the index
+// is wave-uniform, so the look-up is a scalar load, requested at the top of an iteration and used by the copies in its middle
+struct ListSeq {
+    const int* list;
+    int i0, i1;
+    __device__ __forceinline__ int count() const { return i1 - i0; }
+    __device__ __forceinline__ int tile(int i) const { return list[i0 + i]; }
 };
 
-template <int NI, int NO>
+template <int NI, int NO, class Seq>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
-                                               const ContigSeq seq, char* smem) {
+                                               const Seq seq, char* smem) {
     constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
     constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
     constexpr int ROWS = NI + 1;
@@ -124,7 +152,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
     static_assert(NO == WO, "one output tile per wave column");
 
-    const long long cnt = seq.count();
+    const int cnt = seq.count();
     if (cnt <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the per-wave tile branches uniform
@@ -141,23 +169,24 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             lane_off[r] = par * 1024 + (2 * (8 * h + 4 * (r ^ par) + q) + (p & 1)) * 16 + (p >> 1) * 8;
     }
 
-    // stage sample tile number i (clamped at the end: a harmless re-read keeps the vmcnt arithmetic uniform) into `slot`
-    auto issue = [&](long long i, int slot, bool late = false) {
-        const long long t = seq.tile(i < cnt ? i : cnt - 1);
-        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)act_blk * 1024 + lane * 16;
-        const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)dz_blk * 1024 + lane * 16;
+    // sample tile number i of the sequence, clamped at the end (a harmless re-read keeps the vmcnt arithmetic uniform)
+    auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
+    // stage sample tile t into `slot`
+    auto issue = [&](int t, int slot, bool late = false) {
+        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_blk * kSavedBlockStride + lane * 16;
+        const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)dz_blk * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
-            glds16(src_in + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
+            glds16(src_in + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
         }
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_DZ;
-            glds16(src_dz + (ok ? b : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch), late);
+            glds16(src_dz + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch), late);
         }
     };
     f32x16 acc[NACC];
@@ -169,12 +198,13 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 
     // prologue: tiles 0..NS-2
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    for (int s = 0; s < NS - 1; ++s) issue(tile_at(s), s);
     int slot = 0;
 #ifdef KNERF_WGRAD_STAMPS
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
 #endif
-    for (long long i = 0; i < cnt; ++i) {
+    for (int i = 0; i < cnt; ++i) {
+        const int t_next = tile_at(i + NS - 1);        // the tile this iteration stages (list mode: a scalar load, used mid-iteration)
         STAMP(s0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile i landed (mine) ...
         STAMP(s1);
@@ -182,7 +212,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         STAMP(s2);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
 #ifdef KNERF_WGRAD_EARLY_ISSUE     // A/B knob: the older order (copies issued right behind the barrier)
-        issue(i + NS - 1, nslot);
+        issue(t_next, nslot);
 #endif
         STAMP(s3);
         const char* in_reg = smem + slot * TILE_BYTES;
@@ -213,7 +243,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         if (kBoth) read_k(1, b1, afr1);
 #pragma unroll
         for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr0[n], b0, acc[n], 0, 0, 0);
-        issue(i + NS - 1, nslot, true);
+        issue(t_next, nslot, true);
         if (!kBoth) read_k(1, b1, afr1);
 #pragma unroll
         for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr1[n], b1, acc[n], 0, 0, 0);
@@ -255,8 +285,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         if (it < NI) {
             flush_acc(a, dst, 32 * it + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else if (it == NI) {
-            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];   // bias row: every row of the ones-tile holds the column sums
-            if (d >= 0 && hh == 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), acc[n][0]);
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);   // bias row: every row of the ones-tile holds the column sums
         }
     }
 }
@@ -270,7 +299,8 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 // permutation (only the per-lane offsets of the transposed reads change; the bank pattern stays conflict-free: 32 q + 128
 // (h ^ par) covers the 64 banks in two passes).  W_0's fragments are the forward stream's own layer_0 blocks: an A fragment of
 // W^T and a B fragment of W hold the same registers (layout.h: the 32x32x16 operand maps are symmetric).
-__device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const ContigSeq seq, char* smem) {
+template <class Seq>
+__device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq seq, char* smem) {
     constexpr int NI = 8, BLK_IN = 4, BLK_DZ = 16;
     constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
     constexpr int G_IN = 1, G_DZ = 2, G = G_IN + G_DZ;
@@ -279,7 +309,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
     static_assert(NS * TILE_BYTES + kXch + kWgScratch <= 160 * 1024, "LDS budget");
     constexpr int job = 1, NACC = NI + 1, NCOLS = 256;
 
-    const long long cnt = seq.count();
+    const int cnt = seq.count();
     if (cnt <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,17 +334,17 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
             lane_off[r] = par * 1024 + (2 * (4 * (h ^ par) + 8 * r + q) + (p & 1)) * 16 + (p >> 1) * 8;
         enc_off = (2 * (lane & 31) + (lane >> 5)) * 16;      // saved_off(b even, h, s); odd b: s ^ 4  <=>  byte offset ^ 128
     }
-    auto issue = [&](long long i, int slot, bool late = false) {
-        const long long t = seq.tile(i < cnt ? i : cnt - 1);
-        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)kActEnc * 1024 + lane * 16;
-        const char* src_dz = a.dz + (size_t)t * kDzTileBytes + (size_t)16 * 1024 + lane * 16;
+    auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
+    auto issue = [&](int t, int slot, bool late = false) {
+        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)kActEnc * kSavedBlockStride + lane * 16;
+        const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)16 * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
         const bool ok = wave < BLK_IN;
-        glds16(src_in + (ok ? wave : 0) * 1024, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
+        glds16(src_in + (ok ? wave : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
-            glds16(src_dz + b * 1024, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024), late);
+            glds16(src_dz + b * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024), late);
         }
     };
     f32x16 acc[NACC];
@@ -343,14 +373,15 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
         *reinterpret_cast<bf16x8*>(x + 1024) = relu_packed(hi);
     };
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    for (int s = 0; s < NS - 1; ++s) issue(tile_at(s), s);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");       // tile 0 landed
     __builtin_amdgcn_s_barrier();
     recompute(smem, 0);
     int slot = 0;
     // One barrier per tile: iteration i consumes tile i (its h0 fragments were written during iteration i-1) and recomputes
     // h0 of tile i+1 into the other half of the exchange buffer, so tile i+1 must have landed too (one tile less in flight).
-    for (long long i = 0; i < cnt; ++i) {
+    for (int i = 0; i < cnt; ++i) {
+        const int t_next = tile_at(i + NS - 1);
         // tiles <= i+1 landed (mine) and my h0 fragments of tile i are written (lgkmcnt: the ds_writes of the recompute) ...
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 3)) : "memory");
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 and h0(i-1) are free
@@ -366,7 +397,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
             afr[NI] = ones;
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], b, acc[n], 0, 0, 0);
-            if (kk == 0) issue(i + NS - 1, nslot, true);      // behind the first half's MFMAs (see wgrad_job_body)
+            if (kk == 0) issue(t_next, nslot, true);          // behind the first half's MFMAs (see wgrad_job_body)
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
         recompute(smem + slot * TILE_BYTES, (int)((i + 1) & 1));               // past the end: the clamped re-read of the last tile, unused
@@ -381,8 +412,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
         if (n < NI) {
             flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else {
-            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
-            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);
         }
     }
 }
@@ -396,7 +426,8 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Con
 // sample permutation as in wgrad_l1_recompute.  H's fragment is the dgrad stream's own block `wo` (stage B0).
 // The recompute of tile i+1 runs inside tile i's MFMA sequence (its VALU selects and conversions issue between MFMAs), so
 // the strip is a register operand by the time the tile's own products start.
-__device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const ContigSeq seq, char* smem) {
+template <class Seq>
+__device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq seq, char* smem) {
     constexpr int NI = 8, BLK_IN = 16, BLK_X = 2;           // x: [0] dz_head block, [1] mask7 block
     constexpr int TILE_BYTES = (BLK_IN + BLK_X) * 1024;
     constexpr int G = 3;                                     // 2 h6 copies + 1 (dz_head / mask / padding) per wave and tile
@@ -404,7 +435,7 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
     static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
     constexpr int job = 7, NACC = NI + 1, NCOLS = 256;
 
-    const long long cnt = seq.count();
+    const int cnt = seq.count();
     if (cnt <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,17 +460,17 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
         mbit = (wo & 1) * 8 + (i >> 1) + 16 * (i & 1);
     }
     static_assert((kDzHead & 1) == 0, "dz_head block parity");
-    auto issue = [&](long long i, int slot, bool late = false) {
-        const long long t = seq.tile(i < cnt ? i : cnt - 1);
-        const char* src_in = a.act + (size_t)t * kActTileBytes + (size_t)act_h(6) * 1024 + lane * 16;
+    auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
+    auto issue = [&](int t, int slot, bool late = false) {
+        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_h(6) * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int b = r * kWgWaves + wave;
-            glds16(src_in + b * 1024, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
+            glds16(src_in + b * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
         }
-        const char* src_x = wave == 1 ? a.mask + (size_t)t * kMaskTileBytes + 7 * 1024 + lane * 16
-                                      : a.dz + (size_t)t * kDzTileBytes + (size_t)kDzHead * 1024 + lane * 16;
+        const char* src_x = wave == 1 ? a.mask + mask_tile_off((size_t)t) + 7 * kSavedBlockStride + lane * 16
+                                      : a.dz + dz_tile_off((size_t)t) + (size_t)kDzHead * kSavedBlockStride + lane * 16;
         glds16(src_x, __builtin_amdgcn_readfirstlane(wave < 2 ? dst + (BLK_IN + wave) * 1024 : scratch), late);
     };
     const int hh = lane >> 5;
@@ -468,7 +499,7 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
     asm volatile("" ::"v"(hfrag));   // the wait for this global load is pinned here: inside the loop it would be a vmcnt(0) that drains the LDS-DMA pipeline every tile
 
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    for (int s = 0; s < NS - 1; ++s) issue(tile_at(s), s);
     bf16x8 bnext[2];
     {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile 0 landed
@@ -478,7 +509,8 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
         dz7_pack(dzf, mw, bnext);
     }
     int slot = 0;
-    for (long long i = 0; i < cnt; ++i) {
+    for (int i = 0; i < cnt; ++i) {
+        const int t_next = tile_at(i + NS - 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 3)) : "memory");   // tile i+1 landed (mine) ...
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
@@ -496,7 +528,7 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[n], bfr[kk], acc[n], 0, 0, 0);
             if (kk == 0) {
-                issue(i + NS - 1, nslot, true);                // behind the first half's MFMAs (see wgrad_job_body)
+                issue(t_next, nslot, true);                    // behind the first half's MFMAs (see wgrad_job_body)
                 dz7_pack(dzf, mw, bnext);
             }
         }
@@ -511,14 +543,14 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Con
         if (n < NI) {
             flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
         } else {
-            const int d = dst[NI * 32 * NCOLS + 32 * wo + c];
-            if (d >= 0 && hh == 0) atomicAdd(a.grad + d, acc[n][0]);
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);
         }
     }
 }
 
 // one job of the plan over the given tile range
-__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const ContigSeq& seq, char* smem) {
+template <class Seq>
+__device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const Seq& seq, char* smem) {
     switch (job) {
         case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, seq, smem); break;
         case 1: wgrad_l1_recompute(a, seq, smem); break;                                  // h0 recomputed from enc

@@ -34,7 +34,12 @@ class KnerfContext:
     """Owns one knerf_ctx on the current CUDA(HIP) device."""
 
     def __init__(self, n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4,
-                 white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None):
+                 white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None,
+                 force_generic=None, options=None):
+        """force_generic: run the default MLP shape through the general-shape kernels as well (tests).  options: {name: value}
+        for knerf_set_option.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
+        KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c8"), KNERF_DETERMINISTIC and
+        KNERF_SKIP_DEAD_TILES into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
         if not torch.cuda.is_available():
             raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
@@ -43,8 +48,12 @@ class KnerfContext:
         torch.cuda.set_device(self.device)
         if oob not in ("zero", "clamp"):
             raise ValueError("oob must be 'zero' or 'clamp'")
+        import os
+        if force_generic is None:
+            force_generic = bool(os.environ.get("KNERF_FORCE_GENERIC"))
         self.cfg = KnerfConfig(n_coarse, n_fine, pos_emb_xyz, pos_emb_dir, n_layers, dense_units, skip_layer,
-                               int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon)
+                               int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon,
+                               _lib.FLAG_FORCE_GENERIC if force_generic else 0)
         self.n_coarse, self.n_fine = n_coarse, n_fine
         rc = self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
         if rc != 0:
@@ -52,6 +61,18 @@ class KnerfContext:
             self._ctx = C.c_void_p()
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
         self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
+        opts = {}
+        env = os.environ
+        for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),
+                          ("KNERF_DETERMINISTIC", "deterministic"), ("KNERF_SKIP_DEAD_TILES", "skip_dead_tiles")):
+            if env.get(key):
+                opts[name] = float(env[key])
+        if env.get("KNERF_WGRAD_COSTS"):
+            for j, v in enumerate(env["KNERF_WGRAD_COSTS"].split(",")[:9]):
+                opts[f"wgrad_cost{j}"] = float(v)
+        opts.update(options or {})
+        for k, v in opts.items():
+            self.set_option(k, v)
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -63,6 +84,21 @@ class KnerfContext:
             self.close()
         except Exception:
             pass
+
+    # ---- run-time options (include/knerf.h knerf_set_option)
+    def set_option(self, name: str, value) -> None:
+        self._check(self.lib.knerf_set_option(self._ctx, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double()
+        self._check(self.lib.knerf_get_option(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def tile_stats(self, reset: bool = True):
+        """(live, total) 32-sample tiles seen by the dgrad launches since the last reset (skip_dead_tiles on)"""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.knerf_tile_stats(self._ctx, self._stream(), C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
 
     # ---- helpers
     def _check(self, rc: int):

@@ -110,8 +110,10 @@ class TorchKerasAdam:  # nerf.py:163-165, Keras form (eps outside the bias-corre
 
 
 def train_step(cp: List[torch.Tensor], fp: List[torch.Tensor], oc, of_, images, o, d, t, u, cfg: NerfConfig,
-               ray_chunks: int, white_background: bool, oob="zero", coarse_only=False):
-    """nerf.py:332-473 with autograd.  ``coarse_only`` is BASELINE config 1 (coarse net, no fine pass)."""
+               ray_chunks: int, white_background: bool, oob="zero", coarse_only=False, chunk_order=None):
+    """nerf.py:332-473 with autograd.  ``coarse_only`` is BASELINE config 1 (coarse net, no fine pass).
+    ``chunk_order`` (a permutation of range(C)) visits the chunks in another order: the same sums in a different
+    floating-point order, used to measure the fp32 arithmetic's own run-to-run spread (tools/convergence128.py)."""
     N = o.numel() // 3
     R = min(ray_chunks, N)
     assert N % R == 0
@@ -121,14 +123,14 @@ def train_step(cp: List[torch.Tensor], fp: List[torch.Tensor], oc, of_, images, 
     acc_c = [torch.zeros_like(p) for p in cp]
     acc_f = [torch.zeros_like(p) for p in fp]
     lc_tot = 0.0; lf_tot = 0.0
-    for i in range(C):
+    for i in (range(C) if chunk_order is None else chunk_order):
         sl = slice(i * R, (i + 1) * R)
         img, _, w = chunk_forward(cp, o_[sl], d_[sl], t_[sl], cfg, white_background)
         lc = torch.mean((im[sl] - img) ** 2)
         gc = torch.autograd.grad(lc, cp)
         for a, g in zip(acc_c, gc):
             a.add_(g / C)
-        lc_tot += float(lc) / C
+        lc_tot += float(lc.detach()) / C
         if coarse_only:
             continue
         with torch.no_grad():
@@ -140,7 +142,7 @@ def train_step(cp: List[torch.Tensor], fp: List[torch.Tensor], oc, of_, images, 
         gf = torch.autograd.grad(lf, fp)
         for a, g in zip(acc_f, gf):
             a.add_(g / C)
-        lf_tot += float(lf) / C
+        lf_tot += float(lf.detach()) / C
     if oc is not None:
         oc.apply(cp, acc_c)
         if not coarse_only:

@@ -1,0 +1,45 @@
+"""Procedural nerf_synthetic-SHAPED scene for the convergence experiments and the trained-scene tests (the datasets are absent:
+no network).  An analytic density / colour field inside the unit-ish sphere, cameras on the radius-4 sphere (`pose_spherical`,
+the synthetic datasets' convention), fov 0.6911112070083618, white background; views rendered at 512 samples per ray in fp64
+with torch on the GPU (test / experiment infrastructure only)."""
+import numpy as np
+import torch
+
+FOV = 0.6911112070083618
+
+
+def field(p, scale=1.0):
+    """analytic scene (torch, fp64): three soft blobs and a ring, position-dependent colour; p [...,3] -> sigma [...], rgb [...,3]"""
+    p = p / scale
+    c = torch.tensor([[0.45, 0.0, 0.15], [-0.55, 0.3, -0.25], [0.0, -0.5, 0.35]], dtype=p.dtype, device=p.device)
+    d = [((p - ci) ** 2).sum(-1) for ci in c]
+    ring = (torch.sqrt(p[..., 0] ** 2 + p[..., 1] ** 2) - 0.8) ** 2 + (p[..., 2] + 0.1) ** 2
+    sigma = 14.0 * torch.exp(-d[0] / 0.12) + 10.0 * torch.exp(-d[1] / 0.2) + 12.0 * torch.exp(-d[2] / 0.08) + 9.0 * torch.exp(-ring / 0.015)
+    rgb = torch.stack([0.5 + 0.5 * torch.sin(4 * p[..., 0] + 1.0), 0.5 + 0.5 * torch.cos(3 * p[..., 1] + 0.5),
+                       0.25 + 0.7 * (d[0] < d[1]).to(p.dtype) * (0.5 + 0.5 * torch.sin(6 * p[..., 2]))], -1)
+    return sigma, rgb.clamp(0, 1)
+
+
+def make_scene(ctx, wh=128, n_views=104, scale=1.0, ray_seed=2026):
+    """views: o, d [V,H,W,3], t [V,H,W,64] (fp32, on the GPU, jitter fixed per view), img [V,H,W,3]; ctx = a KnerfContext
+    (its on-device ray generator)"""
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    V = n_views
+    poses = np.stack([pose_spherical(360.0 * i / V * 7 % 360.0, -30.0 + 20.0 * np.sin(0.7 * i), 4.0) for i in range(V)])
+    o, d, t = ctx.generate_rays(poses, get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, 64, None, seed=ray_seed)
+    imgs = []
+    tt = torch.linspace(2.0, 6.0, 512, device="cuda", dtype=torch.float64)
+    for v in range(V):
+        p = o[v].double()[..., None, :] + d[v].double()[..., None, :] * tt[:, None]          # [H,W,512,3]
+        sg, col = field(p, scale)
+        delta = torch.cat([tt[1:] - tt[:-1], tt.new_full((1,), 1e-10)])
+        alpha = 1.0 - torch.exp(-sg * delta)
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha[..., :-1] + 1e-10], -1), -1)
+        w = alpha * T
+        img = (w[..., None] * col).sum(-2) + (1.0 - w.sum(-1))[..., None]                     # white background (utils.py:52-53)
+        imgs.append(img.clamp(0, 1).float())
+    return o, d, t, torch.stack(imgs)
+
+
+def psnr(a, b):
+    return float(-10.0 * torch.log10(((a - b) ** 2).mean()))

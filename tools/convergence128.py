@@ -32,46 +32,15 @@ sys.path.insert(0, ROOT)
 from oracle import nerf_oracle as O   # noqa: E402  (experiment script: the oracle supplies poses, initial weights and the fp32 leg)
 
 WH, NTRAIN, NVAL, BATCH, CHUNK = 128, 100, 4, 2, 4096
-FOV = 0.6911112070083618
 
+
+from tests.procedural_scene import make_scene as _make_scene, psnr   # noqa: E402  (the scene lives with the tests that share it)
 
 SCALE = 1.0        # --scale: object size (1.0: the blobs span about +-0.8 of the +-1.44 half-width the cameras see)
 
 
-def field(p):
-    """analytic scene (torch, fp64): three soft blobs and a ring, position-dependent colour; p [...,3] -> sigma [...], rgb [...,3]"""
-    p = p / SCALE
-    c = torch.tensor([[0.45, 0.0, 0.15], [-0.55, 0.3, -0.25], [0.0, -0.5, 0.35]], dtype=p.dtype, device=p.device)
-    d = [((p - ci) ** 2).sum(-1) for ci in c]
-    ring = (torch.sqrt(p[..., 0] ** 2 + p[..., 1] ** 2) - 0.8) ** 2 + (p[..., 2] + 0.1) ** 2
-    sigma = 14.0 * torch.exp(-d[0] / 0.12) + 10.0 * torch.exp(-d[1] / 0.2) + 12.0 * torch.exp(-d[2] / 0.08) + 9.0 * torch.exp(-ring / 0.015)
-    rgb = torch.stack([0.5 + 0.5 * torch.sin(4 * p[..., 0] + 1.0), 0.5 + 0.5 * torch.cos(3 * p[..., 1] + 0.5),
-                       0.25 + 0.7 * (d[0] < d[1]).to(p.dtype) * (0.5 + 0.5 * torch.sin(6 * p[..., 2]))], -1)
-    return sigma, rgb.clamp(0, 1)
-
-
 def make_scene(ctx):
-    """views: o, d [V,H,W,3], t [V,H,W,64] (fp32, on the GPU, jitter fixed per view), img [V,H,W,3]"""
-    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
-    V = NTRAIN + NVAL
-    poses = np.stack([pose_spherical(360.0 * i / V * 7 % 360.0, -30.0 + 20.0 * np.sin(0.7 * i), 4.0) for i in range(V)])
-    o, d, t = ctx.generate_rays(poses, get_focal_from_fov(FOV, WH), WH, WH, 2.0, 6.0, 64, None, seed=2026)
-    imgs = []
-    tt = torch.linspace(2.0, 6.0, 512, device="cuda", dtype=torch.float64)
-    for v in range(V):
-        p = o[v].double()[..., None, :] + d[v].double()[..., None, :] * tt[:, None]          # [H,W,512,3]
-        sg, col = field(p)
-        delta = torch.cat([tt[1:] - tt[:-1], tt.new_full((1,), 1e-10)])
-        alpha = 1.0 - torch.exp(-sg * delta)
-        T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha[..., :-1] + 1e-10], -1), -1)
-        w = alpha * T
-        img = (w[..., None] * col).sum(-2) + (1.0 - w.sum(-1))[..., None]                     # white background (utils.py:52-53)
-        imgs.append(img.clamp(0, 1).float())
-    return o, d, t, torch.stack(imgs)
-
-
-def psnr(a, b):
-    return float(-10.0 * torch.log10(((a - b) ** 2).mean()))
+    return _make_scene(ctx, WH, NTRAIN + NVAL, SCALE)
 
 
 def main():
@@ -85,6 +54,13 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate of both legs (Keras default 1e-3, nerf.py:163-165)")
     ap.add_argument("--seeds", default="0,1", help="glorot seeds of the coarse and fine MLP")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--deterministic", action="store_true", help="hip leg: bit-reproducible gradient sums (knerf_set_option deterministic)")
+    ap.add_argument("--skip-dead", action="store_true", help="hip leg: skip dead 32-sample tiles in the backward (exact); logs the dead fraction "
+                                                            "and the ms per step between checkpoints")
+    ap.add_argument("--save-weights", default=None, help="hip leg: write coarse/fine flat weights at every checkpoint to this .npz prefix")
+    ap.add_argument("--perturb", type=int, default=0,
+                    help="fp32 leg only: visit each step's chunks in a permutation drawn from this seed (0 = reference order). Same "
+                         "sums, another floating-point order: measures the fp32 arithmetic's own trajectory spread")
     args = ap.parse_args()
     global SCALE
     SCALE = args.scale
@@ -109,7 +85,8 @@ def main():
 
     if args.backend == "hip":
         nerf = NeRF()
-        nerf.compile({"learning_rate": args.lr}, "mse", batch_size=BATCH, image_height=WH, image_width=WH, ray_chunks=CHUNK, white_background=True)
+        nerf.compile({"learning_rate": args.lr}, "mse", batch_size=BATCH, image_height=WH, image_width=WH, ray_chunks=CHUNK, white_background=True,
+                     deterministic=args.deterministic, skip_dead_tiles=args.skip_dead)
         nerf.coarse.set_flat_weights(O.flatten_params(cp)); nerf.fine.set_flat_weights(O.flatten_params(fp))
         ev = NeRF()
         ev.compile("adam", "mse", batch_size=1, image_height=WH, image_width=WH, ray_chunks=CHUNK, white_background=True, is_training=False)
@@ -157,7 +134,8 @@ def main():
 
         def step(s):
             im, oo, dd, tt_, uu = batch(s)
-            lc, lf, _, _ = T.train_step(tc, tf_, oc, of_, im, oo, dd, tt_, uu, cfg, CHUNK, True)
+            co = None if not args.perturb else [int(i) for i in np.random.default_rng([args.perturb, s]).permutation(BATCH * WH * WH // CHUNK)]
+            lc, lf, _, _ = T.train_step(tc, tf_, oc, of_, im, oo, dd, tt_, uu, cfg, CHUNK, True, chunk_order=co)
             return lc, lf
 
     def save_state(s):
@@ -168,11 +146,22 @@ def main():
         log.append(dict(step=0, val_psnr=evaluate(), wall_s=0.0)); print(log[-1], flush=True)
     t0 = time.time()
     s = start
+    t_seg, s_seg = time.time(), start
     while s < args.steps:
         lc, lf = step(s)
         s += 1
         if s % args.eval_every == 0 or s == args.steps:
-            log.append(dict(step=s, coarse_loss=float(lc), fine_loss=float(lf), val_psnr=evaluate(), wall_s=time.time() - t0))
+            extra = {}
+            if args.backend == "hip":
+                torch.cuda.synchronize()
+                extra["ms_per_step"] = (time.time() - t_seg) / (s - s_seg) * 1e3
+                if args.skip_dead:
+                    live, total = nerf._ctx.tile_stats(reset=True)
+                    extra["dead_tile_frac"] = 1.0 - live / max(total, 1)
+                if args.save_weights:
+                    np.savez(f"{args.save_weights}_step{s}.npz", coarse=nerf.coarse.get_flat_weights(), fine=nerf.fine.get_flat_weights())
+            log.append(dict(step=s, coarse_loss=float(lc), fine_loss=float(lf), val_psnr=evaluate(), wall_s=time.time() - t0, **extra))
+            t_seg, s_seg = time.time(), s
             print(log[-1], flush=True)
             json.dump(log, open(args.out, "w"))
             save_state(s)
