@@ -10,6 +10,8 @@ data-parallel all-reduce(SUM) of the accumulated gradients when N > 1, both Adam
 PSNR/SSIM bookkeeping is excluded.  Per-GPU work is fixed as N grows ("weak" scaling, the
 reference's train.py semantics: global batch = batch_size x replicas).
 
+    python bench.py --mode fit [--config cfg2|cfg4]     what NeRF.fit delivers (loader -> train_step with metrics -> monitor), see bench_fit
+
 One JSON line is printed by rank 0; see the task contract for the fields.  `roofline` is measured live with HIP events
 around the dominant kernel (knerf_profile_*), `cpu_baseline` times the op-for-op torch-CPU restatement of the reference
 path (oracle/torch_ref.py, kind "port") on a bounded sample of the same workload.
@@ -233,6 +235,94 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def write_synthetic_dataset(root, wh, n=(100, 4, 4)):
+    """nerf_synthetic-layout directory (transforms_{train,val,test}.json + RGBA PNGs, reference loader.py:55-113) with procedural
+    images: 100 training views like the real scenes; the pixel content is irrelevant to throughput"""
+    from PIL import Image
+    from keras_nerf_amd.data.utils import pose_spherical
+    yy, xx = np.mgrid[0:wh, 0:wh].astype(np.float32) / wh
+    for subset, cnt in zip(("train", "val", "test"), n):
+        os.makedirs(os.path.join(root, subset), exist_ok=True)
+        frames = []
+        for i in range(cnt):
+            r = np.hypot(xx - 0.5 + 0.1 * np.sin(i), yy - 0.5) * 3
+            alpha = (r < 1).astype(np.float32)
+            rgb = np.stack([1 - r, 0.5 + 0.5 * np.cos(i + 3 * r), r], -1).clip(0, 1) * alpha[..., None]
+            Image.fromarray((np.concatenate([rgb, alpha[..., None]], -1) * 255).astype(np.uint8), "RGBA").save(os.path.join(root, subset, f"r_{i}.png"))
+            frames.append({"file_path": f"./{subset}/r_{i}", "transform_matrix": np.asarray(pose_spherical(360.0 * i / cnt, -30.0, 4.0)).tolist()})
+        json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, open(os.path.join(root, f"transforms_{subset}.json"), "w"))
+    return root
+
+
+def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
+    """`--mode fit`: the rate of the thing train_single.py:137-143 calls -- DatasetLoader (PNG decode, device-resident views,
+    on-device rays) -> NeRF.fit -> train_step WITH its six metrics -> NeRFTrainMonitor (panels off; CSV, checkpoint and the two
+    monitor renders at every epoch end) -- against the plain `train_step(with_metrics=False)` loop on one resident batch that
+    the default mode times.  One warm-up epoch (decodes the PNGs, fills the device cache), then `--epochs` timed epochs of 100
+    training views.  value = rays*samples of the training batches / time of the train loops (from an epoch's first batch to the
+    read-back of its logs, GPU drained); `fit_wall_*` adds validation and the monitor."""
+    import tempfile
+    from keras_nerf_amd.data.loader import DatasetLoader
+    from keras_nerf_amd.model.nerf.callback import NeRFTrainMonitor
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    root = tempfile.mkdtemp(prefix="knerf_fit_")
+    if rank == 0:
+        write_synthetic_dataset(os.path.join(root, "data"), wh)
+    if world > 1:
+        torch.distributed.barrier()
+    train, val, test = DatasetLoader(os.path.join(root, "data"), white_background=True).load_dataset(batch, wh, wh, 2.0, 6.0, 64)
+    nerf = NeRF(seed=0)
+    nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)
+    monitor = NeRFTrainMonitor(test, os.path.join(root, "log"), batch, update_freq=1, plots=False)
+    marks = []
+
+    class Clock:
+        def on_epoch_begin(self, epoch, logs=None):
+            torch.cuda.synchronize(); marks.append(["begin", time.perf_counter()])
+
+        def on_test_begin(self, logs=None):          # fit has read the epoch's logs back: the train loop is over and the GPU drained
+            marks.append(["train_end", time.perf_counter()])
+
+        def on_epoch_end(self, epoch, logs=None):
+            torch.cuda.synchronize(); marks.append(["end", time.perf_counter()])
+    epochs = 1 + args.epochs
+    nerf.fit(train, epochs=epochs, validation_data=val, callbacks=[Clock(), monitor], verbose=0)
+    torch.cuda.synchronize()
+    t = {k: [m[1] for m in marks if m[0] == k] for k in ("begin", "train_end", "end")}
+    steps = len(train)
+    loop = sum(t["train_end"][e] - t["begin"][e] for e in range(1, epochs))
+    wall = t["end"][-1] - t["begin"][1]
+    per_step = wh * wh * batch * 256
+    value = world * per_step * steps * args.epochs / loop
+    # the default mode's loop in the same process on the same device: one resident batch, no metrics
+    data = make_batch(nerf, wh, batch, rank)
+    for _ in range(3):
+        nerf.train_step(data, with_metrics=False)
+    sync(world); t0 = time.perf_counter()
+    for _ in range(20):
+        nerf.train_step(data, with_metrics=False)
+    sync(world); ts = (time.perf_counter() - t0) / 20
+    for _ in range(3):
+        nerf.train_step(data, sync=False)
+    sync(world); t0 = time.perf_counter()
+    for _ in range(20):
+        nerf.train_step(data, sync=False)
+    sync(world); tm = (time.perf_counter() - t0) / 20
+    if rank == 0:
+        print(json.dumps({"metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
+                          "unit": "rays*samples/s", "n_gpus": world, "steps": steps * args.epochs, "warmup": steps, "ms_per_step": loop / (steps * args.epochs) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"{args.config} through NeRF.fit: {desc}; 100 procedural training views in nerf_synthetic layout, "
+                                                 f"{steps} steps per epoch, {args.epochs} timed epochs after one warm-up epoch", "parallelism": f"dp{world}"},
+                          "train_step_ms": ts * 1e3, "train_step_with_metrics_ms": tm * 1e3, "metrics_ms_per_step": (tm - ts) * 1e3,
+                          "fit_vs_train_step": (loop / (steps * args.epochs)) and ts / (loop / (steps * args.epochs)),
+                          "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
+                          "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
+                          "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
+    import shutil
+    shutil.rmtree(root, ignore_errors=True)
+
+
 def spawn_ranks(args, backend, n_dev):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
     rendezvous on 127.0.0.1), wait, exit with their code.  Rank 0's JSON line goes to the inherited stdout.  The parent has
@@ -258,6 +348,10 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--mode", default="step", choices=["step", "fit"], help="step: the train_step loop on one resident batch (the contract's line); "
+                                                                            "fit: NeRF.fit through the loader, the metrics and the monitor")
+    ap.add_argument("--epochs", type=int, default=2, help="--mode fit: timed epochs")
+    ap.add_argument("--skip-dead-tiles", type=int, default=None, help="override the library default of the skip_dead_tiles option (0/1)")
     args = ap.parse_args()
 
     # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
@@ -277,6 +371,11 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible (RCCL needs one GPU per rank)")
     device_index = local_rank % max(n_dev, 1)
     torch.cuda.set_device(device_index)
+    if world > 1:          # which device every rank really sits on (a run that silently shares devices would still print a number)
+        pr = torch.cuda.get_device_properties(device_index)
+        pci = ":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, k)) or "n/a"
+        print(f"[bench rank {rank}/{world}] local_rank {local_rank} -> cuda:{device_index} {pr.name} pci {pci} uuid {getattr(pr, 'uuid', 'n/a')} "
+              f"backend {backend} visible_devices {n_dev}", file=sys.stderr, flush=True)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -291,9 +390,17 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    if args.mode == "fit":
+        RANK_ELAPSED[:] = [0.0]
+        bench_fit(args, world, rank, wh, batch, chunks, desc, backend)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     nerf = NeRF(seed=0)
     nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
                  white_background=True)
+    if args.skip_dead_tiles is not None:
+        nerf._ctx.set_option("skip_dead_tiles", args.skip_dead_tiles)
     data = make_batch(nerf, wh, batch, rank)
     n_rays = batch * wh * wh
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
@@ -301,12 +408,33 @@ def main():
     for _ in range(args.warmup):
         nerf.train_step(data, with_metrics=False)
     sync(world)
+    if world > 1:
+        nerf._allreduce_events = []            # HIP events on the compute stream around the gradient all-reduce of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nerf.train_step(data, with_metrics=False)
     sync(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    local_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(local_elapsed, world)
     value = world * n_rays * samples_per_ray * args.steps / elapsed
+    comm = {}
+    if world > 1:
+        ev, nerf._allreduce_events = nerf._allreduce_events, None
+        ms = [a.elapsed_time(b_) for a, b_ in ev]
+        # from the moment this rank's last chunk has finished to the moment the reduced gradients are usable: the collective
+        # itself plus the wait for the slowest rank
+        comm = {"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
+                "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4}
+    # what the six logged metrics add to a step (SURVEY.md 8d reports them separately): the same loop with metrics on, still
+    # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step)
+    for _ in range(2):
+        nerf.train_step(data, sync=False)
+    sync(world)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        nerf.train_step(data, sync=False)
+    sync(world)
+    metrics_ms = (time.perf_counter() - t1) / args.steps * 1e3 - local_elapsed / args.steps * 1e3      # this rank's own two loops
 
     roofline = None
     if not args.no_profile:
@@ -373,6 +501,7 @@ def main():
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
             "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
+            "metrics_ms_per_step": metrics_ms, **comm,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

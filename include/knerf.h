@@ -163,6 +163,13 @@ int knerf_ray_points(void* stream, const float* o, const float* d, const float* 
  * channels, sum of squared differences}: ssim = sums[0] / ((H-10)(W-10)C), psnr = -10 log10(sums[1] / (HWC)). */
 int knerf_image_metrics(void* stream, const float* a, const float* b, int n_images, int height, int width, int channels,
                         float* sums);
+/* NeRF.update_and_return_metrics (nerf.py:306-330) without a host round trip: the six tf.keras.metrics.Mean objects as device
+ * state [6][2] doubles = {total, count} in the order coarse_loss, coarse_psnr, coarse_ssim, fine_loss, fine_psnr, fine_ssim.
+ * sums_coarse / sums_fine = knerf_image_metrics(images, coarse images) / (images, fine images) [n_images][2]; loss [2] = the
+ * step's coarse and fine loss (device), or NULL for test_step's whole-image mean squared error (nerf.py:484-487) taken from
+ * the same sums.  PSNR and SSIM add one value per image, the losses one per step, as Keras' Mean does. */
+int knerf_metrics_update(void* stream, const float* sums_coarse, const float* sums_fine, const float* loss, int n_images,
+                         int height, int width, int channels, double* state);
 int knerf_composite(void* stream, const float* raw, const float* t, int n_rays, int n_samples, int white_background /* bit 0: white background, bit 1: no clip (utils.py:99-134) */,
                     float* image, float* depth, float* weights);
 int knerf_inverse_cdf(void* stream, const float* mid_points, const float* weights, const float* u, int n_rays, int n_mid,

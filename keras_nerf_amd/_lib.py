@@ -50,6 +50,7 @@ SIGNATURES = {
     "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "knerf_ray_points": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "knerf_image_metrics": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "knerf_metrics_update": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "knerf_mlp_call": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_uint64, _P]),
     "knerf_step_count": (C.c_int, [_P]),
     "knerf_set_step_count": (C.c_int, [_P, C.c_int]),

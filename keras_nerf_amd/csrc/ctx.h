@@ -57,6 +57,8 @@ struct knerf_ctx {
     knerf::Tables tab;
     int step = 0;
     int* d_flag = nullptr;             // device: set by the finite check of the current step
+    int* d_step = nullptr;             // device: optimizer steps applied so far (Adam's t - 1 of the next step)
+    float* d_lr_t = nullptr;           // device: bias-corrected learning rate of the next step, derived from d_step on the device
     int* h_status = nullptr;           // pinned host: [0] number of skipped (non-finite) steps so far, written by the device
     int skipped_seen = 0;
     int n_cu = 256;

@@ -117,14 +117,17 @@ hipError_t launch_sample_fine(const SampleArgs& a, hipStream_t stream);
 struct AdamArgs {
     float* w; float* m; float* v; float* g;   // kParamCount each; g is zeroed
     int n;
-    float lr_t, b1, b2, eps;
+    const float* lr_t;                         // device: bias-corrected learning rate of this step (optim.hip step_status_kernel)
+    float b1, b2, eps;
     const int* nonfinite;                      // device flag of this step's finite check: non-zero = skip the update
 };
+struct AdamHyper { float lr, b1, b2; };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 hipError_t launch_pack(const float* w, const int* table, unsigned short* out, size_t n, hipStream_t stream);
 hipError_t launch_gather_f32(const float* w, const int* table, float* out, size_t n, hipStream_t stream);
 hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t stream);
-hipError_t launch_step_status(const int* flag, int* host_status, hipStream_t stream);
+hipError_t launch_step_status(const int* flag, int* host_status, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream);
+hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream);
 // collapsed head (layout.h): w = one net's extended weight buffer (kExtParamCount floats).  compose writes the head matrix
 // and bias behind the parameters; expand turns the wgrad head job's aux sums into the gradients of features, rgb_features
 // and rgb (added to grad, aux zeroed).

@@ -417,6 +417,9 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(hipMemset(ctx->aux, 0, 2 * (size_t)kAuxCount * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->d_flag, sizeof(int)));
     CREATECHK(hipMemset(ctx->d_flag, 0, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->d_step, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->d_lr_t, sizeof(float)));
+    CREATECHK(launch_step_set(0, ctx->d_step, ctx->d_lr_t, AdamHyper{cfg->lr, cfg->beta1, cfg->beta2}, nullptr));
     CREATECHK(hipHostMalloc(&ctx->h_status, 2 * sizeof(int), hipHostMallocDefault));   // written by the device (optim.hip step_status)
     ctx->h_status[0] = ctx->h_status[1] = 0;
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
@@ -457,7 +460,7 @@ int knerf_destroy(knerf_ctx* ctx) {
         Net& N = ctx->net[n];
         free_dev(N.w); free_dev(N.m); free_dev(N.v); free_dev(N.fwd_stream); free_dev(N.bwd_stream); free_dev(N.bias);
     }
-    free_dev(ctx->grads); free_dev(ctx->aux); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp);
+    free_dev(ctx->grads); free_dev(ctx->aux); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp); free_dev(ctx->d_step); free_dev(ctx->d_lr_t);
     if (ctx->h_status) { (void)hipHostFree(ctx->h_status); ctx->h_status = nullptr; }
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
@@ -648,20 +651,18 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
     // a pinned status word (knerf_poll_nonfinite).
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), s));
     HIPCHK(launch_check_finite(ctx->grads, 2 * ctx->n_params, ctx->d_flag, s));
-    ctx->step += 1;
-    const double b1 = ctx->cfg.beta1, b2 = ctx->cfg.beta2;
-    const float lr_t = (float)((double)ctx->cfg.lr * std::sqrt(1.0 - std::pow(b2, ctx->step)) / (1.0 - std::pow(b1, ctx->step)));
+    ctx->step += 1;           // host mirror: steps enqueued minus the skipped ones that have been polled; Adam's t lives on the device
     ProfScope ps(ctx, s, P_ADAM);
     for (int n = 0; n < 2; ++n) {
         AdamArgs a{};
         a.w = ctx->net[n].w; a.m = ctx->net[n].m; a.v = ctx->net[n].v; a.g = ctx->net[n].g; a.n = ctx->n_params;
-        a.lr_t = lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
+        a.lr_t = ctx->d_lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
     }
     if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, s));      // both nets' heads in one launch
     for (int n = 0; n < 2; ++n)
         if (int r = repack(ctx, n, s, false)) return r;
-    HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, s));
+    HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, ctx->d_step, ctx->d_lr_t, AdamHyper{ctx->cfg.lr, ctx->cfg.beta1, ctx->cfg.beta2}, s));
     return KNERF_OK;
 }
 
@@ -737,7 +738,10 @@ int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total
 int knerf_step_count(const knerf_ctx* ctx) { return ctx ? ctx->step : KNERF_ERR_INVALID; }
 int knerf_set_step_count(knerf_ctx* ctx, int step) {
     if (!ctx || step < 0) return KNERF_ERR_INVALID;
+    HIPCHK(hipDeviceSynchronize());        // steps still in flight count from the old value
     ctx->step = step;
+    HIPCHK(launch_step_set(step, ctx->d_step, ctx->d_lr_t, AdamHyper{ctx->cfg.lr, ctx->cfg.beta1, ctx->cfg.beta2}, nullptr));
+    HIPCHK(hipDeviceSynchronize());
     return KNERF_OK;
 }
 

@@ -1,7 +1,8 @@
 // optim.hip -- Keras-form Adam over the flat parameter buffer, bf16 re-packing of the MFMA weight streams, finite check.
 //
 // Adam restates tf.keras.optimizers Adam as used at reference keras_nerf/model/nerf/nerf.py:163-165,455-458:
-//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host, double);  m += (g-m)(1-b1);  v += (g*g-v)(1-b2);
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (double; computed ON THE DEVICE from the device-side count of APPLIED steps, so a step that
+//   follows a skipped one uses the right t without the host knowing yet);  m += (g-m)(1-b1);  v += (g*g-v)(1-b2);
 //   w -= lr_t * m / (sqrt(v) + eps)      -- eps OUTSIDE the bias-corrected root, eps = 1e-7.
 // The gradient accumulator is zeroed in the same pass (nerf.py:464-471).  Finiteness (the reference asserts it per chunk,
 // nerf.py:381-382,410-411) is checked once per step BEFORE the update by check_finite_kernel; the Adam kernels read that
@@ -23,7 +24,7 @@ __global__ void adam_kernel(AdamArgs a) {
     m = m + (g - m) * (1.f - a.b1);
     v = v + (g * g - v) * (1.f - a.b2);
     a.m[i] = m; a.v[i] = v;
-    a.w[i] = a.w[i] - a.lr_t * m / (sqrtf(v) + a.eps);
+    a.w[i] = a.w[i] - *a.lr_t * m / (sqrtf(v) + a.eps);
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(adam_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
@@ -63,14 +64,33 @@ hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t str
     return hipGetLastError();
 }
 
-// host_status (pinned, device-visible): [0] += 1 when this step's finite check failed, [1] = steps processed
-__global__ void step_status_kernel(const int* flag, int* host_status) {
-    if (*flag) host_status[0] = host_status[0] + 1;
+// End of a step (one thread).  host_status (pinned, device-visible): [0] += 1 when this step's finite check failed, [1] = steps
+// processed.  step_state (device): [0] = optimizer steps APPLIED so far; lr_t = the bias-corrected learning rate of the NEXT
+// step, t = applied + 1 (Keras form, see the header) -- a skipped step leaves both as they were.
+__device__ __forceinline__ float keras_lr_t(AdamHyper h, int t) {
+    return (float)((double)h.lr * sqrt(1.0 - pow((double)h.b2, (double)t)) / (1.0 - pow((double)h.b1, (double)t)));
+}
+__global__ void step_status_kernel(const int* flag, int* host_status, int* step_state, float* lr_t, AdamHyper h) {
+    if (*flag) {
+        host_status[0] = host_status[0] + 1;
+    } else {
+        step_state[0] = step_state[0] + 1;
+        *lr_t = keras_lr_t(h, step_state[0] + 1);
+    }
     host_status[1] = host_status[1] + 1;
     __threadfence_system();
 }
-hipError_t launch_step_status(const int* flag, int* host_status, hipStream_t stream) {
-    hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, flag, host_status);
+hipError_t launch_step_status(const int* flag, int* host_status, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream) {
+    hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, flag, host_status, step_state, lr_t, h);
+    return hipGetLastError();
+}
+// the applied-step counter set from the host (knerf_create, knerf_set_step_count)
+__global__ void step_set_kernel(int step, int* step_state, float* lr_t, AdamHyper h) {
+    step_state[0] = step;
+    *lr_t = keras_lr_t(h, step + 1);
+}
+hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream) {
+    hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, stream, step, step_state, lr_t, h);
     return hipGetLastError();
 }
 

@@ -110,9 +110,41 @@ __global__ __launch_bounds__(256) void image_metrics_kernel(MetricArgs m) {
     }
 }
 
+// NeRF.update_and_return_metrics (nerf.py:306-330) on the device: six running means (tf.keras.metrics.Mean: total and count)
+// in the order coarse_loss, coarse_psnr, coarse_ssim, fine_loss, fine_psnr, fine_ssim; one thread, enqueued behind the two
+// image_metrics launches -- nothing returns to the host until somebody reads a result.
+struct MetricUpdateArgs { const float* sc; const float* sf; const float* loss; double* state; int n_images, nwin, npix; };
+__global__ void metrics_update_kernel(MetricUpdateArgs m) {
+    double ps[2] = {0.0, 0.0}, ss[2] = {0.0, 0.0};
+    float sq[2] = {0.f, 0.f};
+    for (int b = 0; b < m.n_images; ++b) {
+        const float* s[2] = {m.sc + 2 * b, m.sf + 2 * b};
+        for (int k = 0; k < 2; ++k) {
+            ss[k] += (double)(s[k][0] / (float)m.nwin);                              // tf.image.ssim: mean over windows and channels
+            ps[k] += (double)(-10.0f * log10f(s[k][1] / (float)m.npix));            // tf.image.psnr, max_val 1
+            sq[k] += s[k][1];
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        double* st = m.state + 6 * k;
+        // loss == null: test_step's whole-image mean squared error (nerf.py:484-487) from the same squared-difference sums
+        st[0] += m.loss ? (double)m.loss[k] : (double)(sq[k] / ((float)m.npix * (float)m.n_images)); st[1] += 1.0;
+        st[2] += ps[k]; st[3] += (double)m.n_images;
+        st[4] += ss[k]; st[5] += (double)m.n_images;
+    }
+}
+
 }  // namespace knerf
 
 using namespace knerf;
+
+extern "C" int knerf_metrics_update(void* stream, const float* sums_coarse, const float* sums_fine, const float* loss, int n_images,
+                                    int height, int width, int channels, double* state) {
+    if (!sums_coarse || !sums_fine || !state || n_images <= 0 || height < 11 || width < 11 || channels <= 0) return KNERF_ERR_INVALID;
+    MetricUpdateArgs m{sums_coarse, sums_fine, loss, state, n_images, (height - 10) * (width - 10) * channels, height * width * channels};
+    hipLaunchKernelGGL(metrics_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, m);
+    return hipGetLastError() == hipSuccess ? KNERF_OK : KNERF_ERR_HIP;
+}
 
 extern "C" int knerf_ray_points(void* stream, const float* o, const float* d, const float* t, int n_rays, int n_samples, float* out) {
     if (!o || !d || !t || !out || n_rays <= 0 || n_samples <= 0) return KNERF_ERR_INVALID;

@@ -11,7 +11,14 @@ Data parallel (one process per GPU, reference train.py:75-93): the reference bui
 same dataset with the per-replica `batch_size`; all ranks draw the same shuffled order (one shared seed, buffer = global
 batch), cut it into global batches of `batch_size x world` (remainder dropped) and keep their own slice, so the replicas
 see disjoint images and the SUM all-reduce of NeRF.train_step adds gradients of different data.  The ray jitter stream is
-keyed by the rank as well."""
+keyed by the rank as well.
+
+Feeding the GPU (the reference prefetches with tf.data, loader.py:104-106): the decoded images and the camera matrices of a
+dataset are kept RESIDENT ON THE DEVICE (100 views of 800 x 800 x 4 floats are 1 GB of 288), filled as the first pass touches
+them, so from the second epoch on a batch is one gather on the device plus the ray-generation kernel -- no host-to-device copy
+and, above all, no pageable copy that would make the host wait for the previous train step.  The few indices a batch needs
+travel through pinned memory with a non-blocking copy.  A dataset larger than `device_cache_gb` (default 64) is staged through
+two pinned buffers on a side stream instead, one batch ahead of the step that consumes it."""
 from __future__ import annotations
 
 import json
@@ -71,13 +78,17 @@ def replica_batches(order, batch_size, rank=0, world=1, limit=None):
 
 class RayImageDataset:
     def __init__(self, image_paths, camera_params, image_loader, rays_generator_factory, batch_size, seed=0, limit=None,
-                 rank=None, world=None):
-        """rank / world: data-parallel placement; None = taken from torch.distributed when an iteration starts"""
+                 rank=None, world=None, device_cache_gb=64.0, _shared=None):
+        """rank / world: data-parallel placement; None = taken from torch.distributed when an iteration starts.
+        device_cache_gb: keep the whole dataset on the device when it fits this budget (see the module docstring)."""
         self.image_paths, self.camera_params = list(image_paths), [np.asarray(c, np.float32) for c in camera_params]
         self.image_loader, self._rg_factory, self._rg = image_loader, rays_generator_factory, None
         self.batch_size, self._rng, self._limit = batch_size, np.random.default_rng(seed), limit
         self._rank, self._world = rank, world
-        self._cache = {}
+        self.device_cache_gb = device_cache_gb
+        # decoded host images and the device-resident copies are shared between a dataset and its take() views
+        self._shared = _shared if _shared is not None else {"host": {}, "dev": None, "have": None, "cams": None}
+        self._cache = self._shared["host"]
 
     def _placement(self):
         if self._rank is not None and self._world is not None:
@@ -90,12 +101,42 @@ class RayImageDataset:
 
     def take(self, n):
         return RayImageDataset(self.image_paths, self.camera_params, self.image_loader, self._rg_factory, self.batch_size,
-                               seed=int(self._rng.integers(1 << 31)), limit=n, rank=self._rank, world=self._world)
+                               seed=int(self._rng.integers(1 << 31)), limit=n, rank=self._rank, world=self._world,
+                               device_cache_gb=self.device_cache_gb, _shared=self._shared)
+
+    def private_view(self, seed=0, limit=None):
+        """the same data behind an INDEPENDENT shuffle stream: iterating the view never advances this dataset's generator.
+        For consumers that iterate on one rank only (NeRFTrainMonitor on rank 0), so that the ranks' shared order of THIS
+        dataset stays in lock-step."""
+        return RayImageDataset(self.image_paths, self.camera_params, self.image_loader, self._rg_factory, self.batch_size,
+                               seed=seed, limit=self._limit if limit is None else limit, rank=self._rank, world=self._world,
+                               device_cache_gb=self.device_cache_gb, _shared=self._shared)
 
     def _image(self, i):
         if i not in self._cache:
             self._cache[i] = self.image_loader(self.image_paths[i])
         return self._cache[i]
+
+    # ---- device-resident copy
+    def _resident(self, shape):
+        """(images [N,H,W,4], have [N] host bools, cams [N,4,4]) on the device, or None when the dataset exceeds the budget"""
+        import torch
+        sh = self._shared
+        if sh["dev"] is None and sh.get("dev_refused") is None:
+            n = len(self.image_paths)
+            if n * int(np.prod(shape)) * 4 > self.device_cache_gb * 1e9:
+                sh["dev_refused"] = True
+            else:
+                sh["dev"] = torch.empty((n, *shape), device="cuda", dtype=torch.float32)
+                sh["have"] = np.zeros(n, bool)
+                sh["cams"] = torch.as_tensor(np.stack(self.camera_params)).pin_memory().to("cuda", non_blocking=True)
+        return None if sh["dev"] is None else (sh["dev"], sh["have"], sh["cams"])
+
+    @staticmethod
+    def _to_device_async(array):
+        """small host array -> device without a pageable copy (which would make the host wait for the stream's earlier work)"""
+        import torch
+        return torch.as_tensor(array).pin_memory().to("cuda", non_blocking=True)
 
     def __iter__(self):
         import torch
@@ -106,12 +147,51 @@ class RayImageDataset:
         order = shuffled_order(len(self.image_paths), self.batch_size * world, self._rng)
         batches = replica_batches(order, self.batch_size, rank, world, self._limit)
 
-        def gen():
+        def gen_resident(res):
+            dev, have, cams = res
             for idx in batches:
+                missing = [i for i in idx if not have[i]]
+                if missing:                                   # first touch: decode on the host, one pinned non-blocking upload
+                    up = self._to_device_async(np.stack([self._image(i) for i in missing]))
+                    dev[self._to_device_async(np.asarray(missing, np.int64))] = up
+                    have[missing] = True
+                    for i in missing:
+                        self._cache.pop(i, None)              # the device copy is the cache now
+                sel = self._to_device_async(np.asarray(idx, np.int64))
+                o, d, t = self._rg(cams.index_select(0, sel))
+                yield dev.index_select(0, sel), (o, d, t)
+
+        def gen_staged():
+            # two pinned staging buffers, copies on a side stream one batch ahead of the consumer
+            side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            pinned, copied, pending = [None, None], [None, None], None
+
+            def stage(k, idx):
                 images = np.stack([self._image(i) for i in idx])
-                o, d, t = self._rg(np.stack([self.camera_params[i] for i in idx]))
-                yield torch.as_tensor(images).to(o.device), (o, d, t)
-        return _Iterator(gen())
+                if copied[k] is not None:
+                    copied[k].synchronize()                   # the buffer's previous upload (two batches ago) has left it
+                if pinned[k] is None or pinned[k].shape != images.shape:
+                    pinned[k] = torch.empty(images.shape, dtype=torch.float32).pin_memory()
+                pinned[k].copy_(torch.as_tensor(images))
+                with torch.cuda.stream(side):
+                    dev = pinned[k].to("cuda", non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(side)
+                copied[k] = ev
+                return dev, ev
+            for n, idx in enumerate(batches):
+                cur = pending if pending is not None else stage(n & 1, idx)
+                pending = stage((n + 1) & 1, batches[n + 1]) if n + 1 < len(batches) else None
+                dev, ev = cur
+                main.wait_event(ev)
+                dev.record_stream(main)
+                o, d, t = self._rg(self._to_device_async(np.stack([self.camera_params[i] for i in idx])))
+                yield dev, (o, d, t)
+
+        if not batches:
+            return _Iterator(iter(()))
+        res = self._resident(self._image(batches[0][0]).shape)
+        return _Iterator(gen_resident(res) if res is not None else gen_staged())
 
 
 class DatasetLoader:

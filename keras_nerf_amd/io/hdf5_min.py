@@ -70,13 +70,28 @@ class Hdf5Reader:
             self.buf = f.read()
         if self.buf[:8] != SIGNATURE:
             raise Hdf5FormatError(f"{path}: not an HDF5 file (signature missing)")
-        self._superblock()
-        self.root = self._object(self.root_addr)
+        # The file is untrusted input: every address is bounds-checked (_u), object / B-tree / continuation references that
+        # loop back are refused (_object's path set, _MAX_DEPTH, _MAX_BLOCKS), and whatever a damaged structure still trips
+        # (a bad length in a message, a name without terminator, ...) surfaces as Hdf5FormatError, never as a bare IndexError,
+        # a short silent read or an endless recursion.
+        self._path, self._done = set(), {}
+        try:
+            self._superblock()
+            self.root = self._object(self.root_addr)
+        except Hdf5FormatError:
+            raise
+        except (IndexError, ValueError, struct.error, RecursionError, UnicodeDecodeError, OverflowError, MemoryError) as e:
+            raise Hdf5FormatError(f"{path}: damaged or unsupported HDF5 structure ({type(e).__name__}: {e})") from e
         if not isinstance(self.root, _Group):
             raise Hdf5FormatError("root object is not a group")
 
+    _MAX_DEPTH = 64            # nesting of groups (a Keras weight file has 4)
+    _MAX_BLOCKS = 4096         # object-header continuation blocks / B-tree nodes followed per object
+
     # ---- primitives
     def _u(self, off, n):
+        if off < 0 or off + n > len(self.buf):
+            raise Hdf5FormatError(f"address {off} (+{n}) lies outside the file ({len(self.buf)} bytes)")
         return int.from_bytes(self.buf[off:off + n], "little")
 
     def _addr(self, off):
@@ -118,8 +133,12 @@ class Hdf5Reader:
             chunk0 = self._u(p, csz); p += csz
             tracked = bool(flags & 0x04)
             blocks = [(p, chunk0)]
+            seen = 0
             while blocks:
                 p, size = blocks.pop(0)
+                seen += 1
+                if seen > self._MAX_BLOCKS or p < 0 or p + size > len(b):
+                    raise Hdf5FormatError("object header continuation chain is cyclic or leaves the file")
                 end = p + size
                 while p + 4 <= end - 0:
                     t = b[p]; sz = self._u(p + 1, 2); fl = b[p + 3]; p += 4
@@ -141,8 +160,12 @@ class Hdf5Reader:
         n_msgs = self._u(addr + 2, 2)
         size = self._u(addr + 8, 4)
         blocks = [(addr + 16, size)]
+        seen = 0
         while blocks and len(msgs) < n_msgs + 64:
             p, size = blocks.pop(0)
+            seen += 1
+            if seen > self._MAX_BLOCKS or p < 0 or p + size > len(b):
+                raise Hdf5FormatError("object header continuation chain is cyclic or leaves the file")
             end = p + size
             while p + 8 <= end:
                 t, sz, fl = self._u(p, 2), self._u(p + 2, 2), b[p + 4]
@@ -156,6 +179,22 @@ class Hdf5Reader:
         return msgs
 
     def _object(self, addr):
+        """the group or dataset whose object header sits at addr; an address that is already on the path from the root (a
+        group that contains itself) is refused, one that was reached by another path (a hard link) is returned again"""
+        if addr in self._done:
+            return self._done[addr]
+        if addr in self._path or len(self._path) >= self._MAX_DEPTH:
+            raise Hdf5FormatError(f"group structure is cyclic or nested deeper than {self._MAX_DEPTH} (object header at {addr})")
+        if addr < 0 or addr >= len(self.buf):
+            raise Hdf5FormatError(f"object header address {addr} lies outside the file")
+        self._path.add(addr)
+        try:
+            obj = self._done[addr] = self._object_at(addr)
+        finally:
+            self._path.discard(addr)
+        return obj
+
+    def _object_at(self, addr):
         msgs = self._messages(addr)
         types = {t for t, _, _ in msgs}
         if 0x11 in types:                                    # symbol table: old-style group
@@ -199,6 +238,8 @@ class Hdf5Reader:
 
     # ---- old-style groups
     def _heap_name(self, heap_data_addr, off):
+        if heap_data_addr + off >= len(self.buf):
+            raise Hdf5FormatError("link name offset lies outside the file")
         end = self.buf.index(b"\x00", heap_data_addr + off)
         return self.buf[heap_data_addr + off:end].decode("utf8")
 
@@ -214,20 +255,27 @@ class Hdf5Reader:
             n = self._u(snod + 6, 2)
             p = snod + 8
             for _ in range(n):
-                name_off, ohdr = self._u(p, 8), self._u(p + 8, 8)
-                g[self._heap_name(heap_data, name_off)] = self._object(ohdr)
+                name_off, ohdr, cache = self._u(p, 8), self._u(p + 8, 8), self._u(p + 16, 4)
+                if cache != 2:                               # cache type 2 = symbolic link: its "object header address" is not one
+                    g[self._heap_name(heap_data, name_off)] = self._object(ohdr)
                 p += 40
         return g
 
-    def _btree_leaves(self, addr):
+    def _btree_leaves(self, addr, above=256, budget=None):
         b = self.buf
         if addr == UNDEF:
             return
+        budget = budget if budget is not None else [self._MAX_BLOCKS]
+        budget[0] -= 1
+        if budget[0] < 0 or addr < 0 or addr + 8 > len(b):
+            raise Hdf5FormatError("group B-tree is cyclic or leaves the file")
         if b[addr:addr + 4] != b"TREE":
             raise Hdf5FormatError("bad B-tree node signature")
         if b[addr + 4] != 0:
             raise Hdf5FormatError("chunked-dataset B-tree where a group B-tree was expected")
         level, used = b[addr + 5], self._u(addr + 6, 2)
+        if level >= above:
+            raise Hdf5FormatError("group B-tree levels do not decrease towards the leaves")
         p = addr + 8 + 2 * self.so
         for i in range(used):
             child = self._u(p + self.sl, self.so)           # key_i, child_i, key_i+1, ...
@@ -235,7 +283,7 @@ class Hdf5Reader:
             if level == 0:
                 yield child
             else:
-                yield from self._btree_leaves(child)
+                yield from self._btree_leaves(child, level, budget)
 
     # ---- datasets
     def _dataset(self, msgs) -> _Dataset:

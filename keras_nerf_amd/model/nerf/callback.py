@@ -7,7 +7,10 @@ Same artefacts: `<log_dir>/log.csv` (columns `epoch` + the 12 log keys, header w
 
 Data parallel (one process per GPU): every rank keeps the loss history, only rank 0 renders panels and writes files (the
 replicas hold identical weights and `fit` has already averaged the logs); the other ranks wait at a barrier so that nobody
-runs ahead of a checkpoint that is still being written."""
+runs ahead of a checkpoint that is still being written.  The barrier is reached even when rank 0's rendering, plotting or
+writing raises (try/finally: the error then surfaces on rank 0 instead of as a collective time-out everywhere else), and the
+"other test images" iterator walks a PRIVATE view of the dataset (own shuffle generator), so that its rank-0-only iteration
+never advances the generator from which every rank derives the shared batch order."""
 from __future__ import annotations
 
 import logging
@@ -47,7 +50,9 @@ class NeRFTrainMonitor:
             self.images, self.rays = inputs
             o, d, t = self.rays
             self.ray_origin, self.ray_direction, self.coarse_points = o[:batch_size], d[:batch_size], t[:batch_size]
-        self.dataset_iterator = iter(self.dataset)
+        # rank-0-only iteration below must not touch the dataset's own generator (loader.py: the ranks' shared order)
+        self._sample_view = self.dataset.private_view(seed=20240229) if hasattr(self.dataset, "private_view") else self.dataset
+        self.dataset_iterator = iter(self._sample_view)
         self.dataset_iterator.get_next()
 
     def set_model(self, model):
@@ -92,28 +97,33 @@ class NeRFTrainMonitor:
         if epoch % self.update_freq == 0 and not parallel.is_main():
             parallel.barrier()                                     # rank 0 is writing panels, log.csv and the checkpoint
         elif epoch % self.update_freq == 0:
-            coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
-            curves = [(self.coarse_log_list, "blue", "solid", "Coarse Train Loss"), (self.val_coarse_log_list, "blue", "dashed", "Coarse Val Loss"),
-                      (self.fine_log_list, "orange", "solid", "Fine Train Loss"), (self.val_fine_log_list, "orange", "dashed", "Fine Val Loss")]
-            for i in range(self.batch_size):
-                self._panel(os.path.join(self.log_dir, f"test_{i}_{epoch}.png"), coarse, fine, self.images, i, curves, f"Loss Plot: {epoch}")
-            try:                                                   # "Predict other test images" (callback.py:168-209)
-                images, rays = self.dataset_iterator.get_next()
-            except StopIteration:
-                self.dataset_iterator = iter(self.dataset)
-                images, rays = self.dataset_iterator.get_next()
-            o, d, t = [r[:self.batch_size] for r in rays]
-            coarse, fine = self.model.predict_and_render_images((o, d, t))
-            for i in range(self.batch_size):
-                self._panel(os.path.join(self.log_dir, f"test_sample_{i}_{epoch}.png"), coarse, fine, images, i)
-            with open(self.log_csv, "a") as f:                     # callback.py:211-218
-                new_logs = {"epoch": epoch}
-                new_logs.update(logs)
-                w = DictWriter(f, new_logs.keys())
-                if epoch == 0:
-                    w.writeheader()
-                w.writerow(new_logs)
-            self.model.save_model(self.log_model_dir, weights_only=(epoch != 0))   # callback.py:220-222
-            parallel.barrier()
+            try:
+                self._write_epoch(epoch, logs)
+            finally:
+                parallel.barrier()                                 # also when the writing failed: nobody is left waiting
         if self.verbose:
             self.coarse_log_list_batch, self.fine_log_list_batch = [], []
+
+    def _write_epoch(self, epoch, logs):
+        coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
+        curves = [(self.coarse_log_list, "blue", "solid", "Coarse Train Loss"), (self.val_coarse_log_list, "blue", "dashed", "Coarse Val Loss"),
+                  (self.fine_log_list, "orange", "solid", "Fine Train Loss"), (self.val_fine_log_list, "orange", "dashed", "Fine Val Loss")]
+        for i in range(self.batch_size):
+            self._panel(os.path.join(self.log_dir, f"test_{i}_{epoch}.png"), coarse, fine, self.images, i, curves, f"Loss Plot: {epoch}")
+        try:                                                   # "Predict other test images" (callback.py:168-209)
+            images, rays = self.dataset_iterator.get_next()
+        except StopIteration:
+            self.dataset_iterator = iter(self._sample_view)
+            images, rays = self.dataset_iterator.get_next()
+        o, d, t = [r[:self.batch_size] for r in rays]
+        coarse, fine = self.model.predict_and_render_images((o, d, t))
+        for i in range(self.batch_size):
+            self._panel(os.path.join(self.log_dir, f"test_sample_{i}_{epoch}.png"), coarse, fine, images, i)
+        with open(self.log_csv, "a") as f:                     # callback.py:211-218
+            new_logs = {"epoch": epoch}
+            new_logs.update(logs)
+            w = DictWriter(f, new_logs.keys())
+            if epoch == 0:
+                w.writeheader()
+            w.writerow(new_logs)
+        self.model.save_model(self.log_model_dir, weights_only=(epoch != 0))   # callback.py:220-222

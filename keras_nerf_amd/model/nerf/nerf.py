@@ -18,7 +18,7 @@ import torch
 
 from ... import parallel
 from ...runtime import COARSE, FINE, KnerfContext, NonFiniteGradientError  # noqa: F401
-from .metrics import Mean, psnr, ssim
+from .metrics import Mean, MetricLogs, MetricState
 from .mlp import NeRFMLP
 from .utils import NeRFUtils
 
@@ -110,6 +110,8 @@ class NeRF:
     # ------------------------------------------------------------------ save / load (nerf.py:45-76)
     def save_model(self, path, weights_only=False):
         logging.info("Saving NeRF model")
+        if self._ctx is not None:
+            self._ctx.poll_nonfinite(wait=True)      # never checkpoint past an unreported skipped step
         os.makedirs(path, exist_ok=True)
         if not weights_only:
             cfg = dict(n_coarse=self.n_coarse, n_fine=self.n_fine, pos_emb_xyz=self.pos_emb_xyz, pos_emb_dir=self.pos_emb_dir,
@@ -187,10 +189,12 @@ class NeRF:
             self.fine.load_weights(os.path.join(self.model_path, "fine.h5"))
 
     def _initialize_metrics(self):                       # nerf.py:167-173
-        self.coarse_loss_tracker = Mean("coarse_loss"); self.coarse_psnr_metric = Mean("coarse_psnr")
-        self.corase_ssim_metric = Mean("coarse_ssim")
-        self.fine_loss_tracker = Mean("fine_loss"); self.fine_psnr_metric = Mean("fine_psnr")
-        self.fine_ssim_metric = Mean("fine_ssim")
+        # the six running means share one device-side state (metrics.py): a step enqueues its contribution, nothing is read back
+        st = self._metric_state = MetricState(self.device)
+        self.coarse_loss_tracker = Mean("coarse_loss", st, 0); self.coarse_psnr_metric = Mean("coarse_psnr", st, 1)
+        self.corase_ssim_metric = Mean("coarse_ssim", st, 2)
+        self.fine_loss_tracker = Mean("fine_loss", st, 3); self.fine_psnr_metric = Mean("fine_psnr", st, 4)
+        self.fine_ssim_metric = Mean("fine_ssim", st, 5)
 
     @property
     def metrics(self):                                   # nerf.py:499-508
@@ -198,8 +202,7 @@ class NeRF:
                 self.fine_loss_tracker, self.fine_psnr_metric, self.fine_ssim_metric]
 
     def reset_metrics(self):
-        for m in self.metrics:
-            m.reset_state()
+        self._metric_state.state.zero_()
 
     # ------------------------------------------------------------------ forward
     def _flat_rays(self, rays):
@@ -250,17 +253,19 @@ class NeRF:
 
     # ------------------------------------------------------------------ metrics (nerf.py:306-330)
     def update_and_return_metrics(self, images, coarse_images, fine_images, coarse_loss, fine_loss):
-        self.coarse_loss_tracker.update_state(coarse_loss)
-        self.coarse_psnr_metric.update_state(psnr(images, coarse_images, 1.0))
-        self.corase_ssim_metric.update_state(ssim(images, coarse_images, 1.0))
-        self.fine_loss_tracker.update_state(fine_loss)
-        self.fine_psnr_metric.update_state(psnr(images, fine_images, 1.0))
-        self.fine_ssim_metric.update_state(ssim(images, fine_images, 1.0))
-        return {m.name: m.result() for m in self.metrics}
+        """two metric launches (each yields both the SSIM and the squared-error sums of one image pair) + one update of the
+        device-side means; returns the six running means as a mapping that reads them back lazily (metrics.MetricLogs)"""
+        losses = torch.stack([torch.as_tensor(coarse_loss, device=self.device).reshape(()).float(),
+                              torch.as_tensor(fine_loss, device=self.device).reshape(()).float()])
+        self._metric_state.update(images, coarse_images, fine_images, losses)
+        return self._metric_state.snapshot()
 
     # ------------------------------------------------------------------ train / test step
-    def train_step(self, inputs, u=None, with_metrics=True):
-        """nerf.py:332-473.  inputs = (images [B,H,W,3|4], (o, d, t))."""
+    def train_step(self, inputs, u=None, with_metrics=True, sync=True):
+        """nerf.py:332-473.  inputs = (images [B,H,W,3|4], (o, d, t)).  Returns the six running means (read back lazily).
+        sync=True (a direct call): waits for the step, so a non-finite gradient raises from THIS call as in the reference
+        (nerf.py:381-382).  sync=False (what `fit` uses): nothing waits for the GPU; a skipped step raises from the first later
+        poll (fit polls at every epoch end, save_model and get_weights poll before they read weights)."""
         images, rays = inputs
         images = self._ctx.f32(images)[..., :3].contiguous()                      # nerf.py:335
         o, d, t = self._flat_rays(rays)
@@ -274,7 +279,13 @@ class NeRF:
         # inside the library: one host call per step
         self._ctx.train_batch(o, d, t, tgt, uf, seed, R, self._loss_acc, ci, fi)
         if self._dist:                                                            # nerf.py:455-458 under MirroredStrategy
+            timing = getattr(self, "_allreduce_events", None)                     # bench.py: events around the collective
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             parallel.all_reduce_gradients(self._ctx.grads_view(), self.all_reduce)
+            if timing is not None:
+                e1.record(); timing.append((e0, e1))
         # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471): enqueued, nothing waits for the GPU
         self._ctx.apply_adam(check=False)
         if not with_metrics:
@@ -283,9 +294,9 @@ class NeRF:
             self._ctx.poll_nonfinite(wait=False)
             return {"coarse_loss": self._loss_acc[0], "fine_loss": self._loss_acc[1]}
         B, H, W = self.batch_size, self.image_height, self.image_width
-        logs = self.update_and_return_metrics(images, ci.reshape(B, H, W, 3), fi.reshape(B, H, W, 3),
-                                              self._loss_acc[0].clone(), self._loss_acc[1].clone())
-        self._ctx.poll_nonfinite(wait=True)      # as the reference: the failing batch raises from its own train_step
+        self._metric_state.update(images, ci.reshape(B, H, W, 3), fi.reshape(B, H, W, 3), self._loss_acc)
+        logs = self._metric_state.snapshot()
+        self._ctx.poll_nonfinite(wait=bool(sync))      # sync: as the reference, the failing batch raises from its own train_step
         return logs
 
     def test_step(self, inputs, u=None):
@@ -293,11 +304,9 @@ class NeRF:
         images, rays = inputs
         images = self._ctx.f32(images)[..., :3].contiguous()
         coarse, fine = self.predict_and_render_images(rays, u)
-        # whole-image MSE (nerf.py:484-487) from the metrics kernel's squared-difference sums
-        from .metrics import _image_sums
-        (sc, _, npx), (sf, _, _) = _image_sums(images, coarse["image"]), _image_sums(images, fine["image"])
-        cl = sc[:, 1].sum() / (npx * images.shape[0]); fl = sf[:, 1].sum() / (npx * images.shape[0])
-        return self.update_and_return_metrics(images, coarse["image"], fine["image"], cl, fl)
+        # whole-image MSE (nerf.py:484-487) from the metrics kernel's squared-difference sums (losses=None)
+        self._metric_state.update(images, coarse["image"], fine["image"], None)
+        return self._metric_state.snapshot()
 
     # ------------------------------------------------------------------ fit: the part of tf.keras.Model.fit the reference uses
     def fit(self, dataset, epochs=1, validation_data=None, callbacks=None, initial_epoch=0, verbose=1):
@@ -319,15 +328,22 @@ class NeRF:
                 getattr(cb, "on_epoch_begin", lambda e, logs=None: None)(epoch, {})
             logs = {}
             for b, batch in enumerate(dataset):
-                logs = {k: float(v) for k, v in self.train_step(batch).items()}
+                # asynchronous: the step is enqueued, its logs stay on the device until a callback reads them (MetricLogs)
+                logs = self.train_step(batch, sync=False)
                 for cb in callbacks:
                     getattr(cb, "on_train_batch_end", lambda i, logs=None: None)(b, logs)
+            logs = {k: float(v) for k, v in dict(logs).items()}            # one read-back per epoch
+            self._ctx.poll_nonfinite(wait=True)                            # a skipped step of this epoch raises here at the latest
             if validation_data is not None:
+                for cb in callbacks:
+                    getattr(cb, "on_test_begin", lambda logs=None: None)({})
                 self.reset_metrics()
                 vlogs = {}
                 for batch in validation_data:
                     vlogs = self.test_step(batch)
-                logs.update({"val_" + k: float(v) for k, v in vlogs.items()})
+                logs.update({"val_" + k: float(v) for k, v in dict(vlogs).items()})
+                for cb in callbacks:
+                    getattr(cb, "on_test_end", lambda logs=None: None)(dict(logs))
             logs = parallel.reduce_logs(logs, self.device)    # replica means (one tiny all-reduce)
             for k, v in logs.items():
                 history.setdefault(k, []).append(v)

@@ -8,6 +8,7 @@ import torch
 
 from oracle import nerf_oracle as O
 from tests.problem import make_problem
+from tests.test_gpu_forward import log_stats
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +58,16 @@ def test_train_step_logs_and_metrics(model):
     assert [m.name for m in nerf.metrics] == ["coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim"]
     assert np.abs(nerf.coarse.get_flat_weights() - before).max() > 0
     v = nerf.test_step((P["img"], (P["o"], P["d"], P["t"])), u=P["u"])
-    assert np.isfinite(v["fine_loss"])
+    # test_step's two losses are whole-image mean squared errors of the rendered images (nerf.py:484-487): against the oracle's
+    # render of the same weights (kernel arithmetic) and against the images this model returns for the same rays and u
+    wc, wf = O.unflatten_params(nerf.coarse.get_flat_weights(), P["cfg"]), O.unflatten_params(nerf.fine.get_flat_weights(), P["cfg"])
+    c, f = O.predict_and_render_images(wc, wf, P["o"], P["d"], P["t"], P["u"], P["cfg"], 128, True, emulate_bf16=O.FUSED)
+    assert v["coarse_loss"] == pytest.approx(float(np.mean((c["image"] - P["img"]) ** 2)), abs=2e-3)
+    assert v["fine_loss"] == pytest.approx(float(np.mean((f["image"] - P["img"]) ** 2)), abs=2e-3)
+    gc_, gf_ = nerf.predict_and_render_images((P["o"], P["d"], P["t"]), u=P["u"])
+    assert v["coarse_loss"] == pytest.approx(float(((gc_["image"].cpu().numpy() - P["img"]) ** 2).mean()), rel=1e-5)
+    assert v["fine_loss"] == pytest.approx(float(((gf_["image"].cpu().numpy() - P["img"]) ** 2).mean()), rel=1e-5)
+    assert v["coarse_psnr"] == pytest.approx(float(np.mean(O.psnr(P["img"], gc_["image"].cpu().numpy()))), abs=1e-3)
     nerf.coarse.set_flat_weights(O.flatten_params(P["cp"])); nerf.fine.set_flat_weights(O.flatten_params(P["fp"]))
 
 
@@ -276,6 +286,28 @@ def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     assert np.mean(np.sign(w - a["w_start"])[moved] == np.sign(a["w_end"] - a["w_start"])[moved]) > 0.999
     np.testing.assert_allclose(w, a["w_end"], atol=2e-5)                      # fp32 atomics: summation order only
     ctx.close()
+    # ... and against the ORACLE's mirrored-replica step (train.py:75-157: every replica accumulates g/C over its own image, the
+    # optimizer SUMs the replicas' gradients, one Keras-form Adam per net), in the kernels' arithmetic, at the tolerances of
+    # tests/test_gpu_train.py::test_adam_steps_follow_oracle
+    cfg = O.NerfConfig(n_coarse=32, n_fine=32)
+    cp, fp = O.unflatten_params(a["w_start"][:n].copy(), cfg), O.unflatten_params(a["w_start"][n:].copy(), cfg)
+    cp, fp = [p.copy() for p in cp], [p.copy() for p in fp]
+    accs, ref_losses = [], []
+    for rank, z in enumerate((a, b)):
+        m, _, _, acc = O.train_step(cp, fp, None, None, img[rank:rank + 1], z["o"], z["d"], z["t"], u[rank:rank + 1], cfg, 128, True, "zero",
+                                    emulate_bf16=O.FUSED)
+        accs.append(acc); ref_losses.append((float(m["coarse_loss"]), float(m["fine_loss"])))
+    gc = [x + y for x, y in zip(accs[0][0], accs[1][0])]; gf = [x + y for x, y in zip(accs[0][1], accs[1][1])]      # SUM over the replicas
+    O.KerasAdam(cp).apply(cp, gc); O.KerasAdam(fp).apply(fp, gf)
+    for z, (lc, lf) in zip((a, b), ref_losses):
+        assert abs(float(z["coarse_loss"]) - lc) < 3e-3 and abs(float(z["fine_loss"]) - lf) < 3e-3
+    for sl, ref in ((slice(0, n), O.flatten_params(cp)), (slice(n, 2 * n), O.flatten_params(fp))):
+        init, got = a["w_start"][sl], a["w_end"][sl]
+        moved = np.abs(ref - init) > 1e-4
+        agree = np.mean(np.sign(got - init)[moved] == np.sign(ref - init)[moved])
+        log_stats("dp2_adam_vs_oracle", agree=agree, mean_abs_diff=np.abs(got - ref).mean(), mean_abs_move=np.abs(ref - init).mean())
+        assert agree > 0.995
+        assert np.abs(got - ref).mean() < 0.03 * np.abs(ref - init).mean()
 
 
 def test_bench_spawns_its_own_ranks_gloo_rehearsal():

@@ -20,7 +20,9 @@ from tests.test_gpu_train import per_tensor_err
 pytestmark = pytest.mark.gpu
 
 FOV = 0.6911112070083618          # inference.py:27
-GRAD_TOL_EMU, GRAD_TOL_FP32 = 2.5e-2, 8e-2      # of each tensor's max |g|: vs the oracle in kernel arithmetic / in fp32
+# of each tensor's max |g|.  Against the oracle in the kernels' arithmetic (the check of the KERNELS: measured 1.3e-3 ... 1.1e-2, round 2)
+# / against the fp32 oracle (bounded by the precision choice: the oracle's own bf16-vs-fp32 gap on these problems is 5.8e-2 ... 6.9e-2)
+GRAD_TOL_EMU, GRAD_TOL_FP32 = 1.5e-2, 8e-2
 
 
 def problem_weights(cfg=None):
@@ -92,6 +94,41 @@ def test_cfg5_render_256_in_sixteen_chunks_against_oracle():
     np.testing.assert_allclose(fi, rf["image"], atol=1e-2); np.testing.assert_allclose(fw, rf["weights"], atol=1e-2)
     assert np.abs(fi - rf32["image"]).max() < 2e-2                                   # stated tolerance
     assert cw.std() > 1e-3 and fw.std() > 1e-3
+
+
+def test_grouped_wgrad_path_meets_the_oracle():
+    """the grouped coarse weight-gradient launch (knerf_train_batch, G = 2: two chunks' coarse passes in two workspace regions, one
+    launch) against the ORACLE, not only against the ungrouped kernels: 2 chunks of 128 rays, gradients of both nets per tensor"""
+    from keras_nerf_amd.runtime import KnerfContext
+    from keras_nerf_amd.debug import debug_buffer
+    from tests.problem import make_problem
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+    cfg, N, R = P["cfg"], 256, 128
+    o, d, t, u, img = (P[k].reshape(N, -1) for k in ("o", "d", "t", "u", "img"))
+    ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=2))
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    loss = torch.zeros(2, device="cuda")
+    tf_all = torch.empty((N, 192), device="cuda")
+    ctx.zero_grads()
+    ctx.train_batch(o, d, t, img, u, ray_chunks=R, loss=loss)
+    torch.cuda.synchronize()
+    assert ctx.get_option("wgrad_group") == 2.0
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    # reference: mean over the two chunks of the per-chunk gradients (nerf.py:383-384), fine pass on the oracle's own merged
+    # t-values (bit-equal to the kernels' given the same coarse weights; the sampler tests pin that)
+    gc_ref = np.zeros(n, np.float32); gf_ref = np.zeros(n, np.float32); lc = lf = 0.0
+    for c in range(2):
+        sl = slice(c * R, (c + 1) * R)
+        rc, l0, gc = O.chunk_loss_and_grads(P["cp"], o[sl], d[sl], t[sl], img[sl], cfg, True, emulate_bf16=O.FUSED)
+        tf_ = O.fine_points(t[sl], rc["weights"], u[sl], "zero")
+        _, l1, gf = O.chunk_loss_and_grads(P["fp"], o[sl], d[sl], tf_, img[sl], cfg, True, emulate_bf16=O.FUSED)
+        gc_ref += O.flatten_params(gc) / 2; gf_ref += O.flatten_params(gf) / 2; lc += float(l0) / 2; lf += float(l1) / 2
+    ec, ef = per_tensor_err(g[:n], gc_ref, cfg), per_tensor_err(g[n:], gf_ref, cfg)
+    log_stats("grouped_wgrad_vs_oracle", coarse_worst=ec[0], fine_worst=ef[0])
+    assert ec[0] < GRAD_TOL_EMU, ec
+    assert ef[0] < 5e-2, ef            # the fine pass sees the GPU's own coarse weights: a sample may change bins (oob = zero)
+    assert abs(float(loss[0]) - lc) < 2e-3 and abs(float(loss[1]) - lf) < 2e-3
+    ctx.close()
 
 
 def test_cfg2_train_batch_at_bench_size_against_oracle():

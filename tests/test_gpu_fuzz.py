@@ -13,6 +13,43 @@ from tests.test_gpu_train import per_tensor_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("rays_per_chunk,chunks,group_max", [(37, 3, 4), (8, 5, 4), (129, 4, 4), (1, 6, 4), (64, 7, 3), (96, 4, 2)])
+def test_grouped_train_batch_equals_chunk_by_chunk(rays_per_chunk, chunks, group_max):
+    """knerf_train_batch (coarse weight gradients of a GROUP of chunks in one launch over several workspace regions) against the
+    same chunks fed one by one through knerf_train_chunk, on ray counts that are multiples of nothing -- round 2's one-off
+    tools/fuzz_more.py sweep as a test.  Equal up to the order of the fp32 atomics."""
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = O.NerfConfig()
+    P = make_problem(n_images=3, wh=16, seed=5, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    rc, C = rays_per_chunk, chunks
+    R = rc * C
+    o, d, t, img = (torch.as_tensor(P[k].reshape(P["N"], -1)[:R].copy(), device="cuda") for k in ("o", "d", "t", "img"))
+    u = torch.as_tensor(P["u"].reshape(P["N"], -1)[:R].copy(), device="cuda")
+    gs, ls = [], []
+    for mode in ("batch", "chunks"):
+        ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=group_max))
+        ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+        ctx.zero_grads()
+        loss = torch.zeros(2, device="cuda")
+        if mode == "batch":
+            ctx.train_batch(o, d, t, img, u, ray_chunks=rc, loss=loss)
+            g0 = min(group_max, C); n_groups = -(-C // g0)
+            assert ctx.get_option("wgrad_group") == -(-C // n_groups)          # the smallest group that needs no more launches
+        else:
+            for c in range(C):
+                sl = slice(c * rc, (c + 1) * rc)
+                ctx.train_chunk(o[sl].contiguous(), d[sl].contiguous(), t[sl].contiguous(), img[sl].contiguous(), u[sl].contiguous(),
+                                ray_offset=c * rc, inv_chunks=1.0 / C, loss=loss)
+        torch.cuda.synchronize()
+        gs.append(ctx.grads_view().cpu().numpy().copy()); ls.append(loss.cpu().numpy().copy())
+        ctx.close()
+    n = gs[0].size // 2
+    for sl in (slice(0, n), slice(n, 2 * n)):
+        err = np.abs(gs[0][sl] - gs[1][sl]).max() / (np.abs(gs[1][sl]).max() + 1e-30)
+        assert err < 1e-4, err
+    np.testing.assert_allclose(ls[0], ls[1], atol=1e-6)
+
+
 def _cases():
     rng = np.random.default_rng(20261003)
     out = []

@@ -133,3 +133,43 @@ def test_nerf_mlp_checkpoints_are_keras_hdf5_and_old_npz_still_loads(tmp_path):
     bad = tmp_path / "junk.h5"; bad.write_bytes(b"\x00" * 64)
     with pytest.raises(ValueError, match="neither an HDF5 file"):
         m2.load_weights(str(bad))
+
+
+def test_reader_refuses_damaged_files_with_a_format_error(tmp_path):
+    """the reader takes untrusted files: a group that contains itself, truncation and random byte damage must end in
+    Hdf5FormatError (or load, if the damage missed everything that matters) -- never a hang, a RecursionError or a bare IndexError"""
+    src = open(os.path.join(G, "keras_layout_small_earliest.h5"), "rb").read()
+    # (1) a cycle: point the first symbol-table entry of the root group back at the root's own object header
+    r = H.Hdf5Reader(os.path.join(G, "keras_layout_small_earliest.h5"))
+    root = r.root_addr
+    snod = src.index(b"SNOD")
+    cyc = bytearray(src)
+    cyc[snod + 8 + 8:snod + 8 + 16] = int(root).to_bytes(8, "little")
+    p = tmp_path / "cycle.h5"; p.write_bytes(bytes(cyc))
+    with pytest.raises(H.Hdf5FormatError, match="cyclic"):
+        H.Hdf5Reader(str(p))
+    # (2) truncations
+    refused = 0
+    for cut in (9, 100, 600, len(src) // 3, len(src) // 2, len(src) - 7):
+        p = tmp_path / f"cut{cut}.h5"; p.write_bytes(src[:cut])
+        try:
+            H.Hdf5Reader(str(p)).datasets()           # a cut behind the last object may still load
+        except H.Hdf5FormatError:
+            refused += 1
+    assert refused >= 3
+    # (3) random damage in both fixtures (superblock 0 / symbol tables and superblock 2 / compact groups)
+    rng = np.random.default_rng(0)
+    outcomes = {"ok": 0, "refused": 0}
+    for name in ("keras_layout_small_earliest.h5", "keras_layout_small_latest.h5"):
+        data = open(os.path.join(G, name), "rb").read()
+        for trial in range(150):
+            b = bytearray(data)
+            for pos in rng.integers(8, len(b), size=int(rng.integers(1, 6))):
+                b[pos] = int(rng.integers(0, 256))
+            p = tmp_path / "fuzz.h5"; p.write_bytes(bytes(b))
+            try:
+                H.Hdf5Reader(str(p)).datasets()
+                outcomes["ok"] += 1
+            except H.Hdf5FormatError:
+                outcomes["refused"] += 1
+    assert outcomes["ok"] + outcomes["refused"] == 300 and outcomes["refused"] > 0
