@@ -426,15 +426,20 @@ def main():
         comm = {"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
                 "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4}
     # what the six logged metrics add to a step (SURVEY.md 8d reports them separately): the same loop with metrics on, still
-    # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step)
-    for _ in range(2):
-        nerf.train_step(data, sync=False)
-    sync(world)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        nerf.train_step(data, sync=False)
-    sync(world)
-    metrics_ms = (time.perf_counter() - t1) / args.steps * 1e3 - local_elapsed / args.steps * 1e3      # this rank's own two loops
+    # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step), bracketed by the
+    # plain loop before (the timed region above) and once more after it, so that clock drift does not pass for a difference
+    def loop(**kw):
+        for _ in range(2):
+            nerf.train_step(data, **kw)
+        sync(world)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            nerf.train_step(data, **kw)
+        sync(world)
+        return (time.perf_counter() - t1) / args.steps * 1e3
+    with_metrics_ms = loop(sync=False)
+    plain_again_ms = loop(with_metrics=False)
+    metrics_ms = with_metrics_ms - 0.5 * (local_elapsed / args.steps * 1e3 + plain_again_ms)
 
     roofline = None
     if not args.no_profile:

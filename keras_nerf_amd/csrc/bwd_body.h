@@ -58,9 +58,17 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
     if (a.live) {
         // dead-tile skipping (composite.hip tile flags -> compact_tiles): the grid covers every tile, workgroups past the live
         // count leave at once; the last live workgroup's spare waves redo its last tile (identical stores)
-        const int n_live = *a.n_live;
+        const long long n_all = (a.n_samples + kTile - 1) / kTile;
+        const int n_live = *a.n_live < n_all ? *a.n_live : (int)n_all;      // never more entries than the pass has tiles
         if (wg_tile * kWaves >= n_live) return;
         tile = a.live[tile < n_live ? tile : n_live - 1];
+#ifdef KNERF_LIST_GUARD     // diagnostic build: a list entry outside the pass is counted and replaced instead of faulting
+        const long long nt = (a.n_samples + kTile - 1) / kTile;
+        if (tile < 0 || tile >= nt || n_live > nt) {
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 2, 1ull);
+            tile = 0;
+        }
+#endif
     }
     long long g = tile * kTile + col;
     const bool valid = g < a.n_samples;

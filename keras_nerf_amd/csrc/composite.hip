@@ -145,28 +145,41 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     }
 }
 
-// ---- dead-tile skipping: flags -> ascending list of live tiles.  One workgroup; a launch covers at most a few hundred thousand tiles.
+// ---- dead-tile skipping: flags -> ASCENDING list of live tiles and its length.  One workgroup walks the flags in chunks of 1024
+// (eight chunks' loads in flight per thread), ranks the live ones with a ballot per wavefront and a 16-entry prefix through LDS, and
+// keeps the running total in a register: no atomics, nothing to zero beforehand, the same list every time (the deterministic
+// mode's per-workgroup ranges need the order; the default mode gets a launch-independent tile order for free).  ~10 us for the
+// 24,576 tiles of a fine pass.
 __global__ __launch_bounds__(1024) void compact_tiles_kernel(const int* flags, int n, int period, int real, int* list, int* count, long long* stats) {
-    __shared__ int s_cnt[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int i0 = tid * per, i1 = i0 + per < n ? i0 + per : n;
-    auto is_live = [&](int i) { return (i % period) < real && flags[i] != 0; };
-    int c = 0;
-    for (int i = i0; i < i1; ++i) c += is_live(i) ? 1 : 0;
-    s_cnt[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {           // inclusive scan of the per-thread counts
-        const int v = tid >= o ? s_cnt[tid - o] : 0;
-        __syncthreads();
-        s_cnt[tid] += v;
-        __syncthreads();
+    __shared__ int s_wave[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base = 0, par = 0;
+    for (int c0 = 0; c0 < n; c0 += 8 * 1024) {
+        int f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = c0 + k * 1024 + tid;
+            f[k] = (i < n && (i % period) < real) ? flags[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (c0 + k * 1024 >= n) break;                       // uniform
+            const bool live = f[k] != 0;
+            const unsigned long long m = __ballot(live);
+            if (lane == 0) s_wave[par][wv] = __popcll(m);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const int v = s_wave[par][w]; off += w < wv ? v : 0; tot += v; }
+            if (live) list[base + off + __popcll(m & below)] = c0 + k * 1024 + tid;
+            base += tot;
+            par ^= 1;                                            // the other buffer next time: one barrier per chunk is enough
+        }
     }
-    int pos = s_cnt[tid] - c;
-    for (int i = i0; i < i1; ++i) if (is_live(i)) list[pos++] = i;
-    if (tid == 1023) {
-        *count = s_cnt[1023];
-        if (stats) { stats[0] += s_cnt[1023]; stats[1] += (long long)(n / period) * real + ((n % period) < real ? (n % period) : real); }
+    if (tid == 0) {
+        *count = base;
+        if (stats) { stats[0] += base; stats[1] += (long long)(n / period) * real + ((n % period) < real ? (n % period) : real); }
     }
 }
 hipError_t launch_compact_tiles(const int* flags, int n, int period, int real, int* list, int* count, long long* stats, hipStream_t stream) {

@@ -48,6 +48,7 @@ struct BwdArgs {
     int net;                // 0 coarse / 1 fine: kernel instantiation name only
     const int* live;        // dead-tile skipping: ascending list of the pass's live 32-sample tiles and its length (device), or null
     const int* n_live;
+    long long* stats;       // -DKNERF_LIST_GUARD builds only: [2] += list entries outside [0, n_tiles) seen (and clamped) by this kernel
 };
 hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 
@@ -69,6 +70,7 @@ struct WgradArgs {
     float* partial;         // deterministic mode: [n_plan][kWgradPartialStride] per-workgroup sums instead of atomics (zero-filled by the caller), or null
     const int* live;        // dead-tile skipping: ascending list of live tiles (relative to act / dz / mask) and its length (device), or null
     const int* n_live;
+    long long* stats;       // -DKNERF_LIST_GUARD builds only: [3] += list entries outside [0, n_tiles) seen (and clamped) by this kernel
     int by_range;           // list mode: 0 = the live tiles are dealt out evenly over a job's workgroups; 1 = a workgroup takes the live
                             //   tiles inside the range [n_tiles s/ns, n_tiles (s+1)/ns) it would own without skipping (same sums per
                             //   workgroup as the non-skipping launch: the deterministic mode's bit-exactness check)
@@ -80,7 +82,7 @@ size_t wgrad_partial_floats(int n_plan);
 
 // dead-tile skipping: flags[i] (1 = some sample of tile i has a non-zero dL/d(rgb, sigma), written by the compositing kernel) ->
 // ascending list of the live tile indices among i in [0, n) with (i % period) < real, and their count; stats[0] += count,
-// stats[1] += number of real tiles (running totals for knerf_tile_stats), stats may be null
+// stats[1] += number of real tiles (running totals for knerf_tile_stats), stats may be null.  One workgroup; ascending list.
 hipError_t launch_compact_tiles(const int* flags, int n, int period, int real, int* list, int* count, long long* stats, hipStream_t stream);
 // deterministic mode: *loss += partial[0] + partial[1] + ... (fixed order)
 hipError_t launch_loss_reduce(const float* partial, int n, float* loss, hipStream_t stream);

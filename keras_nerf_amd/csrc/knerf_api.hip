@@ -212,9 +212,17 @@ bool skipping(const knerf_ctx* ctx) {
     return ctx->skip_dead && !ctx->generic && ctx->cfg.n_coarse % kTile == 0 && (ctx->cfg.n_coarse + ctx->cfg.n_fine) % kTile == 0;
 }
 
-// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces.  use_list: the
-// tiles are the ctx->tile_count[0] entries of ctx->tile_list (indices relative to tile0; the caller has just compacted them).
-int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, bool use_list) {
+// Compaction of tile flags into ctx->tile_list / ctx->tile_count.  List and counter are rewritten by every compaction; their readers
+// (the dgrad and wgrad launches that follow it) precede the next one on the stream.
+int compact_tiles(knerf_ctx* ctx, hipStream_t s, const int* flags, int n, int period, int real, bool with_stats, int** count) {
+    *count = ctx->tile_count;
+    HIPCHK(launch_compact_tiles(flags, n, period, real, ctx->tile_list, *count, with_stats ? ctx->tile_stats : nullptr, s));
+    return KNERF_OK;
+}
+
+// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces.  live_count: null,
+// or the device counter of the live tiles the caller has just compacted into ctx->tile_list (indices relative to tile0).
+int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, const int* live_count) {
     WgradArgs wa{};
     wa.act = ctx->act + act_tile_off(tile0); wa.dz = ctx->dz + dz_tile_off(tile0); wa.mask = ctx->mask + mask_tile_off(tile0);
     wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
@@ -222,7 +230,8 @@ int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, siz
     wa.n_tiles = (long long)n_tiles;
     wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
     for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
-    if (use_list) { wa.live = ctx->tile_list; wa.n_live = ctx->tile_count; wa.by_range = ctx->deterministic ? 1 : 0; }
+    if (live_count) { wa.live = ctx->tile_list; wa.n_live = live_count; wa.by_range = ctx->deterministic ? 1 : 0; }
+    wa.stats = ctx->tile_stats;
     if (ctx->deterministic) {
         // per-workgroup slabs (zeroed: a workgroup without tiles writes nothing) + the ordered second pass
         if (!ctx->partial || ctx->partial_plan != ctx->tab.n_plan) {
@@ -265,6 +274,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     ca.loss_scale = inv_chunks / (3.0f * (float)R);
     const bool skip = train && skipping(ctx);
     const size_t n_tiles = tiles_for(fa.n_samples);
+    int* live_count = nullptr;
     if (skip) ca.tile_flags = ctx->tile_flags + tile0;
     if (train && ctx->deterministic) ca.loss_partial = ctx->loss_partial;
     {
@@ -272,7 +282,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         HIPCHK(launch_composite(ca, s));
         if (ca.loss_partial) HIPCHK(launch_loss_reduce(ca.loss_partial, (R + 3) / 4, loss, s));
         // the pass's live tiles (indices relative to tile0); the padding tiles behind the last real one count as dead
-        if (skip) HIPCHK(launch_compact_tiles(ca.tile_flags, (int)n_tiles, (int)n_tiles, (int)(fa.n_samples / kTile), ctx->tile_list, ctx->tile_count, ctx->tile_stats, s));
+        if (skip) { if (int r = compact_tiles(ctx, s, ca.tile_flags, (int)n_tiles, (int)n_tiles, (int)(fa.n_samples / kTile), true, &live_count)) return r; }
     }
     if (train && ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
@@ -281,9 +291,10 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + dz_tile_off(tile0);
         ba.n_samples = fa.n_samples; ba.net = fa.net;
-        if (skip) { ba.live = ctx->tile_list; ba.n_live = ctx->tile_count; }
+        if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; }
+        ba.stats = ctx->tile_stats;
         { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
-        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, skip)) return r; }
+        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, live_count)) return r; }
     }
     return KNERF_OK;
 }
@@ -407,10 +418,10 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (int r = upload_plan(ctx)) { std::string m_ = ctx->err; knerf_destroy(ctx); return fail(nullptr, r, m_); }
-    CREATECHK(hipMalloc(&ctx->tile_count, 2 * sizeof(int)));
-    CREATECHK(hipMemset(ctx->tile_count, 0, 2 * sizeof(int)));
-    CREATECHK(hipMalloc(&ctx->tile_stats, 2 * sizeof(long long)));
-    CREATECHK(hipMemset(ctx->tile_stats, 0, 2 * sizeof(long long)));
+    CREATECHK(hipMalloc(&ctx->tile_count, sizeof(int)));
+    CREATECHK(hipMemset(ctx->tile_count, 0, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->tile_stats, 4 * sizeof(long long)));       // [2], [3]: out-of-range list entries (diagnostic builds)
+    CREATECHK(hipMemset(ctx->tile_stats, 0, 4 * sizeof(long long)));
     CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * NP * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->aux, 2 * (size_t)kAuxCount * sizeof(float)));
@@ -635,9 +646,9 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
                                      f_image ? f_image + r0 * 3 : nullptr, slot, G))
             return r;
         if (G > 1 && last) {                                        // the group's coarse weight gradients in one launch
-            const bool skip = skipping(ctx);
-            if (skip) HIPCHK(launch_compact_tiles(ctx->tile_flags, (int)((slot + 1) * tc), (int)tc, ray_chunks * Nc / kTile, ctx->tile_list, ctx->tile_count, nullptr, s));
-            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, skip)) return r;
+            int* live_count = nullptr;
+            if (skipping(ctx)) { if (int r = compact_tiles(ctx, s, ctx->tile_flags, (int)((slot + 1) * tc), (int)tc, ray_chunks * Nc / kTile, false, &live_count)) return r; }
+            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, live_count)) return r;
         }
     }
     return expand_head_grads(ctx, s);
@@ -727,11 +738,13 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
 
 int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset) {
     if (!ctx || !live || !total) return KNERF_ERR_INVALID;
-    long long h[2] = {0, 0};
+    long long h[4] = {0, 0, 0, 0};
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(h, ctx->tile_stats, sizeof(h), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(ctx->tile_stats, 0, sizeof(h)));
     *live = h[0]; *total = h[1];
+    if (h[2] || h[3])      // only a -DKNERF_LIST_GUARD build counts these
+        return fail(ctx, KNERF_ERR_HIP, "tile list held " + std::to_string(h[2]) + " (dgrad) / " + std::to_string(h[3]) + " (wgrad) entries outside their pass");
     return KNERF_OK;
 }
 

@@ -134,8 +134,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     if (SAVE) {
         act = a.act + act_tile_off((size_t)tile);
         maskp = a.mask + mask_tile_off((size_t)tile);
+#ifndef KNERF_ABLATE_ENC_IO      // timing experiment only (with -DKNERF_CONSERVATIVE_WAIT): the upper bound of re-deriving the encodings in wgrad
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_block(act, kActEnc + q, lane, enc[q]);
+#endif
     }
 
     ring.prologue_wait();
@@ -196,10 +198,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).
     bf16x8 dirc[2];
     encode<kLd, 2>(dx, dy, dz, h, dirc);
+#ifndef KNERF_ABLATE_ENC_IO
     if (SAVE) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
     }
+#endif
     dense_stage<960, 18, 1, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(64), [&](int ks) { return ks < 16 ? y[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
                             [&](int, f32x16 acc) {
                                 if (valid && h == 0) {

@@ -27,12 +27,16 @@ __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
         const ContigSeq seq{(int)(a.n_tiles * pl.split / pl.nsplit), (int)(a.n_tiles * (pl.split + 1) / pl.nsplit)};
         wgrad_dispatch(a, pl.job, seq, smem);
     } else {
-        const int n = *a.n_live;
+        // plain loads, before any LDS-DMA copy is in flight (hipcc waits for them with its own vmcnt)
+        int n = __builtin_amdgcn_readfirstlane(*a.n_live);
+        if (n > a.n_tiles) n = (int)a.n_tiles;                  // never more entries than the launch has tiles
+        if (n < 0) n = 0;
         ListSeq seq{a.live, (int)((long long)n * pl.split / pl.nsplit), (int)((long long)n * (pl.split + 1) / pl.nsplit)};
         if (a.by_range) {
             seq.i0 = list_lower_bound(a.live, n, (int)(a.n_tiles * pl.split / pl.nsplit));
             seq.i1 = list_lower_bound(a.live, n, (int)(a.n_tiles * (pl.split + 1) / pl.nsplit));
         }
+        seq.i0 = __builtin_amdgcn_readfirstlane(seq.i0); seq.i1 = __builtin_amdgcn_readfirstlane(seq.i1);
         wgrad_dispatch(a, pl.job, seq, smem);
     }
 #ifdef KNERF_WGRAD_STAMPS

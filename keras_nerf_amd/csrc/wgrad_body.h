@@ -117,18 +117,56 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* region, int pair, int kk, 
 
 // The job body walks a contiguous range [t0, t1) of sample tiles ...
 struct ContigSeq {
+    static constexpr bool kIsList = false;
     int t0, t1;
     __device__ __forceinline__ int count() const { return t1 - t0; }
     __device__ __forceinline__ int tile(int i) const { return t0 + i; }
 };
-// ... or entries [i0, i1) of the ascending list of LIVE tiles (dead-tile skipping: composite.hip flags -> compact_tiles); the index
-// is wave-uniform, so the look-up is a scalar load, requested at the top of an iteration and used by the copies in its middle
+// ... or entries [i0, i1) of the list of LIVE tiles (dead-tile skipping: composite.hip flags -> compact_tiles).  The index is
+// wave-uniform, so the look-up is a SCALAR load -- written as inline asm, because hipcc would make it a vector load here (it cannot
+// prove the list read-only next to the kernel's atomics and asm copies), and a compiler-visible VMEM load inside the hand-counted
+// vmcnt pipeline makes it drain vmcnt(0) every tile.  SMEM shares lgkmcnt with LDS, so load and wait sit in ONE asm statement at a
+// point where no LDS read is pending: tile_sync (prologue), and tile_wait below, which wraps an iteration's own vmcnt wait and
+// barrier so that the look-up's latency hides behind them.
 struct ListSeq {
+    static constexpr bool kIsList = true;
     const int* list;
     int i0, i1;
     __device__ __forceinline__ int count() const { return i1 - i0; }
-    __device__ __forceinline__ int tile(int i) const { return list[i0 + i]; }
+    __device__ __forceinline__ unsigned long long addr(int i) const {
+        const unsigned long long p = (unsigned long long)(list + i0 + i);
+        // NB the builtin returns int: without the casts the low half is SIGN-extended into the high one (a list above a 2 GiB
+        // boundary then faults at 0xffffffff........ -- r03, found the hard way)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+        return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    }
+    __device__ __forceinline__ int tile(int i) const {          // load and wait: for places outside the pipelined loop
+        int t;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(addr(i)) : "memory");
+        return t;
+    }
 };
+
+// Top of a pipelined iteration: wait until at most VM of this wave's LDS-DMA copies are in flight (and, with LGKM0, for its own LDS
+// writes), take the workgroup barrier, and return the tile that this iteration stages (entry `idx` of the sequence).
+template <int VM, bool LGKM0, class Seq>
+__device__ __forceinline__ int wait_barrier_next(const Seq& seq, int idx) {
+    if constexpr (Seq::kIsList) {
+        int t;
+        if constexpr (LGKM0)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt vmcnt(%2)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(t) : "s"(seq.addr(idx)), "n"(VM) : "memory");
+        else
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt vmcnt(%2)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(t) : "s"(seq.addr(idx)), "n"(VM) : "memory");
+        return t;
+    } else {
+        if constexpr (LGKM0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        __builtin_amdgcn_s_barrier();
+        return seq.tile(idx);
+    }
+}
 
 template <int NI, int NO, class Seq>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
@@ -173,6 +211,9 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
     // stage sample tile t into `slot`
     auto issue = [&](int t, int slot, bool late = false) {
+#ifdef KNERF_LIST_GUARD     // diagnostic build: a list entry outside the launch is counted and replaced instead of faulting
+        if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
+#endif
         const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_blk * kSavedBlockStride + lane * 16;
         const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)dz_blk * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
@@ -180,7 +221,14 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
+#ifdef KNERF_ABLATE_ENC_IO     // timing experiment only: the enc / dir blocks come from tile 0 (L2 hits) -- what wgrad would gain if it re-derived them for free
+            const int blk = act_blk + (ok ? b : 0);
+            const bool is_enc = (blk >= kActEnc && blk < kActEnc + 4) || blk >= kActDir;
+            const char* base = is_enc ? a.act + (size_t)act_blk * kSavedBlockStride + lane * 16 : src_in;
+            glds16(base + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
+#else
             glds16(src_in + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
+#endif
         }
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
@@ -204,11 +252,10 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0;
 #endif
     for (int i = 0; i < cnt; ++i) {
-        const int t_next = tile_at(i + NS - 1);        // the tile this iteration stages (list mode: a scalar load, used mid-iteration)
         STAMP(s0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");   // tile i landed (mine) ...
+        // tile i landed (mine) ... everyone's (barrier); tile i-1 is free; t_next = the tile this iteration stages
+        const int t_next = wait_barrier_next<G * (NS - 2), false>(seq, i + NS - 1 < cnt ? i + NS - 1 : cnt - 1);
         STAMP(s1);
-        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
         STAMP(s2);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
 #ifdef KNERF_WGRAD_EARLY_ISSUE     // A/B knob: the older order (copies issued right behind the barrier)
@@ -336,7 +383,14 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
     }
     auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
     auto issue = [&](int t, int slot, bool late = false) {
+#ifdef KNERF_LIST_GUARD
+        if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
+#endif
+#ifdef KNERF_ABLATE_ENC_IO
+        const char* src_in = a.act + (size_t)kActEnc * kSavedBlockStride + lane * 16;
+#else
         const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)kActEnc * kSavedBlockStride + lane * 16;
+#endif
         const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)16 * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
         const bool ok = wave < BLK_IN;
@@ -381,10 +435,9 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
     // One barrier per tile: iteration i consumes tile i (its h0 fragments were written during iteration i-1) and recomputes
     // h0 of tile i+1 into the other half of the exchange buffer, so tile i+1 must have landed too (one tile less in flight).
     for (int i = 0; i < cnt; ++i) {
-        const int t_next = tile_at(i + NS - 1);
         // tiles <= i+1 landed (mine) and my h0 fragments of tile i are written (lgkmcnt: the ds_writes of the recompute) ...
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 3)) : "memory");
-        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 and h0(i-1) are free
+        // ... everyone's (barrier); tile i-1 and h0(i-1) are free
+        const int t_next = wait_barrier_next<G * (NS - 3), true>(seq, i + NS - 1 < cnt ? i + NS - 1 : cnt - 1);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
         const char* dz_reg = smem + slot * TILE_BYTES + BLK_IN * 1024;
         const char* xr = xch + (int)(i & 1) * (kXch / 2);
@@ -462,6 +515,9 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq
     static_assert((kDzHead & 1) == 0, "dz_head block parity");
     auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
     auto issue = [&](int t, int slot, bool late = false) {
+#ifdef KNERF_LIST_GUARD
+        if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
+#endif
         const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_h(6) * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
@@ -510,9 +566,8 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq
     }
     int slot = 0;
     for (int i = 0; i < cnt; ++i) {
-        const int t_next = tile_at(i + NS - 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 3)) : "memory");   // tile i+1 landed (mine) ...
-        __builtin_amdgcn_s_barrier();                                          // ... everyone's; tile i-1 is free
+        // tile i+1 landed (mine) ... everyone's (barrier); tile i-1 is free
+        const int t_next = wait_barrier_next<G * (NS - 3), false>(seq, i + NS - 1 < cnt ? i + NS - 1 : cnt - 1);
         int nslot = slot + NS - 1; if (nslot >= NS) nslot -= NS;
         const char* in_reg = smem + slot * TILE_BYTES;
         slot = slot + 1 == NS ? 0 : slot + 1;

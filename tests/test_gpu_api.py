@@ -57,6 +57,7 @@ def test_train_step_logs_and_metrics(model):
     assert -1.0 <= logs["fine_ssim"] <= 1.0
     assert [m.name for m in nerf.metrics] == ["coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim"]
     assert np.abs(nerf.coarse.get_flat_weights() - before).max() > 0
+    nerf.reset_metrics()                   # Keras resets the running means between the training and the validation pass of an epoch
     v = nerf.test_step((P["img"], (P["o"], P["d"], P["t"])), u=P["u"])
     # test_step's two losses are whole-image mean squared errors of the rendered images (nerf.py:484-487): against the oracle's
     # render of the same weights (kernel arithmetic) and against the images this model returns for the same rays and u

@@ -102,12 +102,12 @@ def _train_procedural(steps, wh=32, batch=2, chunk=1024):
 _TRAINED = {}
 
 
-@pytest.mark.parametrize("sigma_bias_shift,min_dead", [(0.0, 0.005), (0.5, 0.15)])
+@pytest.mark.parametrize("sigma_bias_shift,min_dead", [(0.0, 0.005), (0.5, 0.05), (3.0, 0.12)])
 def test_dead_tile_skipping_is_exact_on_a_trained_scene(sigma_bias_shift, min_dead):
     """the checkpoint as trained (a few per cent of the tiles are dead after 300 small steps; tools/convergence128.py --skip-dead
-    measures the fraction over a real run, profiles/), and the same checkpoint with the sigma bias of both nets lowered by 0.5,
-    which empties the low-density regions the way longer training does -- the heavy-skipping paths (workgroups with few or no
-    tiles, unbalanced ranges) with the real weights' structure"""
+    measures the fraction over a real run, profiles/), and the same checkpoint with the sigma bias of both nets lowered by 0.5 and
+    by 3, which empties the low-density regions -- the heavier-skipping paths (workgroups with few or no tiles, unbalanced ranges)
+    with the real weights' structure (measured r03: 2.3 % / 9.0 % dead for shifts 0 / 0.5)"""
     from keras_nerf_amd.runtime import KnerfContext
     wh, batch, chunk = 32, 2, 512          # 4 chunks: grouped coarse launches too
     if not _TRAINED:

@@ -14,6 +14,8 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=6)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--save-grads", default=None, help="write the gradient of one train chunk (fixed inputs and Philox seed) to this .npy")
+ap.add_argument("--check-grads", default=None, help="compare that gradient with a saved one (A/B builds must compute the same thing)")
 ap.add_argument("--shape", default="8,256,4,10,4", help="n_layers,dense_units,skip_layer,pos_emb_xyz,pos_emb_dir (non-default: general-shape path)")
 args = ap.parse_args()
 if args.lib:
@@ -33,7 +35,7 @@ wh = 128
 o, d, t = ctx.generate_rays(pose_spherical(20.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, 64, None, seed=1)
 R = args.rays
 o, d, t = o.reshape(-1, 3)[:R].contiguous(), d.reshape(-1, 3)[:R].contiguous(), t.reshape(-1, 64)[:R].contiguous()
-tgt = torch.rand((R, 3), device="cuda")
+tgt = torch.rand((R, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
 loss = torch.zeros(2, device="cuda")
 TRUNK = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256       # executed MACs per sample: trunk + the composed 283x4 head
 FWD, DG, WG = 2 * (TRUNK + 283 * 4), 2 * (256 * 4 + 7 * 256 * 256), 2 * (TRUNK + 283 * 4)
@@ -55,6 +57,19 @@ for _ in range(args.iters):
 pt = ctx.profile_read()
 for k, v in pt.items():
     res["train_" + k] = v
+if args.save_grads or args.check_grads:
+    ctx.zero_grads(); loss.zero_()
+    ctx.train_chunk(o, d, t, tgt, None, seed=1, loss=loss)
+    torch.cuda.synchronize()
+    g = ctx.grads_view().cpu().numpy().copy()
+    if args.save_grads:
+        np.save(args.save_grads, g)
+    if args.check_grads:
+        ref = np.load(args.check_grads)
+        n = g.size // 2
+        errs = [float(np.abs(g[s] - ref[s]).max() / np.abs(ref[s]).max()) for s in (slice(0, n), slice(n, 2 * n))]
+        print(json.dumps({"tag": args.tag, "grad_check_rel_err": errs, "ok": max(errs) < 1e-4}))
+        assert max(errs) < 1e-4, errs
 ctx.apply_adam()
 if hasattr(ctx.lib, "knerf_debug_wgrad_stamps"):
     import ctypes as C
