@@ -278,7 +278,10 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
 
     class Clock:
         def on_epoch_begin(self, epoch, logs=None):
-            torch.cuda.synchronize(); marks.append(["begin", time.perf_counter()])
+            torch.cuda.synchronize()
+            if epoch == 1:
+                nerf._ctx.tile_stats(reset=True)      # dead-tile share of the timed epochs only
+            marks.append(["begin", time.perf_counter()])
 
         def on_test_begin(self, logs=None):          # fit has read the epoch's logs back: the train loop is over and the GPU drained
             marks.append(["train_end", time.perf_counter()])
@@ -294,8 +297,11 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     wall = t["end"][-1] - t["begin"][1]
     per_step = wh * wh * batch * 256
     value = world * per_step * steps * args.epochs / loop
-    # the default mode's loop in the same process on the same device: one resident batch, no metrics
-    data = make_batch(nerf, wh, batch, rank)
+    live, total = nerf._ctx.tile_stats(reset=True)          # over the timed epochs (reset when they began, see Clock)
+    dead_fit = 1.0 - live / max(total, 1) if total else None
+    # the plain train_step loop in the same process, on ONE RESIDENT BATCH OF THE SAME DATASET (with the weights as fit left
+    # them, so that the backward has the same share of exactly-dead tiles to skip as the epochs above): no loader, no metrics
+    data = next(iter(train))
     for _ in range(3):
         nerf.train_step(data, with_metrics=False)
     sync(world); t0 = time.perf_counter()
@@ -308,6 +314,8 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     for _ in range(20):
         nerf.train_step(data, sync=False)
     sync(world); tm = (time.perf_counter() - t0) / 20
+    live, total = nerf._ctx.tile_stats(reset=True)
+    dead_loop = 1.0 - live / max(total, 1) if total else None
     if rank == 0:
         print(json.dumps({"metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
                           "unit": "rays*samples/s", "n_gpus": world, "steps": steps * args.epochs, "warmup": steps, "ms_per_step": loop / (steps * args.epochs) * 1e3,
@@ -316,6 +324,8 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                                                  f"{steps} steps per epoch, {args.epochs} timed epochs after one warm-up epoch", "parallelism": f"dp{world}"},
                           "train_step_ms": ts * 1e3, "train_step_with_metrics_ms": tm * 1e3, "metrics_ms_per_step": (tm - ts) * 1e3,
                           "fit_vs_train_step": (loop / (steps * args.epochs)) and ts / (loop / (steps * args.epochs)),
+                          "dead_tile_frac_fit_epochs": dead_fit, "dead_tile_frac_train_step_loop": dead_loop,
+                          "options": {k: bool(nerf._ctx.get_option(k)) for k in ("skip_dead_tiles", "deterministic")},
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
                           "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
@@ -352,6 +362,7 @@ def main():
                                                                             "fit: NeRF.fit through the loader, the metrics and the monitor")
     ap.add_argument("--epochs", type=int, default=2, help="--mode fit: timed epochs")
     ap.add_argument("--skip-dead-tiles", type=int, default=None, help="override the library default of the skip_dead_tiles option (0/1)")
+    ap.add_argument("--deterministic", type=int, default=None, help="set the deterministic option (0/1): gradient sums without atomics")
     args = ap.parse_args()
 
     # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
@@ -401,6 +412,8 @@ def main():
                  white_background=True)
     if args.skip_dead_tiles is not None:
         nerf._ctx.set_option("skip_dead_tiles", args.skip_dead_tiles)
+    if args.deterministic is not None:
+        nerf._ctx.set_option("deterministic", args.deterministic)
     data = make_batch(nerf, wh, batch, rank)
     n_rays = batch * wh * wh
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
@@ -492,6 +505,21 @@ def main():
         roofline["step_algorithmic_gbytes"] = step_bytes / 1e9
         roofline["step_frac_of_hbm_peak"] = step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
 
+    # how much of this workload's backward is exactly-zero work (skip_dead_tiles): one extra step with the option
+    # on, OUTSIDE every timed region.  Random initial weights: ~0 (sigma is positive almost everywhere), i.e. the line above is
+    # not a measurement of skipped work.
+    opts = {k: bool(nerf._ctx.get_option(k)) for k in ("skip_dead_tiles", "deterministic")}
+    dead_frac = None
+    if nerf._ctx.get_option("general_shape_path") == 0:
+        nerf._ctx.set_option("skip_dead_tiles", 1)
+        if nerf._ctx.get_option("skip_dead_tiles_active"):
+            nerf._ctx.tile_stats(reset=True)
+            nerf.train_step(data, with_metrics=False)
+            live, total = nerf._ctx.tile_stats(reset=True)
+            dead_frac = 1.0 - live / max(total, 1)
+        nerf._ctx.set_option("skip_dead_tiles", int(opts["skip_dead_tiles"]))
+    sync(world)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -506,7 +534,7 @@ def main():
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
             "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
-            "metrics_ms_per_step": metrics_ms, **comm,
+            "metrics_ms_per_step": metrics_ms, "options": opts, "dead_tile_frac": dead_frac, **comm,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

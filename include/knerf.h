@@ -126,7 +126,7 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *   "deterministic"     0/1  weight gradients and losses without floating-point atomics: every workgroup writes its partial sums
  *                            to its own slab and an ordered second pass adds them, so two runs of the same step are bit-identical
  *                            (slower; the reference's TF ops give no such guarantee either -- this is a test/diagnosis mode).
- *   "skip_dead_tiles"   0/1  the backward kernels skip every 32-sample tile whose dL/d(rgb, sigma) is EXACTLY zero for all samples
+ *   "skip_dead_tiles"   0/1  (default 1) the backward kernels skip every 32-sample tile whose dL/d(rgb, sigma) is EXACTLY zero for all samples
  *                            (empty space with a closed ReLU gate on sigma, rays whose pixel error is exactly 0): such samples add
  *                            exactly nothing to any of the 48 gradient tensors (utils.py:36-45, mlp.py:40), so the result is the
  *                            same; applies to the default MLP shape when n_coarse and n_coarse + n_fine are multiples of 32.

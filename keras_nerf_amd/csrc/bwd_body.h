@@ -60,6 +60,10 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
         // count leave at once; the last live workgroup's spare waves redo its last tile (identical stores)
         const long long n_all = (a.n_samples + kTile - 1) / kTile;
         const int n_live = *a.n_live < n_all ? *a.n_live : (int)n_all;      // never more entries than the pass has tiles
+        if (a.stats && wg_tile == 0 && tid == 0) {                            // running totals for knerf_tile_stats
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats), (unsigned long long)n_live);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 1, (unsigned long long)(a.n_samples / kTile));
+        }
         if (wg_tile * kWaves >= n_live) return;
         tile = a.live[tile < n_live ? tile : n_live - 1];
 #ifdef KNERF_LIST_GUARD     // diagnostic build: a list entry outside the pass is counted and replaced instead of faulting

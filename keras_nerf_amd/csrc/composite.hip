@@ -23,12 +23,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int C>
 __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     __shared__ float s_loss[4];
+    __shared__ int s_cnt[4], s_base[2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     const bool training = a.draw != nullptr;
-    if (training && lane == 0) s_loss[wv] = 0.f;
-    if (ray >= a.R) {         // whole wave leaves together; in training it still joins the block's loss reduction
-        if (training) { __syncthreads(); }
+    if (training && lane == 0) { s_loss[wv] = 0.f; s_cnt[wv] = 0; }
+    if (ray >= a.R) {         // whole wave leaves together; in training it still joins the block's loss reduction and list append
+        if (training) { __syncthreads(); if (a.tile_list) { __syncthreads(); __syncthreads(); } }
         return;
     }
     const int S = a.S;
@@ -137,11 +138,32 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
             if (!dead) live |= 1u << (i >> 5);
         }
     }
-    if (a.tile_flags) {            // S % 32 == 0 (checked by the caller): tiles do not straddle rays, S / 32 <= 16 of them per ray
+    if (a.tile_flags || a.tile_list) {      // S % 32 == 0 (checked by the caller): tiles do not straddle rays, S / 32 <= 16 of them per ray
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) live |= __shfl_xor(live, o, 64);
-        const int nt = S >> 5;
-        if (lane < nt) a.tile_flags[(size_t)ray * nt + lane] = (live >> lane) & 1u;
+    }
+    const int nt = S >> 5;
+    if (a.tile_flags && lane < nt) a.tile_flags[(size_t)ray * nt + lane] = (live >> lane) & 1u;     // deterministic mode: compact_tiles_kernel sorts them
+    if (a.tile_list) {
+        // default mode: the live tiles are appended to the pass's list right here (no compaction launch): the block's four rays
+        // reserve their entries with ONE atomic on the pass's counter (zeroed by the caller), the list comes out in block order,
+        // i.e. nearly ascending.  A coarse pass of a grouped launch appends to the group's list (indices + tile_off2) as well.
+        if (lane == 0) s_cnt[wv] = __popc(live);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+            s_base[0] = tot ? atomicAdd(a.tile_count, tot) : 0;
+            s_base[1] = (tot && a.tile_list2) ? atomicAdd(a.tile_count2, tot) : 0;
+        }
+        __syncthreads();
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) off += k < wv ? s_cnt[k] : 0;
+        if (lane < nt && ((live >> lane) & 1u)) {
+            const int r = off + __popc(live & ((1u << lane) - 1u)), id = ray * nt + lane;
+            a.tile_list[s_base[0] + r] = id;
+            if (a.tile_list2) a.tile_list2[s_base[1] + r] = id + a.tile_off2;
+        }
     }
 }
 

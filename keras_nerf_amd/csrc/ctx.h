@@ -75,7 +75,7 @@ struct knerf_ctx {
     float* call_raw = nullptr;
     // run-time options (knerf_set_option)
     bool deterministic = false;         // per-workgroup partial sums + ordered second pass instead of fp32 atomics (wgrad, loss)
-    bool skip_dead = false;             // dgrad / wgrad skip 32-sample tiles whose dL/d(rgb, sigma) is exactly zero
+    bool skip_dead = true;              // dgrad / wgrad skip 32-sample tiles whose dL/d(rgb, sigma) is exactly zero (exact; +0.3 % when nothing is dead)
     int wgrad_group_max = 4;            // chunks per coarse weight-gradient launch of knerf_train_batch (1 = one launch per chunk)
     double wgrad_group_gb = 40.0;       // memory budget of those grouped workspaces
     int wgrad_cost[knerf::kWgradJobs] = {128, 264, 204, 204, 204, 267, 204, 240, 193};   // workgroups per job ~ cost (build_wgrad_plan)
@@ -92,7 +92,11 @@ struct knerf_ctx {
     size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
     // dead-tile skipping: per-tile flags of the training workspaces (composite.hip), the compacted list and its length, running
     // totals (live, all) of the tiles seen by the dgrad launches
-    int *tile_flags = nullptr, *tile_list = nullptr, *tile_count = nullptr;
+    int *tile_flags = nullptr, *tile_list = nullptr, *tile_list_g = nullptr, *tile_count = nullptr;   // tile_list_g: the list of a group of coarse passes
+    // tile_count: a ring of counters, one per list; the whole ring is zeroed by ONE memset when a call takes its first counter (and
+    // again should a call need more than the ring holds: its earlier consumers are already enqueued, the stream orders the memset)
+    static constexpr int kTileCounters = 4096;
+    int tile_counter_next = 0;
     long long* tile_stats = nullptr;
     size_t ws_tiles = 0;
     // deterministic mode: per-workgroup weight-gradient slabs, per-workgroup loss terms, plan offsets of the jobs

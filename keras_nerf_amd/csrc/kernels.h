@@ -48,7 +48,8 @@ struct BwdArgs {
     int net;                // 0 coarse / 1 fine: kernel instantiation name only
     const int* live;        // dead-tile skipping: ascending list of the pass's live 32-sample tiles and its length (device), or null
     const int* n_live;
-    long long* stats;       // -DKNERF_LIST_GUARD builds only: [2] += list entries outside [0, n_tiles) seen (and clamped) by this kernel
+    long long* stats;       // list mode: [0] += live tiles, [1] += tiles of the pass (knerf_tile_stats); -DKNERF_LIST_GUARD builds: [2] +=
+                            //   list entries outside [0, n_tiles) seen (and clamped) by this kernel
 };
 hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 
@@ -101,6 +102,11 @@ struct CompositeArgs {
     float grad_scale;       // 2 / (3R) * inv_chunks  -> dL/dimage = grad_scale * (image - target)
     float loss_scale;       // inv_chunks / (3R)
     int* tile_flags;        // training, S % 32 == 0 only: [R*S/32] 1 = the 32-sample tile has a sample with non-zero draw, 0 = dead; or null
+    int* tile_list;         // or (default mode) the live tiles appended to this list, their number added to *tile_count (zero on entry); and,
+    int* tile_count;        //   for a coarse pass of a grouped weight-gradient launch, also to tile_list2 / tile_count2 as index + tile_off2
+    int* tile_list2;
+    int* tile_count2;
+    int tile_off2;
     float* loss_partial;    // deterministic mode: per-workgroup loss terms [ceil(R/4)] instead of one atomic per workgroup; or null
 };
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream);

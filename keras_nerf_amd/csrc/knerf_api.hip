@@ -163,7 +163,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         const int R = n_rays > ctx->ws_train_rays ? n_rays : ctx->ws_train_rays;
         if (group < ctx->ws_group && n_rays <= ctx->ws_train_rays) group = ctx->ws_group;   // a larger chunk size starts from the group asked for: group x size is what costs memory
         free_dev(ctx->draw); free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
-        free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->loss_partial);
+        free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->tile_list_g); free_dev(ctx->loss_partial);
         ctx->ws_train = false; ctx->ws_train_rays = 0; ctx->ws_group = 1; ctx->group_cache = 0;
         const size_t ns = (size_t)R * Na;
         // group 1: the coarse and the fine pass of a chunk share one region (each pass's weight gradients follow it at once)
@@ -179,6 +179,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         HIPCHK(hipMalloc(&ctx->tile_flags, tiles * sizeof(int)));
         HIPCHK(hipMemsetAsync(ctx->tile_flags, 0, tiles * sizeof(int), s));
         HIPCHK(hipMalloc(&ctx->tile_list, tiles * sizeof(int)));
+        if (group > 1) HIPCHK(hipMalloc(&ctx->tile_list_g, (size_t)group * tiles_for((long long)R * ctx->cfg.n_coarse) * sizeof(int)));
         HIPCHK(hipMalloc(&ctx->loss_partial, ((size_t)R + 3) / 4 * sizeof(float)));
         ctx->ws_tiles = tiles;
         ctx->ws_train = true; ctx->ws_train_rays = R; ctx->ws_group = group;
@@ -212,17 +213,25 @@ bool skipping(const knerf_ctx* ctx) {
     return ctx->skip_dead && !ctx->generic && ctx->cfg.n_coarse % kTile == 0 && (ctx->cfg.n_coarse + ctx->cfg.n_fine) % kTile == 0;
 }
 
-// Compaction of tile flags into ctx->tile_list / ctx->tile_count.  List and counter are rewritten by every compaction; their readers
-// (the dgrad and wgrad launches that follow it) precede the next one on the stream.
-int compact_tiles(knerf_ctx* ctx, hipStream_t s, const int* flags, int n, int period, int real, bool with_stats, int** count) {
-    *count = ctx->tile_count;
-    HIPCHK(launch_compact_tiles(flags, n, period, real, ctx->tile_list, *count, with_stats ? ctx->tile_stats : nullptr, s));
+// A fresh (zero) counter for one list of live tiles.  The ring is zeroed by one memset when a call takes its first counter, and again
+// if a call runs through the whole ring (the consumers of its earlier counters are enqueued by then; the stream orders the memset).
+int next_tile_counter(knerf_ctx* ctx, hipStream_t s, int** count) {
+    if (ctx->tile_counter_next >= knerf_ctx::kTileCounters) ctx->tile_counter_next = 0;
+    if (ctx->tile_counter_next == 0) HIPCHK(hipMemsetAsync(ctx->tile_count, 0, knerf_ctx::kTileCounters * sizeof(int), s));
+    *count = ctx->tile_count + ctx->tile_counter_next++;
     return KNERF_OK;
 }
 
-// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces.  live_count: null,
-// or the device counter of the live tiles the caller has just compacted into ctx->tile_list (indices relative to tile0).
-int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, const int* live_count) {
+// Deterministic mode: tile flags -> ASCENDING list (its per-workgroup ranges need the order) by the one-workgroup compaction kernel.
+int compact_tiles(knerf_ctx* ctx, hipStream_t s, const int* flags, int n, int period, int real, int* list, int** count) {
+    if (int r = next_tile_counter(ctx, s, count)) return r;
+    HIPCHK(launch_compact_tiles(flags, n, period, real, list, *count, nullptr, s));
+    return KNERF_OK;
+}
+
+// weight gradients of `net` over n_tiles sample tiles starting at tile `tile0` of the act / mask / dz workspaces.  live: null, or the
+// list of live tiles (indices relative to tile0) with its device counter.
+int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, const int* live, const int* live_count) {
     WgradArgs wa{};
     wa.act = ctx->act + act_tile_off(tile0); wa.dz = ctx->dz + dz_tile_off(tile0); wa.mask = ctx->mask + mask_tile_off(tile0);
     wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
@@ -230,7 +239,7 @@ int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, siz
     wa.n_tiles = (long long)n_tiles;
     wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
     for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
-    if (live_count) { wa.live = ctx->tile_list; wa.n_live = live_count; wa.by_range = ctx->deterministic ? 1 : 0; }
+    if (live) { wa.live = live; wa.n_live = live_count; wa.by_range = ctx->deterministic ? 1 : 0; }
     wa.stats = ctx->tile_stats;
     if (ctx->deterministic) {
         // per-workgroup slabs (zeroed: a workgroup without tiles writes nothing) + the ordered second pass
@@ -251,9 +260,11 @@ int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, siz
 
 // tile0: first tile of this pass in the training workspaces; wgrad_now: launch the weight-gradient kernel for just this pass
 // (false: the caller launches it later over several passes, launch_wgrad_tiles)
+// group_count: (default-mode skipping, coarse pass of a grouped launch) the group's counter: the pass's live tiles are appended to
+// ctx->tile_list_g as well, as indices relative to the group's first region (+ tile0)
 int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float* d, const float* t, int R, int S,
              float* image, float* depth, float* weights, const float* target, float inv_chunks, float* loss,
-             size_t tile0 = 0, bool wgrad_now = true) {
+             size_t tile0 = 0, bool wgrad_now = true, int* group_count = nullptr) {
     const bool train = target != nullptr;
     FwdArgs fa{};
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
@@ -275,14 +286,21 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     const bool skip = train && skipping(ctx);
     const size_t n_tiles = tiles_for(fa.n_samples);
     int* live_count = nullptr;
-    if (skip) ca.tile_flags = ctx->tile_flags + tile0;
+    if (skip && ctx->deterministic) {
+        ca.tile_flags = ctx->tile_flags + tile0;                     // flags now, an ascending list from the compaction kernel below
+    } else if (skip) {
+        if (int r = next_tile_counter(ctx, s, &live_count)) return r;     // the compositing kernel appends the live tiles itself
+        ca.tile_list = ctx->tile_list; ca.tile_count = live_count;
+        if (group_count) { ca.tile_list2 = ctx->tile_list_g; ca.tile_count2 = group_count; ca.tile_off2 = (int)tile0; }
+    }
     if (train && ctx->deterministic) ca.loss_partial = ctx->loss_partial;
     {
         ProfScope ps(ctx, s, P_COMPOSITE);
         HIPCHK(launch_composite(ca, s));
         if (ca.loss_partial) HIPCHK(launch_loss_reduce(ca.loss_partial, (R + 3) / 4, loss, s));
-        // the pass's live tiles (indices relative to tile0); the padding tiles behind the last real one count as dead
-        if (skip) { if (int r = compact_tiles(ctx, s, ca.tile_flags, (int)n_tiles, (int)n_tiles, (int)(fa.n_samples / kTile), true, &live_count)) return r; }
+        // deterministic mode: the pass's live tiles (indices relative to tile0) in ascending order; the padding tiles behind the
+        // last real one count as dead
+        if (ca.tile_flags) { if (int r = compact_tiles(ctx, s, ca.tile_flags, (int)n_tiles, (int)n_tiles, (int)(fa.n_samples / kTile), ctx->tile_list, &live_count)) return r; }
     }
     if (train && ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
@@ -291,10 +309,9 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + dz_tile_off(tile0);
         ba.n_samples = fa.n_samples; ba.net = fa.net;
-        if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; }
-        ba.stats = ctx->tile_stats;
+        if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; ba.stats = ctx->tile_stats; }
         { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
-        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, live_count)) return r; }
+        if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, skip ? ctx->tile_list : nullptr, live_count)) return r; }
     }
     return KNERF_OK;
 }
@@ -318,14 +335,14 @@ int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
 // both nets grouped: coarse 2.86 -> 2.57 ms, fine 7.8 -> 8.15 ms per step.
 int train_chunk_impl(knerf_ctx* ctx, hipStream_t s, const float* o, const float* d, const float* t, const float* target,
                      const float* u, uint64_t seed, uint64_t ray_offset, int n_rays, float inv_chunks, float* loss,
-                     float* c_image, float* f_image, int slot = 0, int group = 1) {
+                     float* c_image, float* f_image, int slot = 0, int group = 1, int* group_count = nullptr) {
     const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
     float* ci = c_image ? c_image : ctx->img_tmp;
     float* fi = f_image ? f_image : ctx->img_tmp + (size_t)n_rays * 4;
     float* ls = loss ? loss : ctx->loss_tmp;
     const size_t tc = ctx->generic ? 0 : tiles_for((long long)n_rays * Nc);
     const size_t tile0_c = group == 1 ? 0 : slot * tc, tile0_f = group == 1 ? 0 : group * tc;
-    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, ci, nullptr, ctx->w_c, target, inv_chunks, ls, tile0_c, group == 1)) return r;
+    if (int r = run_pass(ctx, s, KNERF_COARSE, o, d, t, n_rays, Nc, ci, nullptr, ctx->w_c, target, inv_chunks, ls, tile0_c, group == 1, group_count)) return r;
     if (int r = knerf_sample_fine(ctx, s, t, ctx->w_c, u, seed, 0, ray_offset, n_rays, ctx->t_f)) return r;
     return run_pass(ctx, s, KNERF_FINE, o, d, ctx->t_f, n_rays, Na, fi, nullptr, nullptr, target, inv_chunks, ls + 1, tile0_f, true);
 }
@@ -418,8 +435,8 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (int r = upload_plan(ctx)) { std::string m_ = ctx->err; knerf_destroy(ctx); return fail(nullptr, r, m_); }
-    CREATECHK(hipMalloc(&ctx->tile_count, sizeof(int)));
-    CREATECHK(hipMemset(ctx->tile_count, 0, sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->tile_count, knerf_ctx::kTileCounters * sizeof(int)));
+    CREATECHK(hipMemset(ctx->tile_count, 0, knerf_ctx::kTileCounters * sizeof(int)));
     CREATECHK(hipMalloc(&ctx->tile_stats, 4 * sizeof(long long)));       // [2], [3]: out-of-range list entries (diagnostic builds)
     CREATECHK(hipMemset(ctx->tile_stats, 0, 4 * sizeof(long long)));
     CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
@@ -476,7 +493,7 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
-    free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->tile_count); free_dev(ctx->tile_stats);
+    free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->tile_list_g); free_dev(ctx->tile_count); free_dev(ctx->tile_stats);
     free_dev(ctx->partial); free_dev(ctx->loss_partial); free_dev(ctx->d_job_wg0);
     free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
     for (int n = 0; n < 2; ++n) { free_dev(ctx->gnet[n].packed); free_dev(ctx->gnet[n].head); free_dev(ctx->gnet[n].gaux); }
@@ -615,6 +632,7 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
     if (!o || !d || !t || !target || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "train_chunk: null/empty argument");
     hipStream_t s = (hipStream_t)stream;
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
+    ctx->tile_counter_next = 0;
     if (int r = ensure_ws(ctx, n_rays, true, s)) return r;
     if (int r = train_chunk_impl(ctx, s, o, d, t, target, u, seed, ray_offset, n_rays, inv_chunks, loss, c_image, f_image)) return r;
     return expand_head_grads(ctx, s);
@@ -629,6 +647,7 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     hipStream_t s = (hipStream_t)stream;
     const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
+    ctx->tile_counter_next = 0;
     int G = wgrad_group_for(ctx, ray_chunks, C);
     if (int r = ensure_ws(ctx, ray_chunks, true, s, G)) {
         if (G == 1) return r;
@@ -637,18 +656,27 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
         if (int r1 = ensure_ws(ctx, ray_chunks, true, s, 1)) return r1;
     }
     const size_t tc = tiles_for((long long)ray_chunks * Nc);
+    const bool skip = skipping(ctx);
+    int* group_count = nullptr;
     for (int i = 0; i < C; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
         const int slot = i % G;
         const bool last = slot == G - 1 || i == C - 1;
+        // default-mode skipping: the coarse passes of a group append their live tiles to the group's list under one counter
+        if (G > 1 && skip && !ctx->deterministic && slot == 0) { if (int r = next_tile_counter(ctx, s, &group_count)) return r; }
         if (int r = train_chunk_impl(ctx, s, o + r0 * 3, d + r0 * 3, t + r0 * Nc, target + r0 * 3, u ? u + r0 * Nf : nullptr, seed,
                                      (uint64_t)r0, ray_chunks, 1.0f / (float)C, loss, c_image ? c_image + r0 * 3 : nullptr,
-                                     f_image ? f_image + r0 * 3 : nullptr, slot, G))
+                                     f_image ? f_image + r0 * 3 : nullptr, slot, G, G > 1 && skip && !ctx->deterministic ? group_count : nullptr))
             return r;
         if (G > 1 && last) {                                        // the group's coarse weight gradients in one launch
-            int* live_count = nullptr;
-            if (skipping(ctx)) { if (int r = compact_tiles(ctx, s, ctx->tile_flags, (int)((slot + 1) * tc), (int)tc, ray_chunks * Nc / kTile, false, &live_count)) return r; }
-            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, live_count)) return r;
+            const int* live = nullptr; int* live_count = nullptr;
+            if (skip && ctx->deterministic) {                       // ascending list of the group's live tiles from its flags
+                if (int r = compact_tiles(ctx, s, ctx->tile_flags, (int)((slot + 1) * tc), (int)tc, ray_chunks * Nc / kTile, ctx->tile_list, &live_count)) return r;
+                live = ctx->tile_list;
+            } else if (skip) {
+                live = ctx->tile_list_g; live_count = group_count;
+            }
+            if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, live, live_count)) return r;
         }
     }
     return expand_head_grads(ctx, s);

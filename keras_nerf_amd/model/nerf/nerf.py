@@ -131,11 +131,11 @@ class NeRF:
 
     # ------------------------------------------------------------------ compile (nerf.py:78-173)
     def compile(self, optimizer="adam", loss="mse", batch_size=1, image_height=128, image_width=128, ray_chunks=2048,
-                white_background=False, is_training=True, all_reduce="sum", deterministic=False, skip_dead_tiles=False, **kwargs):
+                white_background=False, is_training=True, all_reduce="sum", deterministic=False, skip_dead_tiles=True, **kwargs):
         """nerf.py:78-173.  Extensions (keyword-only in spirit; the reference's callers never pass them):
         all_reduce 'sum' | 'mean' (data parallel), deterministic (bit-reproducible gradient sums, slower),
-        skip_dead_tiles (the backward skips 32-sample tiles whose dL/d(rgb, sigma) is exactly zero: same gradients, less work
-        once the scene has empty space)."""
+        skip_dead_tiles (default on: the backward skips 32-sample tiles whose dL/d(rgb, sigma) is exactly zero -- same gradients,
+        less work once the scene has empty space)."""
         logging.info("Compiling NeRF model")
         if not _is_mse(loss):
             raise ValueError("the fused HIP path implements the reference's mean-squared-error loss only")
@@ -162,8 +162,7 @@ class NeRF:
         opts = {}
         if deterministic:
             opts["deterministic"] = 1
-        if skip_dead_tiles:
-            opts["skip_dead_tiles"] = 1
+        opts["skip_dead_tiles"] = int(bool(skip_dead_tiles))
         self._ctx = KnerfContext(self.n_coarse, self.n_fine, self.pos_emb_xyz, self.pos_emb_dir, self.n_layers, self.dense_units,
                                  self.skip_layer, white_background, self.oob, h["lr"], h["beta1"], h["beta2"], h["epsilon"],
                                  options=opts)

@@ -8,19 +8,23 @@ import torch
 FOV = 0.6911112070083618
 
 
-def field(p, scale=1.0):
-    """analytic scene (torch, fp64): three soft blobs and a ring, position-dependent colour; p [...,3] -> sigma [...], rgb [...,3]"""
+def field(p, scale=1.0, compact=False):
+    """analytic scene (torch, fp64): three soft blobs and a ring, position-dependent colour; p [...,3] -> sigma [...], rgb [...,3].
+    compact: the density is cut off (max(0, sigma - 2) x 1.5), so that it is EXACTLY zero outside the objects -- hard-edged shapes in
+    truly empty space, like the nerf_synthetic renders, instead of Gaussians whose haze reaches everywhere"""
     p = p / scale
     c = torch.tensor([[0.45, 0.0, 0.15], [-0.55, 0.3, -0.25], [0.0, -0.5, 0.35]], dtype=p.dtype, device=p.device)
     d = [((p - ci) ** 2).sum(-1) for ci in c]
     ring = (torch.sqrt(p[..., 0] ** 2 + p[..., 1] ** 2) - 0.8) ** 2 + (p[..., 2] + 0.1) ** 2
     sigma = 14.0 * torch.exp(-d[0] / 0.12) + 10.0 * torch.exp(-d[1] / 0.2) + 12.0 * torch.exp(-d[2] / 0.08) + 9.0 * torch.exp(-ring / 0.015)
+    if compact:
+        sigma = 1.5 * torch.clamp(sigma - 2.0, min=0.0)
     rgb = torch.stack([0.5 + 0.5 * torch.sin(4 * p[..., 0] + 1.0), 0.5 + 0.5 * torch.cos(3 * p[..., 1] + 0.5),
                        0.25 + 0.7 * (d[0] < d[1]).to(p.dtype) * (0.5 + 0.5 * torch.sin(6 * p[..., 2]))], -1)
     return sigma, rgb.clamp(0, 1)
 
 
-def make_scene(ctx, wh=128, n_views=104, scale=1.0, ray_seed=2026):
+def make_scene(ctx, wh=128, n_views=104, scale=1.0, ray_seed=2026, compact=False):
     """views: o, d [V,H,W,3], t [V,H,W,64] (fp32, on the GPU, jitter fixed per view), img [V,H,W,3]; ctx = a KnerfContext
     (its on-device ray generator)"""
     from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
@@ -31,7 +35,7 @@ def make_scene(ctx, wh=128, n_views=104, scale=1.0, ray_seed=2026):
     tt = torch.linspace(2.0, 6.0, 512, device="cuda", dtype=torch.float64)
     for v in range(V):
         p = o[v].double()[..., None, :] + d[v].double()[..., None, :] * tt[:, None]          # [H,W,512,3]
-        sg, col = field(p, scale)
+        sg, col = field(p, scale, compact)
         delta = torch.cat([tt[1:] - tt[:-1], tt.new_full((1,), 1e-10)])
         alpha = 1.0 - torch.exp(-sg * delta)
         T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha[..., :-1] + 1e-10], -1), -1)

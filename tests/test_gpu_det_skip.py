@@ -65,7 +65,7 @@ def test_two_deterministic_train_steps_are_bit_identical(ray_chunks, n_rays):
     assert np.array_equal(w0.view(np.int32), w1.view(np.int32))
     assert float(g0.abs().max()) > 0
     # against the default (atomic) mode: the same sums in another order
-    ctx = _ctx(P)
+    ctx = _ctx(P, deterministic=0)
     ga, la = _step(ctx, data, ray_chunks)
     ctx.close()
     n = g0.numel() // 2
@@ -158,7 +158,7 @@ def test_skipping_changes_nothing_when_nothing_is_dead_and_handles_all_dead():
     g, _ = _step(ctx, data, 256)
     live, total = ctx.tile_stats()
     ctx.close()
-    ctx = _ctx(P, deterministic=1)
+    ctx = _ctx(P, deterministic=1, skip_dead_tiles=0)
     g0, _ = _step(ctx, data, 256)
     ctx.close()
     assert total == 512 * 256 // 32 and live > 0.9 * total

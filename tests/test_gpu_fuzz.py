@@ -58,10 +58,14 @@ def _cases():
         nf = int(rng.integers(0, 130))
         out.append(dict(n_coarse=nc, n_fine=nf, rays=int(rng.integers(1, 200)), white=bool(rng.integers(0, 2)),
                         oob=["zero", "clamp"][int(rng.integers(0, 2))], seed=int(rng.integers(0, 1 << 30))))
+    # round 3: the same with the run-time options on (sample counts that are multiples of 32 make skipping active)
+    for i, (nc, nf) in enumerate(((64, 128), (32, 64), (96, 32), (33, 95))):
+        out.append(dict(n_coarse=nc, n_fine=nf, rays=int(rng.integers(1, 200)), white=bool(i & 1), oob=["zero", "clamp"][i >> 1 & 1],
+                        seed=int(rng.integers(0, 1 << 30)), det=int(i != 2), skip=1))
     return out
 
 
-@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"nc{c['n_coarse']}_nf{c['n_fine']}_r{c['rays']}_{'w' if c['white'] else 'b'}_{c['oob']}")
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"nc{c['n_coarse']}_nf{c['n_fine']}_r{c['rays']}_{'w' if c['white'] else 'b'}_{c['oob']}" + ("_det" if c.get("det") else "") + ("_skip" if c.get("skip") else ""))
 def test_random_configuration_matches_oracle(case):
     from keras_nerf_amd.runtime import KnerfContext
     cfg = O.NerfConfig(n_coarse=case["n_coarse"], n_fine=case["n_fine"])
@@ -69,7 +73,10 @@ def test_random_configuration_matches_oracle(case):
     R = case["rays"]
     o, d, t, img = (P[k].reshape(P["N"], -1)[:R].copy() for k in ("o", "d", "t", "img"))
     u = P["u"].reshape(P["N"], -1)[:R].copy() if case["n_fine"] else None
-    ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, white_background=case["white"], oob=case["oob"])
+    ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, white_background=case["white"], oob=case["oob"],
+                       options=dict(deterministic=case.get("det", 0), skip_dead_tiles=case.get("skip", 0)))
+    if case.get("skip"):
+        assert ctx.get_option("skip_dead_tiles_active") == float(cfg.n_coarse % 32 == 0 and (cfg.n_coarse + cfg.n_fine) % 32 == 0)
     ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
     ci, cd, cw = [x.cpu().numpy() for x in ctx.forward_chunk(0, o, d, t)]
     rc = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, case["white"], emulate_bf16=O.FUSED)

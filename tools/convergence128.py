@@ -39,8 +39,11 @@ from tests.procedural_scene import make_scene as _make_scene, psnr   # noqa: E40
 SCALE = 1.0        # --scale: object size (1.0: the blobs span about +-0.8 of the +-1.44 half-width the cameras see)
 
 
+COMPACT = False    # --scene compact: density cut off to exactly zero outside the objects (tests/procedural_scene.py)
+
+
 def make_scene(ctx):
-    return _make_scene(ctx, WH, NTRAIN + NVAL, SCALE)
+    return _make_scene(ctx, WH, NTRAIN + NVAL, SCALE, compact=COMPACT)
 
 
 def main():
@@ -58,12 +61,15 @@ def main():
     ap.add_argument("--skip-dead", action="store_true", help="hip leg: skip dead 32-sample tiles in the backward (exact); logs the dead fraction "
                                                             "and the ms per step between checkpoints")
     ap.add_argument("--save-weights", default=None, help="hip leg: write coarse/fine flat weights at every checkpoint to this .npz prefix")
+    ap.add_argument("--scene", default="soft", choices=["soft", "compact"], help="soft: Gaussian blobs (density > 0 everywhere, the r02 experiments); "
+                                                                                 "compact: the same shapes with the density cut off to exactly 0 outside them")
     ap.add_argument("--perturb", type=int, default=0,
                     help="fp32 leg only: visit each step's chunks in a permutation drawn from this seed (0 = reference order). Same "
                          "sums, another floating-point order: measures the fp32 arithmetic's own trajectory spread")
     args = ap.parse_args()
-    global SCALE
+    global SCALE, COMPACT
     SCALE = args.scale
+    COMPACT = args.scene == "compact"
     t_start = time.time()
     from keras_nerf_amd.model.nerf.nerf import NeRF
     from keras_nerf_amd.runtime import KnerfContext
