@@ -257,10 +257,11 @@ def write_synthetic_dataset(root, wh, n=(100, 4, 4)):
 def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     """`--mode fit`: the rate of the thing train_single.py:137-143 calls -- DatasetLoader (PNG decode, device-resident views,
     on-device rays) -> NeRF.fit -> train_step WITH its six metrics -> NeRFTrainMonitor (panels off; CSV, checkpoint and the two
-    monitor renders at every epoch end) -- against the plain `train_step(with_metrics=False)` loop on one resident batch that
-    the default mode times.  One warm-up epoch (decodes the PNGs, fills the device cache), then `--epochs` timed epochs of 100
+    monitor renders at every epoch end) -- against the plain `train_step(with_metrics=False)` loop on one resident batch (the
+    default mode's loop), both with dead-tile skipping off so that the two loops do the same work.  One warm-up epoch (decodes the PNGs, fills the device cache), then `--epochs` timed epochs of 100
     training views.  value = rays*samples of the training batches / time of the train loops (from an epoch's first batch to the
-    read-back of its logs, GPU drained); `fit_wall_*` adds validation and the monitor."""
+    read-back of its logs, GPU drained); `fit_wall_*` adds validation and the monitor.  One further epoch with skipping on (the
+    library default) is timed and reported with its dead-tile share."""
     import tempfile
     from keras_nerf_amd.data.loader import DatasetLoader
     from keras_nerf_amd.model.nerf.callback import NeRFTrainMonitor
@@ -279,8 +280,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     class Clock:
         def on_epoch_begin(self, epoch, logs=None):
             torch.cuda.synchronize()
-            if epoch == 1:
-                nerf._ctx.tile_stats(reset=True)      # dead-tile share of the timed epochs only
+            nerf._ctx.tile_stats(reset=True)          # dead-tile share per epoch (read after the skipping epoch)
             marks.append(["begin", time.perf_counter()])
 
         def on_test_begin(self, logs=None):          # fit has read the epoch's logs back: the train loop is over and the GPU drained
@@ -288,6 +288,11 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
 
         def on_epoch_end(self, epoch, logs=None):
             torch.cuda.synchronize(); marks.append(["end", time.perf_counter()])
+    # The overhead comparison runs with dead-tile skipping OFF in both loops: with it on, the work of a step depends on how far the
+    # scene has trained (the disc images' exact white background is dead within an epoch), which says nothing about loader, metrics
+    # or monitor.  One more epoch with the option on follows and is reported beside it.
+    skip_default = bool(nerf._ctx.get_option("skip_dead_tiles"))
+    nerf._ctx.set_option("skip_dead_tiles", 0)
     epochs = 1 + args.epochs
     nerf.fit(train, epochs=epochs, validation_data=val, callbacks=[Clock(), monitor], verbose=0)
     torch.cuda.synchronize()
@@ -297,10 +302,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     wall = t["end"][-1] - t["begin"][1]
     per_step = wh * wh * batch * 256
     value = world * per_step * steps * args.epochs / loop
-    live, total = nerf._ctx.tile_stats(reset=True)          # over the timed epochs (reset when they began, see Clock)
-    dead_fit = 1.0 - live / max(total, 1) if total else None
-    # the plain train_step loop in the same process, on ONE RESIDENT BATCH OF THE SAME DATASET (with the weights as fit left
-    # them, so that the backward has the same share of exactly-dead tiles to skip as the epochs above): no loader, no metrics
+    # the plain train_step loop in the same process on one resident batch of the same dataset: no loader, no metrics, no callbacks
     data = next(iter(train))
     for _ in range(3):
         nerf.train_step(data, with_metrics=False)
@@ -314,8 +316,18 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     for _ in range(20):
         nerf.train_step(data, sync=False)
     sync(world); tm = (time.perf_counter() - t0) / 20
-    live, total = nerf._ctx.tile_stats(reset=True)
-    dead_loop = 1.0 - live / max(total, 1) if total else None
+    # ... and what fit delivers with skipping on (the default), at this point of the training
+    nerf._ctx.set_option("skip_dead_tiles", 1)
+    skip_ms = dead_fit = None
+    if nerf._ctx.get_option("skip_dead_tiles_active"):
+        marks.clear()
+        nerf.fit(train, epochs=epochs + 1, initial_epoch=epochs, validation_data=val, callbacks=[Clock(), monitor], verbose=0)
+        torch.cuda.synchronize()
+        b = [m[1] for m in marks if m[0] == "begin"]; e = [m[1] for m in marks if m[0] == "train_end"]
+        skip_ms = (e[0] - b[0]) / steps * 1e3
+        live, total = nerf._ctx.tile_stats(reset=True)
+        dead_fit = 1.0 - live / max(total, 1) if total else None
+    nerf._ctx.set_option("skip_dead_tiles", int(skip_default))
     if rank == 0:
         print(json.dumps({"metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
                           "unit": "rays*samples/s", "n_gpus": world, "steps": steps * args.epochs, "warmup": steps, "ms_per_step": loop / (steps * args.epochs) * 1e3,
@@ -324,8 +336,8 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                                                  f"{steps} steps per epoch, {args.epochs} timed epochs after one warm-up epoch", "parallelism": f"dp{world}"},
                           "train_step_ms": ts * 1e3, "train_step_with_metrics_ms": tm * 1e3, "metrics_ms_per_step": (tm - ts) * 1e3,
                           "fit_vs_train_step": (loop / (steps * args.epochs)) and ts / (loop / (steps * args.epochs)),
-                          "dead_tile_frac_fit_epochs": dead_fit, "dead_tile_frac_train_step_loop": dead_loop,
-                          "options": {k: bool(nerf._ctx.get_option(k)) for k in ("skip_dead_tiles", "deterministic")},
+                          "options_during_comparison": {"skip_dead_tiles": False, "deterministic": False},
+                          "fit_ms_per_step_with_skip_dead_tiles": skip_ms, "dead_tile_frac_that_epoch": dead_fit,
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
                           "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
