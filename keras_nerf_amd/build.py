@@ -16,6 +16,11 @@ LIB = os.path.join(HERE, "libknerf_hip.so")
 PROBE_LIB = os.path.join(HERE, "libknerf_probe.so")
 SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.hip", "composite.hip", "sampler.hip", "optim.hip",
            "raygen.hip", "utils_ops.hip"]
+# The three big kernels are templates on the trunk shape (csrc/layout.h KNERF_FUSED_SHAPES): each of these sources is compiled once
+# per shape with -DKNERF_SHAPE_SLICE=<index> (that translation unit then defines the kernels of its shape only; slice 0 also holds
+# the run-time dispatchers), so the shapes build in parallel and the default shape's object is what it was before the others existed.
+SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
+N_SHAPE_SLICES = 5      # = kNumFusedShapes (knerf_api.hip static_asserts it)
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]
@@ -31,18 +36,33 @@ def _newer(a: str, b: str) -> bool:
 def _compile(hipcc, sources, objdir, flags, force, verbose):
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
+    jobs = []
     for src in sources:
+        if src in SLICED:
+            jobs += [(src, src.replace(".hip", f"_s{k}.o"), [f"-DKNERF_SHAPE_SLICE={k}", f"-DKNERF_N_SHAPE_SLICES={N_SHAPE_SLICES}"]) for k in range(N_SHAPE_SLICES)]
+        else:
+            jobs.append((src, src.replace(".hip", ".o"), [f"-DKNERF_N_SHAPE_SLICES={N_SHAPE_SLICES}"]))
+    todo = []
+    for src, obj, extra in jobs:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, obj)
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdr_paths):
-            cmd = [hipcc, *flags, "-c", s, "-o", o]
+            todo.append((obj, [hipcc, *flags, *extra, "-c", s, "-o", o]))
+    limit = max(1, min(len(todo), (os.cpu_count() or 8)))      # hipcc processes in flight
+    running = []
+    while todo or running:
+        while todo and len(running) < limit:
+            name, cmd = todo.pop(0)
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+            running.append((name, subprocess.Popen(cmd)))
+            procs.append(name)
+        name, p = running.pop(0)
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+            for _, q in running:
+                q.kill()
+            raise RuntimeError(f"hipcc failed on {name}")
     return objs, bool(procs)
 
 

@@ -14,39 +14,26 @@
 
 namespace knerf {
 
-// store schedule: 2 dZ blocks per out tile of every stage but the first (dz7 is recomputed by wgrad, not stored; the dz_head
-// block is stored BEFORE the ring's prologue, i.e. it is older than every LDS-DMA and never counted)
-#ifndef KNERF_STORE_BURST
-#define KNERF_STORE_BURST 2      // dZ blocks written per burst (see mlp_fwd.hip)
-#endif
-constexpr int kBwdBurstTiles = KNERF_STORE_BURST / 2;
-#if KNERF_STORE_BURST == 2
-constexpr StoreSched<8> kBwdStores = {{{0, 1, 8, 0, 0, 0}, {8, 16, 8, 2, 0, 0}, {136, 16, 8, 2, 0, 0}, {264, 16, 8, 2, 0, 0},
-                                       {392, 16, 8, 2, 0, 0}, {520, 16, 8, 2, 0, 0}, {648, 16, 8, 2, 0, 0}, {776, 16, 8, 2, 0, 0}}, 0};
-constexpr int kBwdStoreStages = 8;
-#else
-constexpr int kBwdParts = 8 / kBwdBurstTiles;
-constexpr int kBwdStoreStages = 8 * kBwdParts;
-constexpr StoreSched<kBwdStoreStages> make_bwd_burst_sched() {
-    StoreSched<kBwdStoreStages> s{};
-    for (int st = 0; st < 8; ++st)
-        for (int p = 0; p < kBwdParts; ++p) {
-            const int b0 = st == 0 ? 0 : 8 + 128 * (st - 1), nks = st == 0 ? 1 : 16;
-            s.st[st * kBwdParts + p] = StoreStage{b0 + p * kBwdBurstTiles * nks, nks, kBwdBurstTiles, 0, st == 0 ? 0 : 2 * kBwdBurstTiles, 0};
-        }
-    s.initial = 0;
-    return s;
+// store schedule: 2 dZ blocks per out tile of every stage but the first (the last layer's dz is recomputed by wgrad, not stored --
+// unless that layer is a concat layer, Shape::kSaveLastDz; the dz_head block is stored BEFORE the ring's prologue, i.e. it is older
+// than every LDS-DMA and never counted)
+template <class S>
+constexpr StoreSched<S::kBwdStages> make_bwd_stores() {
+    StoreSched<S::kBwdStages> t{};
+    for (int st = 0; st < S::kBwdStages; ++st)
+        t.st[st] = StoreStage{S::bwd_b0(st), st == 0 ? 1 : 16, 8, (st == 0 && !S::kSaveLastDz) ? 0 : 2, 0, 0};
+    t.initial = 0;
+    return t;
 }
-constexpr StoreSched<kBwdStoreStages> kBwdStores = make_bwd_burst_sched();
-#endif
 #ifdef KNERF_CONSERVATIVE_WAIT
 constexpr StoreSched<1> kNoStoresB = {{{0, 1, 0, 0, 0, 0}}, 0};
-struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<1, kBwdBlocks>(kNoStoresB); };
+template <class S> struct BwdWait { static constexpr WaitTable<S::kBwdBlocks> tab = make_wait_table<1, S::kBwdBlocks>(kNoStoresB); };
 #else
-struct BwdWait { static constexpr WaitTable<kBwdBlocks> tab = make_wait_table<kBwdStoreStages, kBwdBlocks>(kBwdStores); };
+template <class S> struct BwdWait { static constexpr WaitTable<S::kBwdBlocks> tab = make_wait_table<S::kBwdStages, S::kBwdBlocks>(make_bwd_stores<S>()); };
 #endif
 
 // dgrad chain of the 8 sample tiles (8 waves x 32 samples) of workgroup tile `wg_tile`
+template <class S>
 __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long long wg_tile) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));    // opaque per call: in a persistent loop nothing derived from it may be hoisted (and spilled)
@@ -79,15 +66,15 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
     if (!valid) g = a.n_samples - 1;
 
     // everything this wave reads with ordinary loads is fetched (and waited for) before the LDS-DMA ring starts
-    u32x4 mk[8];
-    const char* maskp = a.mask + mask_tile_off((size_t)tile) + lane * 16;
+    u32x4 mk[S::NL];
+    const char* maskp = a.mask + mask_tile_off<S>((size_t)tile) + lane * 16;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) mk[l] = *reinterpret_cast<const u32x4*>(maskp + l * kSavedBlockStride);
+    for (int l = 0; l < S::NL; ++l) mk[l] = *reinterpret_cast<const u32x4*>(maskp + l * kSavedBlockStride);
     const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[g];
     f32x4 dr = reinterpret_cast<const f32x4*>(a.draw)[g];
     if (!valid) dr = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int l = 0; l < 8; ++l) asm volatile("" ::"v"(mk[l]));   // pin the waits here, not inside the pipelined loop
+    for (int l = 0; l < S::NL; ++l) asm volatile("" ::"v"(mk[l]));   // pin the waits here, not inside the pipelined loop
 
     bf16x8 zhead;
 #pragma unroll
@@ -98,16 +85,16 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
         zhead[2] = (__bf16)(dr[2] * raw[2] * (1.f - raw[2]));
         zhead[3] = (__bf16)(raw[3] > 0.f ? dr[3] : 0.f);
     }
-    char* dz = a.dz + dz_tile_off((size_t)tile);
-    store_block(dz, kDzHead, lane, zhead);     // block kDzHead+1 stays zero (the buffer is zero-initialised)
+    char* dz = a.dz + dz_tile_off<S>((size_t)tile);
+    store_block(dz, S::kDzHead, lane, zhead);     // block kDzHead+1 stays zero (the buffer is zero-initialised)
 
     asm volatile("" ::: "memory");            // the store above stays ahead of the first LDS-DMA in program order
     Ring ring{a.stream, smem, tid, wave};
     ring.prologue_issue();
     ring.prologue_wait();
     Prefetch pf;
-    pf.start<kBwdBlocks>(ring, lane);
-    BwdWait waits;
+    pf.start<S::kBwdBlocks>(ring, lane);
+    BwdWait<S> waits;
 
     bf16x8 x[16], y[16];
     auto zero_init = [](int) { return zero_acc(); };
@@ -119,28 +106,24 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
 #ifndef KNERF_ABLATE_MASK      // timing experiment only
             apply_mask_packed(out[2 * ot], out[2 * ot + 1], mk[layer][ot >> 1] >> ((ot & 1) * 8));
 #endif
-            // dz7 is not written: it is mask7 * (H dz_head) with only 4 input channels, which the layer_7 wgrad job recomputes from
-            // the dz_head block and the mask block (wgrad_body.h wgrad_l7_recompute)
-            if (layer != 7 && (ot + 1) % kBwdBurstTiles == 0) {        // bursts of kBwdBurstTiles out tiles (the layer's dZ stays in registers anyway)
-#pragma unroll
-                for (int q = ot + 1 - kBwdBurstTiles; q <= ot; ++q) {
-                    store_block(dz, 16 * layer + 2 * q, lane, out[2 * q]);
-                    store_block(dz, 16 * layer + 2 * q + 1, lane, out[2 * q + 1]);
-                }
+            // the last layer's dz is not written: it is mask * (H dz_head) with only 4 input channels, which its wgrad job recomputes
+            // from the dz_head block and the mask block (wgrad_body.h wgrad_last_recompute) -- unless that job is the two-range
+            // one of a concat layer (Shape::kSaveLastDz)
+            if (layer != S::NL - 1 || S::kSaveLastDz) {
+                store_block(dz, 16 * layer + 2 * ot, lane, out[2 * ot]);
+                store_block(dz, 16 * layer + 2 * ot + 1, lane, out[2 * ot + 1]);
             }
         };
     };
-    // B0: dz_head (r, g, b, sigma) -> dh7 -> dz7 (y)
-    dense_stage<0, 1, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zhead; }, mask_epi(y, 7));
-    // B1..B7: dz_l -> dz_{l-1}
-    dense_stage<8, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 6));
-    dense_stage<136, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 5));
-    dense_stage<264, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 4));
-    dense_stage<392, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 3));
-    dense_stage<520, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 2));
-    dense_stage<648, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, 1));
-    dense_stage<776, 16, 8, kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, 0));
-    ring_finish<kBwdBlocks>(ring, grp);
+    // B0: dz_head (r, g, b, sigma) -> dh_{NL-1} -> dz_{NL-1} (y)
+    dense_stage<0, 1, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zhead; }, mask_epi(y, S::NL - 1));
+    // Bq: dz_l -> dz_{l-1}, l = NL-q; odd stages read y and write x, even stages the other way round
+    static_for<S::NL - 1>([&](auto q_) {
+        constexpr int q = decltype(q_)::value + 1;
+        if constexpr (q % 2) dense_stage<S::bwd_b0(q), 16, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, S::NL - 1 - q));
+        else dense_stage<S::bwd_b0(q), 16, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, S::NL - 1 - q));
+    });
+    ring_finish<S::kBwdBlocks>(ring, grp);
 }
 
 

@@ -28,22 +28,32 @@ struct Tables {
     int n_plan = 0;
 };
 
-// the packing / destination tables of layout.h, built once per process (host only)
+// the packing / destination tables of layout.h for one trunk shape, built once per process and shape (host only)
+template <class S>
 inline void build_wgrad_tables(Tables& t) {
-    auto tt = tensor_table();
+    auto tt = tensor_table<S>();
     t.wgrad.clear(); t.wgrad_off.clear();
-    for (int jb = 0; jb < kWgradJobs; ++jb) {
+    for (int jb = 0; jb < S::kWgradJobs; ++jb) {
         t.wgrad_off.push_back((int32_t)t.wgrad.size());
-        WgradJob J = wgrad_job(jb);
+        const WgradJob J = wgrad_job<S>(jb);
         const int rows = J.n_it * 32 + 1, cols = J.n_ot * 32;     // last row = bias
         for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) t.wgrad.push_back(wgrad_dst(tt, jb, r == rows - 1 ? -2 : r, c));
+            for (int c = 0; c < cols; ++c) t.wgrad.push_back(wgrad_dst<S>(tt, jb, r == rows - 1 ? -2 : r, c));
     }
     t.wgrad_off.push_back((int32_t)t.wgrad.size());
 }
-inline const Tables& host_tables() {
-    static const Tables t = [] { Tables x; build_fwd(x.host); build_bwd(x.host); build_wgrad_tables(x); return x; }();
+template <class S>
+inline const Tables& host_tables_of() {
+    static const Tables t = [] { Tables x; build_fwd<S>(x.host); build_bwd<S>(x.host); build_wgrad_tables<S>(x); return x; }();
     return t;
+}
+inline const Tables& host_tables(int shape_id = 0) {      // layout.h fused_shape_id
+    switch (shape_id) {
+#define KNERF_X(I, NL, SK) case I: return host_tables_of<Shape<NL, SK>>();
+        KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+        default: return host_tables_of<DefaultShape>();
+    }
 }
 
 }  // namespace knerf
@@ -62,8 +72,10 @@ struct knerf_ctx {
     int* h_status = nullptr;           // pinned host: [0] number of skipped (non-finite) steps so far, written by the device
     int skipped_seen = 0;
     int n_cu = 256;
-    // general-shape MLP path (generic.h): used when the config is not the default NeRFMLP shape
+    // general-shape MLP path (generic.h): used when the fused kernels do not cover the config's MLP shape (layout.h KNERF_FUSED_SHAPES)
     bool generic = false;
+    int shape = 0;                      // fused path: layout.h fused_shape_id of the trunk
+    knerf::ShapeInfo si = knerf::shape_info(0);
     int n_params = knerf::kParamCount;
     knerf::gen::Plan gplan;
     knerf::gen::Workspace gws;
@@ -78,7 +90,7 @@ struct knerf_ctx {
     bool skip_dead = true;              // dgrad / wgrad skip 32-sample tiles whose dL/d(rgb, sigma) is exactly zero (exact; +0.3 % when nothing is dead)
     int wgrad_group_max = 4;            // chunks per coarse weight-gradient launch of knerf_train_batch (1 = one launch per chunk)
     double wgrad_group_gb = 40.0;       // memory budget of those grouped workspaces
-    int wgrad_cost[knerf::kWgradJobs] = {128, 264, 204, 204, 204, 267, 204, 240, 193};   // workgroups per job ~ cost (build_wgrad_plan)
+    int wgrad_cost[17] = {};            // workgroups per job ~ cost (build_wgrad_plan); filled from the job kinds at creation
     bool plan_dirty = false;
     int group_cache_rays = 0, group_cache_chunks = 0, group_cache = 0;   // wgrad_group_for memo (hipMemGetInfo is a driver call)
     // workspaces (grow-only).  Inference buffers (raw, w_c, t_f, img_tmp) follow the largest chunk seen by any call; the training

@@ -63,7 +63,7 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
         case 6: *dev = ctx->w_c; *bytes = (size_t)ctx->ws_rays * ctx->cfg.n_coarse * sizeof(float); break;
         case 7:
             if (net != 0 && net != 1) return KNERF_ERR_INVALID;
-            *dev = ctx->net[net].w; *bytes = (size_t)(ctx->generic ? ctx->n_params : kExtParamCount) * sizeof(float); break;
+            *dev = ctx->net[net].w; *bytes = (size_t)(ctx->generic ? ctx->n_params : ctx->si.ext_param_count) * sizeof(float); break;
         default: return KNERF_ERR_INVALID;
     }
     // not allocated: no pass has run yet, or the buffer belongs to the fused path and this context runs the general-shape kernels

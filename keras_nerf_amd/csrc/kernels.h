@@ -35,8 +35,10 @@ struct FwdArgs {
     long long n_samples;    // R*S
     int S;
     int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
+    int shape;              // layout.h fused_shape_id: which trunk shape's instantiation
 };
 hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream);
+template <class S> hipError_t launch_mlp_fwd_t(const FwdArgs& a, bool save, hipStream_t stream);
 
 struct BwdArgs {
     const char* stream;     // packed dgrad A-fragments
@@ -46,12 +48,14 @@ struct BwdArgs {
     char* dz;               // out: [tiles][kDzBlocks][1 KiB]
     long long n_samples;
     int net;                // 0 coarse / 1 fine: kernel instantiation name only
+    int shape;              // layout.h fused_shape_id
     const int* live;        // dead-tile skipping: ascending list of the pass's live 32-sample tiles and its length (device), or null
     const int* n_live;
     long long* stats;       // list mode: [0] += live tiles, [1] += tiles of the pass (knerf_tile_stats); -DKNERF_LIST_GUARD builds: [2] +=
                             //   list entries outside [0, n_tiles) seen (and clamped) by this kernel
 };
 hipError_t launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
+template <class S> hipError_t launch_mlp_bwd_t(const BwdArgs& a, hipStream_t stream);
 
 struct WgradArgs {
     const char* act;        // [tiles][kActBlocks][1 KiB]
@@ -67,7 +71,10 @@ struct WgradArgs {
     long long n_tiles;
     int n_plan;
     int net;                // 0 coarse / 1 fine: selects the kernel instantiation (a name for profilers), nothing else
-    int job_off[10];        // offset of each job's table inside dst (kWgradJobs + 1)
+    int shape;              // layout.h fused_shape_id
+    int n_jobs;             // Shape::kWgradJobs = n_layers + 1
+    int aux_base;           // Shape::kAuxBase = the shape's parameter count: destination indices >= it address `aux`
+    int job_off[18];        // offset of each job's table inside dst (n_jobs + 1 entries)
     float* partial;         // deterministic mode: [n_plan][kWgradPartialStride] per-workgroup sums instead of atomics (zero-filled by the caller), or null
     const int* live;        // dead-tile skipping: ascending list of live tiles (relative to act / dz / mask) and its length (device), or null
     const int* n_live;
@@ -77,6 +84,7 @@ struct WgradArgs {
                             //   workgroup as the non-skipping launch: the deterministic mode's bit-exactness check)
 };
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
+template <class S> hipError_t launch_wgrad_t(const WgradArgs& a, hipStream_t stream);
 // deterministic mode, after launch_wgrad: grad[dst] += sum over the job's workgroups (ascending split) of their partial slabs
 hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0 /* device: kWgradJobs+1 plan offsets */, hipStream_t stream);
 size_t wgrad_partial_floats(int n_plan);
@@ -139,8 +147,9 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // collapsed head (layout.h): w = one net's extended weight buffer (kExtParamCount floats).  compose writes the head matrix
 // and bias behind the parameters; expand turns the wgrad head job's aux sums into the gradients of features, rgb_features
 // and rgb (added to grad, aux zeroed).
-hipError_t launch_head_compose(float* w0, float* w1 /* may be null */, hipStream_t stream);   // one workgroup per net
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, hipStream_t stream);
+// trunk_params = layout.h Shape::kTrunkParams: the offset of the sigma kernel in the flat parameter vector
+hipError_t launch_head_compose(float* w0, float* w1 /* may be null */, int trunk_params, hipStream_t stream);   // one workgroup per net
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, hipStream_t stream);
 
 struct RayGenArgs {
     const float* c2w;       // [B,4,4] row-major (device)

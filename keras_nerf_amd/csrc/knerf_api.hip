@@ -18,6 +18,10 @@
 
 using namespace knerf;
 
+#ifdef KNERF_N_SHAPE_SLICES
+static_assert(KNERF_N_SHAPE_SLICES == kNumFusedShapes, "keras_nerf_amd/build.py N_SHAPE_SLICES must equal the number of entries of layout.h KNERF_FUSED_SHAPES");
+#endif
+
 namespace {
 
 std::string g_create_error;
@@ -27,7 +31,7 @@ std::string g_create_error;
 // (layer_0, head) latency-bound, so bytes alone mis-balance them.  About one workgroup per CU in total.
 // knerf_set_option(ctx, "wgrad_cost<j>", c) overrides an entry (tuning sweeps in one gpurun call: tools/tune_costs.py).
 // job_wg0[j] = index of job j's first workgroup (kWgradJobs + 1 entries): the deterministic mode's second pass walks them in order.
-std::vector<int32_t> build_wgrad_plan(int n_wg, const int (&cost)[kWgradJobs], std::vector<int32_t>& job_wg0) {
+std::vector<int32_t> build_wgrad_plan(int n_wg, const int* cost, int n_jobs, std::vector<int32_t>& job_wg0) {
     // r02 stamps (gpurun_out/r2b/stamps.json): 1180 / 2080 / 2590 / 1530 cycles per tile for layer_0 / 256x256 / layer_5 / head;
     // head swept 100..200 (1.40 / 1.20 / 1.13 / 1.12 ms per fine launch at 100 / 130 / 160 / 200)
     // layer_1 recomputes h0 (wgrad_l1_recompute, 20 KiB tiles but 22 MFMAs and an LDS exchange per tile): swept 160 / 204 / 240 /
@@ -35,20 +39,22 @@ std::vector<int32_t> build_wgrad_plan(int n_wg, const int (&cost)[kWgradJobs], s
     // layer_7 recomputes dz7 (wgrad_l7_recompute, 18 KiB tiles): 204 -> 240; with the copies issued behind the first half's MFMAs
     // the plain jobs gained most, tools/tune_costs.py (coordinate search on the box) moved the others up: coarse + fine launch
     // 1.439 -> 1.382 ms
-    // (the defaults live in knerf_ctx::wgrad_cost: 128, 264, 204, 204, 204, 267, 204, 240, 193)
+    // (the defaults are set per job KIND at creation, default_wgrad_cost: 128 first layer, 264 layer_1, 204 plain, 267 concat, 240
+    // last layer, 193 head -- i.e. 128, 264, 204, 204, 204, 267, 204, 240, 193 for the default shape)
     int total = 0;
-    for (int j = 0; j < kWgradJobs; ++j) total += cost[j] > 0 ? cost[j] : 0;
+    for (int j = 0; j < n_jobs; ++j) total += cost[j] > 0 ? cost[j] : 0;
     std::vector<int32_t> plan;
-    job_wg0.assign(kWgradJobs + 1, 0);
-    for (int j = 0; j < kWgradJobs; ++j) {
+    job_wg0.assign(n_jobs + 1, 0);
+    for (int j = 0; j < n_jobs; ++j) {
         job_wg0[j] = (int32_t)plan.size() / 4;
         if (cost[j] <= 0) continue;          // a sweep may switch a job off (its gradient is then missing: timing experiments only)
         int ns = (cost[j] * (n_wg - 4) + total / 2) / total; if (ns < 1) ns = 1;
         for (int s = 0; s < ns; ++s) { plan.push_back(j); plan.push_back(s); plan.push_back(ns); plan.push_back(0); }
     }
-    job_wg0[kWgradJobs] = (int32_t)plan.size() / 4;
+    job_wg0[n_jobs] = (int32_t)plan.size() / 4;
     return plan;
 }
+int default_wgrad_cost(int kind) { const int c[6] = {128, 264, 204, 267, 240, 193}; return c[kind >= 0 && kind < 6 ? kind : 2]; }
 
 }  // namespace
 
@@ -65,8 +71,7 @@ int fail(knerf_ctx* c, int code, const std::string& msg) {
             return fail(ctx, KNERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-constexpr size_t kFwdStreamBytes = (size_t)((kFwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
-constexpr size_t kBwdStreamBytes = (size_t)((kBwdBlocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024;
+size_t stream_bytes(int blocks) { return (size_t)((blocks + kPageBlocks - 1) / kPageBlocks * kPageBlocks + kTailPages * kPageBlocks) * 1024; }
 
 // compose = false: the caller has already composed the heads of both nets in one launch (knerf_apply_adam)
 int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
@@ -75,10 +80,10 @@ int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
         HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n], s));
         return KNERF_OK;
     }
-    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
-    HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)kFwdBlocks * 512, s));
-    HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)kBwdBlocks * 512, s));
-    HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)kFwdBiasTiles * 32, s));
+    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, ctx->si.trunk_params, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
+    HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)ctx->si.fwd_blocks * 512, s));
+    HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)ctx->si.bwd_blocks * 512, s));
+    HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)ctx->si.fwd_bias_tiles * 32, s));
     return KNERF_OK;
 }
 
@@ -91,7 +96,7 @@ size_t tiles_for(long long n_samples) {
 // (re)build the wgrad plan from ctx->wgrad_cost and upload it with the jobs' workgroup offsets
 int upload_plan(knerf_ctx* ctx) {
     std::vector<int32_t> job_wg0;
-    std::vector<int32_t> plan = build_wgrad_plan(ctx->n_cu, ctx->wgrad_cost, job_wg0);
+    std::vector<int32_t> plan = build_wgrad_plan(ctx->n_cu, ctx->wgrad_cost, ctx->si.n_jobs, job_wg0);
     if (ctx->tab.d_plan) { (void)hipFree(ctx->tab.d_plan); ctx->tab.d_plan = nullptr; }
     if (ctx->d_job_wg0) { (void)hipFree(ctx->d_job_wg0); ctx->d_job_wg0 = nullptr; }
     HIPCHK(hipMalloc(&ctx->tab.d_plan, plan.size() * sizeof(int32_t)));
@@ -168,8 +173,8 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         const size_t ns = (size_t)R * Na;
         // group 1: the coarse and the fine pass of a chunk share one region (each pass's weight gradients follow it at once)
         const size_t tiles = group == 1 ? tiles_for((long long)ns) : (size_t)group * tiles_for((long long)R * ctx->cfg.n_coarse) + tiles_for((long long)ns);
-        ctx->act_bytes = saved_region_bytes(tiles, kActBlocks); ctx->mask_bytes = saved_region_bytes(tiles, kMaskBlocks);
-        ctx->dz_bytes = saved_region_bytes(tiles, kDzBlocks);
+        ctx->act_bytes = saved_region_bytes(tiles, ctx->si.act_blocks); ctx->mask_bytes = saved_region_bytes(tiles, ctx->si.mask_blocks);
+        ctx->dz_bytes = saved_region_bytes(tiles, ctx->si.dz_blocks);
         HIPCHK(hipMalloc(&ctx->draw, ns * 4 * sizeof(float)));
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
@@ -233,12 +238,14 @@ int compact_tiles(knerf_ctx* ctx, hipStream_t s, const int* flags, int n, int pe
 // list of live tiles (indices relative to tile0) with its device counter.
 int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, size_t n_tiles, const int* live, const int* live_count) {
     WgradArgs wa{};
-    wa.act = ctx->act + act_tile_off(tile0); wa.dz = ctx->dz + dz_tile_off(tile0); wa.mask = ctx->mask + mask_tile_off(tile0);
+    wa.act = ctx->act + saved_tile_off(tile0, ctx->si.act_blocks); wa.dz = ctx->dz + saved_tile_off(tile0, ctx->si.dz_blocks);
+    wa.mask = ctx->mask + saved_tile_off(tile0, ctx->si.mask_blocks);
+    wa.shape = ctx->shape; wa.n_jobs = ctx->si.n_jobs; wa.aux_base = ctx->si.param_count;
     wa.grad = ctx->net[net].g; wa.aux = ctx->net[net].aux; wa.dst = ctx->tab.d_wgrad;
     wa.fwd_stream = ctx->net[net].fwd_stream; wa.bias = ctx->net[net].bias; wa.bwd_stream = ctx->net[net].bwd_stream;
     wa.n_tiles = (long long)n_tiles;
     wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
-    for (int j = 0; j <= kWgradJobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
+    for (int j = 0; j <= ctx->si.n_jobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
     if (live) { wa.live = live; wa.n_live = live_count; wa.by_range = ctx->deterministic ? 1 : 0; }
     wa.stats = ctx->tile_stats;
     if (ctx->deterministic) {
@@ -269,8 +276,9 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     FwdArgs fa{};
     fa.stream = ctx->net[net].fwd_stream; fa.bias = ctx->net[net].bias;
     fa.o = o; fa.d = d; fa.t = t; fa.raw = ctx->raw;
-    fa.act = ctx->act ? ctx->act + act_tile_off(tile0) : nullptr; fa.mask = ctx->mask ? ctx->mask + mask_tile_off(tile0) : nullptr;
-    fa.n_samples = (long long)R * S; fa.S = S; fa.net = net == KNERF_COARSE ? 0 : 1;
+    fa.act = ctx->act ? ctx->act + saved_tile_off(tile0, ctx->si.act_blocks) : nullptr;
+    fa.mask = ctx->mask ? ctx->mask + saved_tile_off(tile0, ctx->si.mask_blocks) : nullptr;
+    fa.n_samples = (long long)R * S; fa.S = S; fa.net = net == KNERF_COARSE ? 0 : 1; fa.shape = ctx->shape;
     if (ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_FWD_C : P_FWD_F);
         HIPCHK(gen::forward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->net[net].w, o, d, t, fa.n_samples, S, ctx->raw, s));
@@ -307,8 +315,8 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s));
     } else if (train) {
         BwdArgs ba{};
-        ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + dz_tile_off(tile0);
-        ba.n_samples = fa.n_samples; ba.net = fa.net;
+        ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + saved_tile_off(tile0, ctx->si.dz_blocks);
+        ba.n_samples = fa.n_samples; ba.net = fa.net; ba.shape = ctx->shape;
         if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; ba.stats = ctx->tile_stats; }
         { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
         if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, skip ? ctx->tile_list : nullptr, live_count)) return r; }
@@ -323,7 +331,7 @@ int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
         for (int n = 0; n < 2; ++n) HIPCHK(gen::expand_head(ctx->gplan, ctx->gnet[n], ctx->net[n].w, ctx->net[n].g, s));
         return KNERF_OK;
     }
-    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, s));
+    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, ctx->si.trunk_params, s));
     return KNERF_OK;
 }
 
@@ -356,8 +364,8 @@ int wgrad_group_for(knerf_ctx* ctx, int n_rays, int n_chunks) {
     const double budget = ctx->wgrad_group_gb;
     if (budget <= 0 || ctx->wgrad_group_max <= 1) return memo(1);
     const int Nc = ctx->cfg.n_coarse, Na = Nc + ctx->cfg.n_fine;
-    const double per_chunk = (double)(saved_region_bytes(tiles_for((long long)n_rays * Nc), kActBlocks) + saved_region_bytes(tiles_for((long long)n_rays * Nc), kMaskBlocks) +
-                                      saved_region_bytes(tiles_for((long long)n_rays * Nc), kDzBlocks));   // one coarse region
+    const double per_chunk = (double)(saved_region_bytes(tiles_for((long long)n_rays * Nc), ctx->si.act_blocks) + saved_region_bytes(tiles_for((long long)n_rays * Nc), ctx->si.mask_blocks) +
+                                      saved_region_bytes(tiles_for((long long)n_rays * Nc), ctx->si.dz_blocks));   // one coarse region
     (void)Na;
     size_t free_b = 0, total_b = 0;
     double avail = budget * 1e9;
@@ -406,14 +414,19 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         return fail(nullptr, KNERF_ERR_NODEVICE, std::string("libknerf_hip is built for gfx950 only; device is ") + prop.gcnArchName);
     ctx = new knerf_ctx();
     ctx->cfg = *cfg;
-    ctx->generic = !gen::is_default_shape(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir) ||
-                   (cfg->flags & KNERF_FLAG_FORCE_GENERIC) != 0;       // the flag lets tests run the default shape through both paths
+    // the fused kernels cover the trunk shapes of layout.h KNERF_FUSED_SHAPES at width 256 with the reference's encodings; everything
+    // else -- and, for tests, any shape under KNERF_FLAG_FORCE_GENERIC -- runs on the general-shape kernels
+    const int sid = (cfg->dense_units == kUnits && cfg->pos_emb_xyz == kLx && cfg->pos_emb_dir == kLd) ? fused_shape_id(cfg->n_layers, cfg->skip_layer) : -1;
+    ctx->generic = sid < 0 || (cfg->flags & KNERF_FLAG_FORCE_GENERIC) != 0;
     if (ctx->generic) {
         ctx->gplan = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
         ctx->n_params = ctx->gplan.n_params;
+    } else {
+        ctx->shape = sid; ctx->si = shape_info(sid); ctx->n_params = ctx->si.param_count;
     }
+    for (int j = 0; j < ctx->si.n_jobs; ++j) ctx->wgrad_cost[j] = default_wgrad_cost(ctx->si.job_kind[j]);
     const size_t NP = (size_t)ctx->n_params;
-    const Tables& ht = host_tables();
+    const Tables& ht = host_tables(ctx->shape);
     ctx->tab.host = ht.host; ctx->tab.wgrad = ht.wgrad; ctx->tab.wgrad_off = ht.wgrad_off;
     auto up = [&](int*& dptr, const std::vector<int32_t>& v) -> hipError_t {
         hipError_t e = hipMalloc(&dptr, v.size() * sizeof(int32_t));
@@ -453,7 +466,7 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(hipMalloc(&ctx->loss_tmp, 2 * sizeof(float)));
     for (int n = 0; n < 2; ++n) {
         Net& N = ctx->net[n];
-        const size_t NW = ctx->generic ? NP : (size_t)kExtParamCount;          // fused path: parameters + composed head (layout.h)
+        const size_t NW = ctx->generic ? NP : (size_t)ctx->si.ext_param_count;  // fused path: parameters + composed head (layout.h)
         CREATECHK(hipMalloc(&N.w, NW * sizeof(float)));
         CREATECHK(hipMalloc(&N.m, NP * sizeof(float)));
         CREATECHK(hipMalloc(&N.v, NP * sizeof(float)));
@@ -470,12 +483,12 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
             CREATECHK(hipMalloc(&ctx->gnet[n].gaux, gen::aux_floats(ctx->gplan) * sizeof(float)));
             CREATECHK(hipMemset(ctx->gnet[n].gaux, 0, gen::aux_floats(ctx->gplan) * sizeof(float)));
         }
-        CREATECHK(hipMalloc(&N.fwd_stream, kFwdStreamBytes));
-        CREATECHK(hipMalloc(&N.bwd_stream, kBwdStreamBytes));
-        CREATECHK(hipMemset(N.fwd_stream, 0, kFwdStreamBytes));
-        CREATECHK(hipMemset(N.bwd_stream, 0, kBwdStreamBytes));
-        CREATECHK(hipMalloc(&N.bias, kFwdBiasTiles * 32 * sizeof(float)));
-        CREATECHK(hipMemset(N.bias, 0, kFwdBiasTiles * 32 * sizeof(float)));
+        CREATECHK(hipMalloc(&N.fwd_stream, stream_bytes(ctx->si.fwd_blocks)));
+        CREATECHK(hipMalloc(&N.bwd_stream, stream_bytes(ctx->si.bwd_blocks)));
+        CREATECHK(hipMemset(N.fwd_stream, 0, stream_bytes(ctx->si.fwd_blocks)));
+        CREATECHK(hipMemset(N.bwd_stream, 0, stream_bytes(ctx->si.bwd_blocks)));
+        CREATECHK(hipMalloc(&N.bias, ctx->si.fwd_bias_tiles * 32 * sizeof(float)));
+        CREATECHK(hipMemset(N.bias, 0, ctx->si.fwd_bias_tiles * 32 * sizeof(float)));
     }
 #undef CREATECHK
     *out = ctx;
@@ -698,7 +711,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         a.lr_t = ctx->d_lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
     }
-    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, s));      // both nets' heads in one launch
+    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, ctx->si.trunk_params, s));      // both nets' heads in one launch
     for (int n = 0; n < 2; ++n)
         if (int r = repack(ctx, n, s, false)) return r;
     HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, ctx->d_step, ctx->d_lr_t, AdamHyper{ctx->cfg.lr, ctx->cfg.beta1, ctx->cfg.beta2}, s));
@@ -740,9 +753,9 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
     } else if (n == "wgrad_group_gb") {
         if (value < 0) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_gb: >= 0");
         ctx->wgrad_group_gb = value; ctx->group_cache = 0;
-    } else if (n.rfind("wgrad_cost", 0) == 0 && n.size() == 11 && n[10] >= '0' && n[10] < '0' + kWgradJobs) {
+    } else if (n.rfind("wgrad_cost", 0) == 0 && n.size() >= 11 && n.size() <= 12 && std::atoi(n.c_str() + 10) < ctx->si.n_jobs && n[10] >= '0' && n[10] <= '9') {
         if (value < 0 || value > 1e6) return fail(ctx, KNERF_ERR_INVALID, "wgrad_cost: 0..1e6");
-        ctx->wgrad_cost[n[10] - '0'] = (int)value; ctx->plan_dirty = true;
+        ctx->wgrad_cost[std::atoi(n.c_str() + 10)] = (int)value; ctx->plan_dirty = true;
     } else {
         return fail(ctx, KNERF_ERR_INVALID, "unknown option '" + n + "'");
     }
@@ -759,7 +772,8 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
     else if (n == "wgrad_group") *value = ctx->ws_train ? ctx->ws_group : 0;            // chunks per coarse wgrad launch of the current workspaces
     else if (n == "general_shape_path") *value = ctx->generic;
-    else if (n.rfind("wgrad_cost", 0) == 0 && n.size() == 11 && n[10] >= '0' && n[10] < '0' + kWgradJobs) *value = ctx->wgrad_cost[n[10] - '0'];
+    else if (n.rfind("wgrad_cost", 0) == 0 && n.size() >= 11 && n.size() <= 12 && n[10] >= '0' && n[10] <= '9' && std::atoi(n.c_str() + 10) < ctx->si.n_jobs)
+        *value = ctx->wgrad_cost[std::atoi(n.c_str() + 10)];
     else return fail(ctx, KNERF_ERR_INVALID, "unknown option '" + n + "'");
     return KNERF_OK;
 }

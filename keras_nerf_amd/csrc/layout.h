@@ -4,8 +4,8 @@
 // knerf_debug_* entry points, where a NumPy lane-level model of v_mfma_f32_32x32x16_bf16 replays the kernels'
 // dataflow against the oracle.  Everything the kernels assume about operand order lives here, once.
 //
-// Architecture covered: NeRFMLP(n_layers=8, dense_units=256, skip_layer=4) with 63-d / 27-d encodings
-// (reference keras_nerf/model/nerf/mlp.py:5-50, nerf.py:118-130).  Other shapes are rejected by knerf_create.
+// Architecture covered: NeRFMLP(n_layers, dense_units=256, skip_layer) with 63-d / 27-d encodings (reference
+// keras_nerf/model/nerf/mlp.py:5-50, nerf.py:118-130), see Shape below; the reference's default is Shape<8, 4>.
 //
 // MFMA 32x32x16 bf16 operand maps (gfx950):
 //   A: lane l (r = l&31, h = l>>5) element j holds A[row r][k = 8h+j]
@@ -25,42 +25,132 @@ namespace knerf {
 constexpr int kUnits = 256;
 constexpr int kLx = 10, kLd = 4;
 constexpr int kXyzDim = 63, kDirDim = 27;
-constexpr int kNumTensors = 24;
 
-// ---- flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias
+// ---- trunk shape ---------------------------------------------------------------------------------------------------------
+// The fused kernels cover NeRFMLP(n_layers = NL, dense_units = 256, skip_layer = SK) with 63-d / 27-d encodings (mlp.py:5-50):
+// layer l (l >= 2) takes [h_{l-1} ; xyz_enc] when the reference concatenated behind layer l-1, i.e. (l-1) % SK == 0 (mlp.py:36-38).
+// Shape<8, 4> is the reference's default and the shape every number in DESIGN.md is quoted for; the other instantiations
+// (knerf_api.hip kFusedShapes) share every line of kernel code with it.  Not covered (-> general-shape path, generic.hip): other
+// widths or encodings, fewer than 3 layers, a concat behind the LAST layer (the head would take [h ; xyz_enc ; dir_enc]).
+template <int NL_, int SK_>
+struct Shape {
+    static constexpr int NL = NL_, SK = SK_;
+    static constexpr bool concat_in(int l) { return l >= 2 && l < NL && (l - 1) % SK == 0; }
+    static constexpr bool kConcatBehindLast = (NL - 1) % SK == 0 && NL - 1 > 0;
+    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast;
+    static constexpr int first_concat() { for (int l = 2; l < NL; ++l) if (concat_in(l)) return l; return 0; }
+    static constexpr int kFirstConcat = first_concat();
+    // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias
+    static constexpr int fan_in(int l) { return l == 0 ? kXyzDim : (concat_in(l) ? kUnits + kXyzDim : kUnits); }
+    static constexpr int trunk_params() { int n = 0; for (int l = 0; l < NL; ++l) n += fan_in(l) * kUnits + kUnits; return n; }
+    static constexpr int kTrunkParams = trunk_params();      // = offset of the sigma kernel
+    static constexpr int kParamCount = kTrunkParams + (256 + 1) + (256 * 256 + 256) + (283 * 128 + 128) + (128 * 3 + 3);
+    // forward stream: stage st = trunk layer st (st < NL) or the head (st == NL); order: stage, out tile, k-step
+    static constexpr int kFwdStages = NL + 1;
+    static constexpr int fwd_nks(int st) { return st == 0 ? 4 : st == NL ? 18 : (concat_in(st) ? 20 : 16); }
+    static constexpr int fwd_not(int st) { return st == NL ? 1 : 8; }
+    static constexpr int fwd_b0(int st) { int n = 0; for (int q = 0; q < st; ++q) n += fwd_nks(q) * fwd_not(q); return n; }
+    static constexpr int kFwdBlocks = fwd_b0(NL + 1);
+    static constexpr int kFwdBiasTiles = 8 * NL + 1;         // tiles of 32 fp32: 8 per trunk layer, 1 for the head
+    // backward (dgrad) stream: stage 0 = the head (1 k-step x 8 tiles), stage q = layer NL-q (16 x 8), q = 1 .. NL-1
+    static constexpr int kBwdStages = NL;
+    static constexpr int bwd_b0(int st) { return st == 0 ? 0 : 8 + (st - 1) * 128; }
+    static constexpr int kBwdBlocks = bwd_b0(NL);
+    // saved runs (see "saved tensors" below).  act: h1 .. h_{NL-1} (16 blocks each; h0 is recomputed), the 4 enc blocks directly
+    // behind h_{c-1} for the FIRST concat layer c (its weight-gradient job then reads ONE contiguous range; later concat layers read
+    // two), in front of everything when there is no concat layer, and the 2 dir blocks at the end, directly behind h_{NL-1} (the
+    // head job's range).  dz: dz_0 .. dz_{NL-1} (16 each), dz_head (2).
+    static constexpr int kActEnc = kFirstConcat ? 16 * (kFirstConcat - 1) : 0;
+    static constexpr int act_h(int l) { return 16 * (l - 1) + ((kFirstConcat == 0 || l >= kFirstConcat) ? 4 : 0); }   // l = 1 .. NL-1
+    static constexpr int kActDir = 16 * (NL - 1) + 4, kActBlocks = kActDir + 2;
+    static constexpr int kDzHead = 16 * NL, kDzBlocks = kDzHead + 2;
+    // dz of the last trunk layer is mask * (H dz_head) with 4 input channels: its weight-gradient job recomputes it (wgrad_body.h
+    // wgrad_last_recompute) and dgrad does not write it -- unless that layer takes [h ; xyz_enc] (then the job is the plain
+    // two-range one and dgrad writes the block run like any other)
+    static constexpr bool kSaveLastDz = concat_in(NL - 1);
+    static constexpr int kMaskBlocks = NL;                   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
+    static constexpr int kWgradJobs = NL + 1, kHeadJob = NL; // job j = trunk layer j; the last one = the head
+    // collapsed head (below): 256 h features + 32 dir slots (27 real)
+    static constexpr int kHeadRows = 288;
+    static constexpr int kHeadOff = kParamCount;             // H[row][c], c = 0..2 rgb, 3 sigma
+    static constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
+    static constexpr int kExtParamCount = kHeadBiasOff + 4;  // floats in a net's weight buffer
+    static constexpr int kAuxBase = kParamCount;             // wgrad destination indices >= kAuxBase address the aux buffer
+    static_assert(kSupported, "trunk shape not covered by the fused kernels");
+};
+using DefaultShape = Shape<8, 4>;
+// The trunk shapes the library is built for, X(index, n_layers, skip_layer); index 0 is the reference's default.  Every entry costs
+// one more instantiation of the three big kernels: build.py compiles mlp_fwd / mlp_bwd / wgrad once per entry with
+// -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
+// instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
+#define KNERF_FUSED_SHAPES(X) X(0, 8, 4) X(1, 8, 2) X(2, 6, 3) X(3, 4, 2) X(4, 12, 4)
+constexpr int kNumFusedShapes = 5;
+// index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
+constexpr int fused_shape_id(int n_layers, int skip_layer) {
+#define KNERF_X(I, NL, SK) if (n_layers == NL && skip_layer == SK) return I;
+    KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+    return -1;
+}
+// KNERF_PICK(I, DEF, EXT) -> DEF when this translation unit owns shape I (no slicing: every shape), EXT otherwise
+#define KNERF_SLICE_OWNS(I) (!defined(KNERF_SHAPE_SLICE) || KNERF_SHAPE_SLICE == I)
+#if KNERF_SLICE_OWNS(0)
+#define KNERF_SLICE_0(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_0(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(1)
+#define KNERF_SLICE_1(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_1(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(2)
+#define KNERF_SLICE_2(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_2(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(3)
+#define KNERF_SLICE_3(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_3(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(4)
+#define KNERF_SLICE_4(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_4(DEF, EXT) EXT
+#endif
+#define KNERF_PICK(I, DEF, EXT) KNERF_SLICE_##I(DEF, EXT)
+#define KNERF_HAS_DISPATCH KNERF_SLICE_OWNS(0)
+constexpr int kParamCount = DefaultShape::kParamCount;      // 595,844: knerf_param_count()
+static_assert(kParamCount == 595844 && DefaultShape::kFwdBlocks == 978 && DefaultShape::kBwdBlocks == 904 && DefaultShape::kActBlocks == 118 &&
+              DefaultShape::kActEnc == 64 && DefaultShape::act_h(5) == 68 && DefaultShape::kDzBlocks == 130, "the default shape's layout");
+
 struct TensorInfo { int offset, rows, cols; };  // bias: rows = 1
+template <class S>
 inline std::vector<TensorInfo> tensor_table() {
-    const int fi[12] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
-    const int fo[12] = {256, 256, 256, 256, 256, 256, 256, 256, 1, 256, 128, 3};
     std::vector<TensorInfo> t;
     int off = 0;
-    for (int l = 0; l < 12; ++l) {
-        t.push_back({off, fi[l], fo[l]}); off += fi[l] * fo[l];
-        t.push_back({off, 1, fo[l]});     off += fo[l];
-    }
+    auto add = [&](int fi, int fo) { t.push_back({off, fi, fo}); off += fi * fo; t.push_back({off, 1, fo}); off += fo; };
+    for (int l = 0; l < S::NL; ++l) add(S::fan_in(l), kUnits);
+    add(256, 1); add(256, 256); add(283, 128); add(128, 3);       // sigma, features, rgb_features, rgb
     return t;
 }
-constexpr int kParamCount = 595844;
-enum Layer { L0 = 0, L1, L2, L3, L4, L5, L6, L7, LSIG, LFEAT, LRF, LRGB };
+// index of a tensor in the table: trunk layer l -> l; then sigma, features, rgb_features, rgb
+template <class S> constexpr int LSIG = S::NL;
 
 // ---- collapsed head ------------------------------------------------------------------------------------------------
 // In this reference `features` and `rgb_features` are LINEAR Dense layers (mlp.py:21-24,44-46: no activation argument), so
-// everything between the trunk output h7 and the sigmoid is one affine map of (h7, dir_enc):
-//   rgb_pre = h7 (W_f W_r1 W_c) + dir_enc (W_r2 W_c) + ((b_f W_r1 + b_r) W_c + b_c),   sigma_pre = h7 w_s + b_s
+// everything between the trunk output h and the sigmoid is one affine map of (h, dir_enc):
+//   rgb_pre = h (W_f W_r1 W_c) + dir_enc (W_r2 W_c) + ((b_f W_r1 + b_r) W_c + b_c),   sigma_pre = h w_s + b_s
 // (W_r1 = rows 0..255 of the rgb_features kernel, W_r2 = its 27 dir rows).  The kernels evaluate that map as ONE out tile
 // with 4 real rows (r, g, b, sigma) instead of three dense stages (144 + 72 + 8 MFMAs per 32 samples -> 18), and its
 // backward as one 4-channel dZ.  The 283x4 "head" matrix H and its bias are derived from the fp32 master weights after
-// every weight change (optim.hip head_compose) and live behind the 595,844 parameters in the same buffer, so the packing
-// tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
-// the same identity) from M = [h7 ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
+// every weight change (optim.hip head_compose) and live behind the parameters in the same buffer (Shape::kHeadOff), so the
+// packing tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
+// the same identity) from M = [h ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
 // in an auxiliary buffer (optim.hip head_expand).
-constexpr int kHeadRows = 288;                       // 256 h7 features + 32 dir slots (27 real)
-constexpr int kHeadOff = kParamCount;                // H[row][c], c = 0..2 rgb, 3 sigma
-constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
-constexpr int kExtParamCount = kHeadBiasOff + 4;     // floats in a net's weight buffer
-// auxiliary gradient buffer of one net: M[row][c] (row = 0..255 h7, 256..282 dir; c = 0..2), then s[c]
+// auxiliary gradient buffer of one net: M[row][c] (row = 0..255 h, 256..282 dir; c = 0..2), then s[c]
 constexpr int kAuxM = 0, kAuxS = 283 * 3, kAuxCount = 864;
-constexpr int kAuxBase = kParamCount;                // wgrad destination indices >= kAuxBase address the aux buffer
 
 // ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
 // encoded position: 64 slots (4 k-steps).  half 0: x, y, sin(2^i p_c);  half 1: z, pad, cos(2^i p_c).
@@ -75,14 +165,6 @@ inline int enc_feature(int q, int h, int j, int L) {
 // hidden activations: slot (q,h,j) of a 256-wide tensor (16 k-steps)
 inline int hid_feature(int q, int h, int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-// ---- description of one fused "dense" stage: list of input k-steps and output tiles
-struct KStep { int kind; int q; };   // kind: 0 hidden(prev out), 1 enc, 2 dir, 3 rgb-channels(bwd), 4 sigma(bwd); q = k-step inside that tensor
-struct Stage {
-    std::vector<KStep> ks;
-    int n_ot;                 // output tiles of 32 rows
-    // element source: param index for (k-step, half, j, out row) or -1
-};
-
 // index into the flat param buffer for kernel tensor `layer` at [in_row][out_col], -1 when out of range
 inline int kidx(const std::vector<TensorInfo>& tt, int layer, int in_row, int out_col) {
     const TensorInfo& k = tt[2 * layer];
@@ -96,65 +178,51 @@ inline int bidx(const std::vector<TensorInfo>& tt, int layer, int out_col) {
 }
 
 // =====================================================================================================
-// forward stream: 978 blocks of 1 KiB (64 lanes x 8 bf16).  Order: stage, out tile, k-step.
-// stage list: L0 | L1..L4 | L5 (16 hidden + 4 enc k-steps) | L6 L7 | HEAD (16 h7 + 2 dir k-steps, 1 tile: rows r,g,b,sigma)
+// forward stream: 1 KiB blocks (64 lanes x 8 bf16).  Order: stage, out tile, k-step.  Default shape, 978 blocks:
+// L0 | L1..L4 | L5 (16 hidden + 4 enc k-steps) | L6 L7 | HEAD (16 h7 + 2 dir k-steps, 1 tile: rows r,g,b,sigma)
 // =====================================================================================================
-constexpr int kFwdBlocks = 32 + 4 * 128 + 160 + 2 * 128 + 18;   // 978
-constexpr int kFwdBiasTiles = 8 * 8 + 1;                         // 65 tiles of 32 fp32
-
 struct PackTables {
     std::vector<int32_t> fwd;       // kFwdBlocks*512 entries: index into the extended weight buffer or -1
     std::vector<int32_t> fwd_bias;  // kFwdBiasTiles*32
     std::vector<int32_t> bwd;       // kBwdBlocks*512
 };
 
-// row of the head matrix for k-step ks of the HEAD stage: h7 features, then the dir encoding slots
+// row of the head matrix for k-step ks of the HEAD stage: h features, then the dir encoding slots
 inline int head_in_row(int ks, int h, int j) {
     if (ks < 16) return hid_feature(ks, h, j);
     const int e = enc_feature(ks - 16, h, j, kLd);
     return e < 0 ? -1 : 256 + e;
 }
-inline int hidx(int row, int c) { return (row < 0 || row >= 283 || c < 0 || c > 3) ? -1 : kHeadOff + row * 4 + c; }
+template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= 283 || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
 
 // input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
+template <class S>
 inline int fwd_in_row(int st, int ks, int h, int j) {
-    switch (st) {
-        case 0: return enc_feature(ks, h, j, kLx);                       // layer_0: 63 inputs in 4 k-steps
-        case 5: return ks < 16 ? hid_feature(ks, h, j)                   // layer_5: [h(256), xyz_enc(63)] (mlp.py:36-38)
-                               : (enc_feature(ks - 16, h, j, kLx) < 0 ? -1 : 256 + enc_feature(ks - 16, h, j, kLx));
-        case 8: return head_in_row(ks, h, j);
-        default: return hid_feature(ks, h, j);                           // 256-wide
-    }
+    if (st == 0) return enc_feature(ks, h, j, kLx);                          // layer_0: 63 inputs in 4 k-steps
+    if (st == S::NL) return head_in_row(ks, h, j);
+    if (ks < 16) return hid_feature(ks, h, j);                               // 256-wide
+    const int e = enc_feature(ks - 16, h, j, kLx);                           // concat layer: [h(256), xyz_enc(63)] (mlp.py:36-38)
+    return e < 0 ? -1 : 256 + e;
 }
-struct FwdStage { int layer; int nks; int n_ot; };
-// stage index: 0..7 trunk, 8 = HEAD (layer = -1: addresses the head matrix)
-inline FwdStage fwd_stage(int st) {
-    switch (st) {
-        case 0: return {L0, 4, 8};
-        case 5: return {L5, 20, 8};
-        case 8: return {-1, 18, 1};
-        default: return {st, 16, 8};
-    }
-}
-constexpr int kFwdStages = 9;
 
+template <class S>
 inline void build_fwd(PackTables& pt) {
-    auto tt = tensor_table();
-    pt.fwd.assign((size_t)kFwdBlocks * 512, -1);
-    pt.fwd_bias.assign((size_t)kFwdBiasTiles * 32, -1);
+    auto tt = tensor_table<S>();
+    pt.fwd.assign((size_t)S::kFwdBlocks * 512, -1);
+    pt.fwd_bias.assign((size_t)S::kFwdBiasTiles * 32, -1);
     size_t blk = 0; int btile = 0;
-    for (int st = 0; st < kFwdStages; ++st) {
-        FwdStage s = fwd_stage(st);
-        for (int ot = 0; ot < s.n_ot; ++ot) {
+    for (int st = 0; st < S::kFwdStages; ++st) {
+        const bool head = st == S::NL;
+        for (int ot = 0; ot < S::fwd_not(st); ++ot) {
             for (int r = 0; r < 32; ++r)
-                pt.fwd_bias[(size_t)btile * 32 + r] = s.layer < 0 ? (r < 4 ? kHeadBiasOff + r : -1) : bidx(tt, s.layer, 32 * ot + r);
+                pt.fwd_bias[(size_t)btile * 32 + r] = head ? (r < 4 ? S::kHeadBiasOff + r : -1) : bidx(tt, st, 32 * ot + r);
             ++btile;
-            for (int ks = 0; ks < s.nks; ++ks, ++blk) {
+            for (int ks = 0; ks < S::fwd_nks(st); ++ks, ++blk) {
                 for (int l = 0; l < 64; ++l) {
                     int r = l & 31, h = l >> 5;
                     for (int j = 0; j < 8; ++j)
-                        pt.fwd[blk * 512 + l * 8 + j] = s.layer < 0 ? hidx(fwd_in_row(st, ks, h, j), r)
-                                                                     : kidx(tt, s.layer, fwd_in_row(st, ks, h, j), 32 * ot + r);
+                        pt.fwd[blk * 512 + l * 8 + j] = head ? hidx<S>(fwd_in_row<S>(st, ks, h, j), r)
+                                                             : kidx(tt, st, fwd_in_row<S>(st, ks, h, j), 32 * ot + r);
                 }
             }
         }
@@ -164,27 +232,24 @@ inline void build_fwd(PackTables& pt) {
 // =====================================================================================================
 // backward (dgrad) stream: A = W (rows = the layer's INPUT features, k = its OUTPUT features).
 // stage order (reverse of forward):
-//   B0: dz_head (1 k-step: channels r,g,b,sigma at half 0, j<4) -> dh7 (8 tiles)    H[h7 feature][channel]
-//   B1..B7: dz_l (16) -> dh_{l-1} (8 tiles) for l = 7,6,5,4,3,2,1   (layer 5: rows 0..255 of its 319)
+//   B0: dz_head (1 k-step: channels r,g,b,sigma at half 0, j<4) -> dh_{NL-1} (8 tiles)    H[h feature][channel]
+//   Bq: dz_l (16) -> dh_{l-1} (8 tiles) for l = NL-q, q = 1 .. NL-1   (a concat layer: rows 0..255 of its 319)
 // =====================================================================================================
-constexpr int kBwdBlocks = 8 + 7 * 128;   // 904
-constexpr int kBwdStages = 8;
-struct BwdStage { int nks; int n_ot; };
-inline BwdStage bwd_stage(int st) { return st == 0 ? BwdStage{1, 8} : BwdStage{16, 8}; }
+template <class S>
 inline void build_bwd(PackTables& pt) {
-    auto tt = tensor_table();
-    pt.bwd.assign((size_t)kBwdBlocks * 512, -1);
+    auto tt = tensor_table<S>();
+    pt.bwd.assign((size_t)S::kBwdBlocks * 512, -1);
     size_t blk = 0;
-    for (int st = 0; st < kBwdStages; ++st) {
-        BwdStage s = bwd_stage(st);
-        for (int ot = 0; ot < s.n_ot; ++ot)
-            for (int ks = 0; ks < s.nks; ++ks, ++blk)
+    for (int st = 0; st < S::kBwdStages; ++st) {
+        const int nks = st == 0 ? 1 : 16;
+        for (int ot = 0; ot < 8; ++ot)
+            for (int ks = 0; ks < nks; ++ks, ++blk)
                 for (int l = 0; l < 64; ++l) {
                     int r = l & 31, h = l >> 5, row = 32 * ot + r;   // row = input feature of the layer
                     for (int j = 0; j < 8; ++j) {
                         int v = -1;
-                        if (st == 0) v = hidx(row, h == 0 && j < 4 ? j : -1);
-                        else v = kidx(tt, L7 - (st - 1), row, hid_feature(ks, h, j));
+                        if (st == 0) v = hidx<S>(row, h == 0 && j < 4 ? j : -1);
+                        else v = kidx(tt, S::NL - st, row, hid_feature(ks, h, j));
                         pt.bwd[blk * 512 + l * 8 + j] = v;
                     }
                 }
@@ -196,19 +261,16 @@ inline void build_bwd(PackTables& pt) {
 // stores its 8 bf16 at byte offset saved_off(b, h, s) = (2*(s ^ 4*(b&1)) + h) * 16: the two feature halves of a
 // sample are adjacent (32 B per sample) and odd blocks rotate their sample quads, which makes the wgrad kernel's
 // ds_read_b64_tr_b16 transposed reads bank-conflict free while the store stays one coalesced 1 KiB write.
-// forward "act" run (118 blocks):  h1 h2 h3 h4 enc h5 h6 h7 dir   -- h0 is NOT saved: layer_0 has only 64 input slots, so the
+// forward "act" run (default shape, 118 blocks):  h1 h2 h3 h4 enc h5 h6 h7 dir   -- h0 is NOT saved: layer_0 has only 64 input slots, so the
 //   layer_1 wgrad job recomputes h0 = relu(W_0 enc + b_0) from the 4 enc blocks (4 MFMAs per wave and tile) instead of reading
 //   16 blocks that the forward would have had to write (wgrad_body.h wgrad_l1_recompute)
-// backward "dz" run  (130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero);
+// backward "dz" run  (default shape, 130 blocks): dz0 .. dz7  dz_head(2: channels r,g,b,sigma in the first block, the second stays zero);
 //   the 16 blocks of dz7 are RESERVED BUT NEVER WRITTEN: dz7 = mask7 * (H dz_head) has 4 input channels, so the layer_7 wgrad
-//   job recomputes its 32-column strip with one MFMA per wave and tile (wgrad_body.h wgrad_l7_recompute)
+//   job recomputes its 32-column strip with one MFMA per wave and tile (wgrad_body.h wgrad_last_recompute)
 // so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5, head: act[h7..dir] x dz_head.
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
-constexpr int kActH1 = 0, kActH4 = 48, kActEnc = 64, kActH5 = 68, kActH7 = 100, kActDir = 116, kActBlocks = 118;
-constexpr int act_h(int l) { return l <= 4 ? 16 * (l - 1) : 68 + 16 * (l - 5); }      // l = 1..7 (h0 is not saved)
-constexpr int kDzHead = 128, kDzBlocks = 130;
-constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
+// (block offsets of the runs: Shape::kActEnc, act_h(l), kActDir, kActBlocks, kDzHead, kDzBlocks, kMaskBlocks)
 // Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
 // own tile at about the same time, so a stride that is a large power of two times a small odd number (e.g. 156 KiB =
 // 2^12 * 39) concentrates those writes on a few memory channels; an odd number of 256-B units spreads them.
@@ -217,73 +279,103 @@ constexpr int kMaskBlocks = 8;   // relu masks: one 1 KiB block per trunk layer 
 #endif
 // KNERF_SAVED_GROUP = G (a power of two, default 1): G consecutive tiles form a group that is stored BLOCK-major -- block b of the
 // group's G tiles is one contiguous G KiB piece, so the 8 waves of a chain workgroup (G = 8) write 8 KiB per block instead of
-// eight 1 KiB pieces 118 KiB apart.  G = 1 is the tile-major layout described above.  (r03 A/B experiment)
+// eight 1 KiB pieces 118 KiB apart.  G = 1 is the tile-major layout described above.  (r03 A/B experiment, DESIGN.md 5.0: no gain.)
 #ifndef KNERF_SAVED_GROUP
 #define KNERF_SAVED_GROUP 1
 #endif
 constexpr int kSavedGroup = KNERF_SAVED_GROUP;
 static_assert(kSavedGroup >= 1 && (kSavedGroup & (kSavedGroup - 1)) == 0, "KNERF_SAVED_GROUP must be a power of two");
 constexpr int kSavedBlockStride = kSavedGroup * 1024;        // bytes between consecutive blocks of one tile
-constexpr size_t kActTileBytes = (size_t)kActBlocks * 1024 + KNERF_TILE_SKEW;      // per-tile footprint at G = 1; G x blocks + skew per group
-constexpr size_t kDzTileBytes = (size_t)kDzBlocks * 1024 + KNERF_TILE_SKEW;
-constexpr size_t kMaskTileBytes = (size_t)kMaskBlocks * 1024 + KNERF_TILE_SKEW;
 constexpr size_t saved_group_bytes(int blocks) { return (size_t)kSavedGroup * blocks * 1024 + KNERF_TILE_SKEW; }
 // byte offset of block 0 of tile `tile` in a saved run of `blocks` blocks per tile
 constexpr size_t saved_tile_off(size_t tile, int blocks) {
     return kSavedGroup == 1 ? tile * ((size_t)blocks * 1024 + KNERF_TILE_SKEW)
                             : (tile / kSavedGroup) * saved_group_bytes(blocks) + (tile % kSavedGroup) * 1024;
 }
-constexpr size_t act_tile_off(size_t tile) { return saved_tile_off(tile, kActBlocks); }
-constexpr size_t dz_tile_off(size_t tile) { return saved_tile_off(tile, kDzBlocks); }
-constexpr size_t mask_tile_off(size_t tile) { return saved_tile_off(tile, kMaskBlocks); }
+template <class S> constexpr size_t act_tile_off(size_t tile) { return saved_tile_off(tile, S::kActBlocks); }
+template <class S> constexpr size_t dz_tile_off(size_t tile) { return saved_tile_off(tile, S::kDzBlocks); }
+template <class S> constexpr size_t mask_tile_off(size_t tile) { return saved_tile_off(tile, S::kMaskBlocks); }
 // bytes of a region of `tiles` tiles (whole groups)
 constexpr size_t saved_region_bytes(size_t tiles, int blocks) { return (tiles + kSavedGroup - 1) / kSavedGroup * saved_group_bytes(blocks); }
 
-// wgrad jobs: dW[in_row][out_col] += sum_s act[s][in] * dz[s][out], db[out_col] += sum_s dz[s][out]
+// wgrad jobs: dW[in_row][out_col] += sum_s act[s][in] * dz[s][out], db[out_col] += sum_s dz[s][out].  Job j = trunk layer j, job NL
+// = the head.  Kinds (wgrad_body.h picks the body): 0 first layer (enc x dz_0), 1 layer_1 with h0 recomputed from enc, 2 plain
+// 256 x 256, 3 concat layer ([h ; enc] x dz: input tiles 0..7 from act_blk, 8..9 from act_blk2), 4 last layer with its dz recomputed,
+// 5 head ([h ; dir] x dz_head).
 struct WgradJob {
-    int act_blk, n_it;    // first act block, number of 32-row input tiles (2 blocks each)
-    int dz_blk, n_ot;     // first dz block, number of 32-col output tiles
-    int layer;            // destination kernel/bias; -1: the head job (sigma column -> LSIG, rgb columns -> aux buffer)
+    int kind;
+    int act_blk, act_blk2, n_it;   // first act block (of input tiles 0..7 / of tiles 8..), number of 32-row input tiles (2 blocks each)
+    int dz_blk, n_ot;              // first dz block, number of 32-col output tiles
+    int layer;                     // destination kernel/bias; -1: the head job (sigma column -> LSIG, rgb columns -> aux buffer)
 };
-constexpr int kWgradJobs = 9;
-constexpr int kHeadJob = 8;
-inline WgradJob wgrad_job(int j) {
-    switch (j) {
-        case 0: return {kActEnc, 2, 0, 8, L0};
-        case 5: return {kActH4, 10, 16 * 5, 8, L5};             // [h4 ; enc]
-        case 8: return {kActH7, 9, kDzHead, 1, -1};             // [h7 ; dir] x (r,g,b,sigma)
-        case 1: return {kActEnc, 8, 16, 8, L1};                 // h0 recomputed from enc; the table rows are h0 features
-        default: return {act_h(j - 1), 8, 16 * j, 8, j};        // layers 2-4, 6, 7
-    }
+template <class S>
+constexpr WgradJob wgrad_job(int j) {
+    if (j == 0) return {0, S::kActEnc, S::kActEnc, 2, 0, 8, 0};
+    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), 9, S::kDzHead, 1, -1};          // [h ; dir] x (r,g,b,sigma): dir sits behind h
+    if (j == 1) return {1, S::kActEnc, S::kActEnc, 8, 16, 8, 1};                                       // the table rows are h0 features
+    if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - 16, 10, 16 * j, 8, j};                // tile 8 + k -> block act_blk2 + 16 + 2k
+    if (j == S::NL - 1) return {4, S::act_h(j - 1), S::act_h(j - 1), 8, 16 * j, 8, j};
+    return {2, S::act_h(j - 1), S::act_h(j - 1), 8, 16 * j, 8, j};
 }
 // in_row of job jb for tile-row index tr (0..32*n_it-1) in *natural tr-read order*: the transposed read un-permutes
 // hidden tensors (row = feature), and presents enc/dir blocks in slot order (q = tr>>4, c16 = tr&15 ->
 // h = (c16>>2)&1, j = 4*(c16>>3) + (c16&3)).
 inline int slot_from_c16_h(int c16) { return (c16 >> 2) & 1; }
 inline int slot_from_c16_j(int c16) { return 4 * (c16 >> 3) + (c16 & 3); }
+template <class S>
 inline int wgrad_in_row(int jb, int tr) {
     auto encrow = [](int tr_, int L) { int q = tr_ >> 4, c = tr_ & 15; return enc_feature(q, slot_from_c16_h(c), slot_from_c16_j(c), L); };
-    switch (jb) {
-        case 0: return encrow(tr, kLx);
-        case 5: return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
-        case 8: return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
-        default: return tr;
-    }
+    const int kind = wgrad_job<S>(jb).kind;
+    if (kind == 0) return encrow(tr, kLx);
+    if (kind == 3) return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
+    if (kind == 5) return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
+    return tr;
 }
 // destination of wgrad output element (tile-row tr, column tc): index into the flat gradient, kAuxBase + index into the
 // aux buffer, or -1; tr == -2 selects the bias row (column sums of dz)
+template <class S>
 inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) {
-    WgradJob J = wgrad_job(jb);
+    const WgradJob J = wgrad_job<S>(jb);
     if (J.layer < 0) {                       // head: columns 0..2 = dz_rgb, 3 = dz_sigma
         if (tc > 3) return -1;
-        if (tr == -2) return tc == 3 ? bidx(tt, LSIG, 0) : kAuxBase + kAuxS + tc;
-        const int row = wgrad_in_row(jb, tr);
+        if (tr == -2) return tc == 3 ? bidx(tt, LSIG<S>, 0) : S::kAuxBase + kAuxS + tc;
+        const int row = wgrad_in_row<S>(jb, tr);
         if (row < 0) return -1;
-        if (tc == 3) return row < 256 ? kidx(tt, LSIG, row, 0) : -1;
-        return kAuxBase + kAuxM + row * 3 + tc;
+        if (tc == 3) return row < 256 ? kidx(tt, LSIG<S>, row, 0) : -1;
+        return S::kAuxBase + kAuxM + row * 3 + tc;
     }
     if (tr == -2) return bidx(tt, J.layer, tc);
-    return kidx(tt, J.layer, wgrad_in_row(jb, tr), tc);
+    return kidx(tt, J.layer, wgrad_in_row<S>(jb, tr), tc);
+}
+
+// ---- run-time view of a shape (host): what knerf_api.hip needs to size buffers and pick instantiations
+struct ShapeInfo {
+    int id, n_layers, skip;
+    int param_count, ext_param_count, trunk_params, head_off, head_bias_off;
+    int fwd_blocks, fwd_bias_tiles, bwd_blocks;
+    int act_blocks, dz_blocks, mask_blocks;
+    int n_jobs;
+    int job_kind[17];
+};
+template <class S>
+inline ShapeInfo make_shape_info(int id) {
+    ShapeInfo i{};
+    i.id = id; i.n_layers = S::NL; i.skip = S::SK;
+    i.param_count = S::kParamCount; i.ext_param_count = S::kExtParamCount; i.trunk_params = S::kTrunkParams;
+    i.head_off = S::kHeadOff; i.head_bias_off = S::kHeadBiasOff;
+    i.fwd_blocks = S::kFwdBlocks; i.fwd_bias_tiles = S::kFwdBiasTiles; i.bwd_blocks = S::kBwdBlocks;
+    i.act_blocks = S::kActBlocks; i.dz_blocks = S::kDzBlocks; i.mask_blocks = S::kMaskBlocks;
+    i.n_jobs = S::kWgradJobs;
+    for (int j = 0; j < S::kWgradJobs; ++j) i.job_kind[j] = wgrad_job<S>(j).kind;
+    return i;
+}
+inline const ShapeInfo& shape_info(int id) {
+    static const ShapeInfo all[kNumFusedShapes] = {
+#define KNERF_X(I, NL, SK) make_shape_info<Shape<NL, SK>>(I),
+        KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+    };
+    return all[id >= 0 && id < kNumFusedShapes ? id : 0];
 }
 
 }  // namespace knerf

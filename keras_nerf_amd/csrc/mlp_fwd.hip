@@ -49,38 +49,21 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
 }
 
-// store schedule of the SAVE variant: 4 enc blocks up front, 2 blocks per out tile (none for layer_0) and one mask block per trunk layer, the
-// 2 dir blocks right behind layer_7 (counted as that stage's end-of-stage stores); the head stage stores nothing
-#ifndef KNERF_STORE_BURST
-#define KNERF_STORE_BURST 2      // saved blocks written per burst: 2 = behind every out tile; 4 / 8 / 16 = every 2nd / 4th / 8th tile
-#endif
-constexpr int kBurstTiles = KNERF_STORE_BURST / 2;          // out tiles per burst
-// StoreSched models a burst as a pseudo-stage of kBurstTiles out tiles whose stores all come at its end
-#if KNERF_STORE_BURST == 2
-constexpr StoreSched<9> kFwdStores = {{{0, 4, 8, 0, 1, 0}, {32, 16, 8, 2, 1, 0}, {160, 16, 8, 2, 1, 0}, {288, 16, 8, 2, 1, 0},
-                                       {416, 16, 8, 2, 1, 0}, {544, 20, 8, 2, 1, 0}, {704, 16, 8, 2, 1, 0}, {832, 16, 8, 2, 3, 0},
-                                       {960, 18, 1, 0, 0, 0}}, 4};
-constexpr int kFwdStoreStages = 9;
-#else
-constexpr int kParts = 8 / kBurstTiles;                      // bursts per trunk stage
-constexpr int kFwdStoreStages = 8 * kParts + 1;
-constexpr StoreSched<kFwdStoreStages> make_fwd_burst_sched() {
-    StoreSched<kFwdStoreStages> s{};
-    const int b0[8] = {0, 32, 160, 288, 416, 544, 704, 832}, nks[8] = {4, 16, 16, 16, 16, 20, 16, 16};
-    for (int l = 0; l < 8; ++l)
-        for (int p = 0; p < kParts; ++p) {
-            const int extra = p == kParts - 1 ? (l == 7 ? 3 : 1) : 0;      // mask block (+ the 2 dir blocks behind layer_7)
-            s.st[l * kParts + p] = StoreStage{b0[l] + p * kBurstTiles * nks[l], nks[l], kBurstTiles, 0, (l == 0 ? 0 : 2 * kBurstTiles) + extra, 0};
-        }
-    s.st[8 * kParts] = StoreStage{960, 18, 1, 0, 0, 0};
-    s.initial = 4;
-    return s;
+// store schedule of the SAVE variant: 4 enc blocks up front; per trunk layer 2 blocks behind every out tile (none for layer_0: h0
+// is not saved) and one mask block at its end, the 2 dir blocks right behind the last trunk layer (counted as that stage's
+// end-of-stage stores); the head stage stores nothing
+template <class S>
+constexpr StoreSched<S::kFwdStages> make_fwd_stores() {
+    StoreSched<S::kFwdStages> t{};
+    for (int st = 0; st < S::kFwdStages; ++st)
+        t.st[st] = StoreStage{S::fwd_b0(st), S::fwd_nks(st), S::fwd_not(st), (st == 0 || st == S::NL) ? 0 : 2,
+                              st == S::NL ? 0 : (st == S::NL - 1 ? 3 : 1), 0};
+    t.initial = 4;
+    return t;
 }
-constexpr StoreSched<kFwdStoreStages> kFwdStores = make_fwd_burst_sched();
-#endif
 constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
-struct FwdWaitSave { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<kFwdStoreStages, kFwdBlocks>(kFwdStores); };
-struct FwdWaitPlain { static constexpr WaitTable<kFwdBlocks> tab = make_wait_table<1, kFwdBlocks>(kNoStores); };
+template <class S> struct FwdWaitSave { static constexpr WaitTable<S::kFwdBlocks> tab = make_wait_table<S::kFwdStages, S::kFwdBlocks>(make_fwd_stores<S>()); };
+template <class S> struct FwdWaitPlain { static constexpr WaitTable<S::kFwdBlocks> tab = make_wait_table<1, S::kFwdBlocks>(kNoStores); };
 
 #ifdef KNERF_FWD_STAMPS     // diagnostic build only (tools/fwd_stamps.py): per-workgroup s_memtime at entry / first MFMA / exit + HW_ID of the fine inference launch
 __device__ unsigned long long g_fwd_stamps[4096 * 4];
@@ -94,8 +77,8 @@ __device__ __forceinline__ unsigned long long fwd_stamp() {
 #define FWD_STAMP(v)
 #endif
 
-// NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries
-template <bool SAVE, int NET>
+// NET only names the instantiation (0 = coarse pass, 1 = fine pass) for profiler summaries; S = the trunk shape (layout.h)
+template <class S, bool SAVE, int NET>
 __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     FWD_STAMP(st0);
@@ -107,7 +90,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 
     // biases -> LDS (plain loads, before any LDS-DMA is in flight; requesting the ring's first pages ahead of these loads shortens
     // the measured ramp by 0.3 us per workgroup and lengthens the body by 0.15: not worth a second ordering rule)
-    for (int i = tid; i < kFwdBiasTiles * 32; i += kThreads) bias_lds[i] = a.bias[i];
+    for (int i = tid; i < S::kFwdBiasTiles * 32; i += kThreads) bias_lds[i] = a.bias[i];
 
     const long long tile = (long long)blockIdx.x * kWaves + wave;
     long long g = tile * kTile + col;
@@ -132,22 +115,22 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 
     char* act = nullptr; char* maskp = nullptr;
     if (SAVE) {
-        act = a.act + act_tile_off((size_t)tile);
-        maskp = a.mask + mask_tile_off((size_t)tile);
+        act = a.act + act_tile_off<S>((size_t)tile);
+        maskp = a.mask + mask_tile_off<S>((size_t)tile);
 #ifndef KNERF_ABLATE_ENC_IO      // timing experiment only (with -DKNERF_CONSERVATIVE_WAIT): the upper bound of re-deriving the encodings in wgrad
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_block(act, kActEnc + q, lane, enc[q]);
+        for (int q = 0; q < 4; ++q) store_block(act, S::kActEnc + q, lane, enc[q]);
 #endif
     }
 
     ring.prologue_wait();
     FWD_STAMP(st1);
     Prefetch pf;
-    pf.start<kFwdBlocks>(ring, lane);
+    pf.start<S::kFwdBlocks>(ring, lane);
 #ifdef KNERF_CONSERVATIVE_WAIT
-    FwdWaitPlain waits;
+    FwdWaitPlain<S> waits;
 #else
-    std::conditional_t<SAVE, FwdWaitSave, FwdWaitPlain> waits;
+    std::conditional_t<SAVE, FwdWaitSave<S>, FwdWaitPlain<S>> waits;
 #endif
 
     bf16x8 x[16], y[16];
@@ -158,15 +141,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
             out[2 * ot] = relu_packed(out[2 * ot]);
             out[2 * ot + 1] = relu_packed(out[2 * ot + 1]);
             if (SAVE) {
-                // the layer's output stays in registers until the next layer has read it, so the blocks of kBurstTiles out
-                // tiles can leave together: longer contiguous bursts per wave (2 KiB x kBurstTiles) for the same registers
-                // (h0 is not saved at all: the layer_1 wgrad job recomputes it from enc, layout.h)
-                if (layer > 0 && (ot + 1) % kBurstTiles == 0) {
-#pragma unroll
-                    for (int q = ot + 1 - kBurstTiles; q <= ot; ++q) {
-                        store_block(act, act_h(layer) + 2 * q, lane, out[2 * q]);
-                        store_block(act, act_h(layer) + 2 * q + 1, lane, out[2 * q + 1]);
-                    }
+                // two blocks per out tile, right behind it (h0 is not saved at all: the layer_1 wgrad job recomputes it from enc,
+                // layout.h); longer bursts per wave were measured in round 2 and are slower
+                if (layer > 0) {
+                    store_block(act, S::act_h(layer) + 2 * ot, lane, out[2 * ot]);
+                    store_block(act, S::act_h(layer) + 2 * ot + 1, lane, out[2 * ot + 1]);
                 }
                 // mask word of tile ot in byte lanes: even tile -> bits 0-7 / 16-23, odd tile -> bits 8-15 / 24-31
                 const unsigned m = relu_mask_bits(out[2 * ot], out[2 * ot + 1]);
@@ -176,46 +155,55 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         };
     };
     unsigned mb[4];
-    int btile = 0;
     auto bias_init = [&](int base) { return [&, base](int ot) { return bias_acc(bias_lds, base + ot, h); }; };
 
-    // layer_0: 63 -> 256
-    dense_stage<0, 4, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
-    // layer_1..4
-    dense_stage<32, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8), [&](int ks) { return x[ks]; }, relu_epi(y, 1, mb));
-    dense_stage<160, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(16), [&](int ks) { return y[ks]; }, relu_epi(x, 2, mb));
-    dense_stage<288, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(24), [&](int ks) { return x[ks]; }, relu_epi(y, 3, mb));
-    dense_stage<416, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(32), [&](int ks) { return y[ks]; }, relu_epi(x, 4, mb));
-    // layer_5: [h4, xyz_enc] -> 256   (skip concat: h first, input second; mlp.py:36-38)
-    bf16x8 enc5[4];
-    encode<kLx, 4>(px, py, pz, h, enc5);
-    dense_stage<544, 20, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(40), [&](int ks) { return ks < 16 ? x[ks < 16 ? ks : 0] : enc5[ks >= 16 ? ks - 16 : 0]; },
-                            relu_epi(y, 5, mb));
-    dense_stage<704, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(48), [&](int ks) { return y[ks]; }, relu_epi(x, 6, mb));
-    dense_stage<832, 16, 8, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(56), [&](int ks) { return x[ks]; }, relu_epi(y, 7, mb));
-    (void)btile;
-    // head: [h7, dir_enc] -> (r, g, b, sigma) pre-activations, one out tile on the composed matrix (layout.h); lanes of
+    // layer_0: 63 -> 256, into x
+    dense_stage<0, 4, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
+    // layers 1 .. NL-1, ping-pong x -> y -> x ...: even layers write x, odd layers y.  A concat layer takes [h, xyz_enc] (skip concat:
+    // h first, input second; mlp.py:36-38) -- the encoding is recomputed where it is consumed instead of pinning 16 VGPRs
+    // across the trunk: 42 v_sin per re-encode vs ~1000 MFMAs per tile
+    static_for<S::NL - 1>([&](auto l_) {
+        constexpr int l = decltype(l_)::value + 1;
+        auto run = [&](bf16x8 (&in)[16], bf16x8 (&out)[16]) {
+            if constexpr (S::concat_in(l)) {
+                bf16x8 encc[4];
+                encode<kLx, 4>(px, py, pz, h, encc);
+                dense_stage<S::fwd_b0(l), 20, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * l),
+                                                                [&](int ks) { return ks < 16 ? in[ks < 16 ? ks : 0] : encc[ks >= 16 ? ks - 16 : 0]; },
+                                                                relu_epi(out, l, mb));
+            } else {
+                dense_stage<S::fwd_b0(l), 16, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * l), [&](int ks) { return in[ks]; },
+                                                                relu_epi(out, l, mb));
+            }
+        };
+        if constexpr (l % 2) run(x, y); else run(y, x);
+    });
+    // head: [h_{NL-1}, dir_enc] -> (r, g, b, sigma) pre-activations, one out tile on the composed matrix (layout.h); lanes of
     // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).
     bf16x8 dirc[2];
     encode<kLd, 2>(dx, dy, dz, h, dirc);
 #ifndef KNERF_ABLATE_ENC_IO
     if (SAVE) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) store_block(act, kActDir + q, lane, dirc[q]);
+        for (int q = 0; q < 2; ++q) store_block(act, S::kActDir + q, lane, dirc[q]);
     }
 #endif
-    dense_stage<960, 18, 1, kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(64), [&](int ks) { return ks < 16 ? y[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
-                            [&](int, f32x16 acc) {
-                                if (valid && h == 0) {
-                                    f32x4 r;
-                                    r[0] = 1.f / (1.f + expf(-acc[0]));
-                                    r[1] = 1.f / (1.f + expf(-acc[1]));
-                                    r[2] = 1.f / (1.f + expf(-acc[2]));
-                                    r[3] = acc[3] > 0.f ? acc[3] : 0.f;
-                                    reinterpret_cast<f32x4*>(a.raw)[g] = r;
-                                }
-                            });
-    ring_finish<kFwdBlocks>(ring, grp);
+    auto head = [&](bf16x8 (&in)[16]) {
+        dense_stage<S::fwd_b0(S::NL), 18, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * S::NL),
+                                [&](int ks) { return ks < 16 ? in[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
+                                [&](int, f32x16 acc) {
+                                    if (valid && h == 0) {
+                                        f32x4 r;
+                                        r[0] = 1.f / (1.f + expf(-acc[0]));
+                                        r[1] = 1.f / (1.f + expf(-acc[1]));
+                                        r[2] = 1.f / (1.f + expf(-acc[2]));
+                                        r[3] = acc[3] > 0.f ? acc[3] : 0.f;
+                                        reinterpret_cast<f32x4*>(a.raw)[g] = r;
+                                    }
+                                });
+    };
+    if constexpr ((S::NL - 1) % 2) head(y); else head(x);
+    ring_finish<S::kFwdBlocks>(ring, grp);
 #ifdef KNERF_FWD_STAMPS
     if (!SAVE && NET == 1 && threadIdx.x == 0 && blockIdx.x < 4096) {
         unsigned hw;
@@ -234,14 +222,15 @@ extern "C" int knerf_debug_fwd_stamps(unsigned long long* host, int n) {
 }
 #endif
 
-hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
+template <class S>
+hipError_t launch_mlp_fwd_t(const FwdArgs& a, bool save, hipStream_t stream) {
     const long long tiles = (a.n_samples + kTile - 1) / kTile;
     const int grid = (int)((tiles + kWaves - 1) / kWaves);
-    const size_t lds = kRingBytes + kFwdBiasTiles * 32 * sizeof(float);
+    const size_t lds = kRingBytes + S::kFwdBiasTiles * 32 * sizeof(float);
     static AttrOnce once;
     hipError_t ae = once([&]() -> hipError_t {
-        const void* fns[4] = {reinterpret_cast<const void*>(mlp_fwd_kernel<false, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<false, 1>),
-                              reinterpret_cast<const void*>(mlp_fwd_kernel<true, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<true, 1>)};
+        const void* fns[4] = {reinterpret_cast<const void*>(mlp_fwd_kernel<S, false, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<S, false, 1>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<S, true, 0>), reinterpret_cast<const void*>(mlp_fwd_kernel<S, true, 1>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -251,13 +240,29 @@ hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
     if (ae != hipSuccess) return ae;
     const dim3 g(grid), b(kThreads);
     if (save) {
-        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<true, 0>), g, b, lds, stream, a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<true, 1>), g, b, lds, stream, a);
+        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<S, true, 0>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<S, true, 1>), g, b, lds, stream, a);
     } else {
-        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<false, 0>), g, b, lds, stream, a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<false, 1>), g, b, lds, stream, a);
+        if (a.net == 0) hipLaunchKernelGGL((mlp_fwd_kernel<S, false, 0>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<S, false, 1>), g, b, lds, stream, a);
     }
     return hipGetLastError();
 }
+
+// explicit instantiation of this translation unit's shape(s), `extern template` for the others (layout.h KNERF_FUSED_SHAPES)
+#define KNERF_X(I, NL, SK) KNERF_PICK(I, template, extern template) hipError_t launch_mlp_fwd_t<Shape<NL, SK>>(const FwdArgs&, bool, hipStream_t);
+KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+
+#if KNERF_HAS_DISPATCH
+hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
+    switch (a.shape) {
+#define KNERF_X(I, NL, SK) case I: return launch_mlp_fwd_t<Shape<NL, SK>>(a, save, stream);
+        KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
 
 }  // namespace knerf

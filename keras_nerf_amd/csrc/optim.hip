@@ -97,36 +97,43 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // ---- collapsed head (layout.h) --------------------------------------------------------------------------------------
 // Offsets of the six tensors behind the trunk in the flat parameter vector (Keras order: sigma, features, rgb_features, rgb)
 namespace {
-constexpr int kOffL = 63 * 256 + 256 + 4 * (256 * 256 + 256) + (319 * 256 + 256) + 2 * (256 * 256 + 256);   // first float behind layer_7
-constexpr int kWs = kOffL, kBs = kWs + 256;                  // sigma kernel [256,1], bias [1]
-constexpr int kWf = kBs + 1, kBf = kWf + 256 * 256;          // features kernel [256,256], bias [256]
-constexpr int kWr = kBf + 256, kBr = kWr + 283 * 128;        // rgb_features kernel [283,128], bias [128]
-constexpr int kWc = kBr + 128, kBc = kWc + 128 * 3;          // rgb kernel [128,3], bias [3]
-static_assert(kBc + 3 == kParamCount, "head tensor offsets");
+// the six tensors behind the trunk, from the offset of the first float behind the last trunk layer (layout.h Shape::kTrunkParams)
+struct HeadOff {
+    int ws, bs, wf, bf, wr, br, wc, bc, head, head_bias;
+    __device__ explicit HeadOff(int off_l) {
+        ws = off_l; bs = ws + 256;                     // sigma kernel [256,1], bias [1]
+        wf = bs + 1; bf = wf + 256 * 256;              // features kernel [256,256], bias [256]
+        wr = bf + 256; br = wr + 283 * 128;            // rgb_features kernel [283,128], bias [128]
+        wc = br + 128; bc = wc + 128 * 3;              // rgb kernel [128,3], bias [3]
+        head = bc + 3; head_bias = head + 288 * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
+    }
+};
+static_assert(DefaultShape::kTrunkParams + 257 + 256 * 257 + 283 * 128 + 128 + 128 * 3 + 3 == DefaultShape::kParamCount && DefaultShape::kHeadRows == 288, "head tensor offsets");
 }  // namespace
 
 // H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < 256);  H[256+m][0..2] = (W_r2 W_c)[m], H[256+m][3] = 0 (m < 27);
 // bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP.
-__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1) {
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l) {
     float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
+    const HeadOff o(off_l);
     __shared__ float P[283][3];          // W_r W_c : rows 0..255 = W_r1 W_c, 256..282 = W_r2 W_c
     __shared__ float wc[128][3];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 128 * 3; i += 256) wc[i / 3][i % 3] = w[kWc + i];
+    for (int i = tid; i < 128 * 3; i += 256) wc[i / 3][i % 3] = w[o.wc + i];
     __syncthreads();
     for (int r = tid; r < 283; r += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wr = w + kWr + (size_t)r * 128;
+        const float* wr = w + o.wr + (size_t)r * 128;
         for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
         P[r][0] = a0; P[r][1] = a1; P[r][2] = a2;
     }
     __syncthreads();
-    float* H = w + kHeadOff;
+    float* H = w + o.head;
     {   // row tid of A = W_f P1
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wf = w + kWf + (size_t)tid * 256;
+        const float* wf = w + o.wf + (size_t)tid * 256;
         for (int j = 0; j < 256; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
-        H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[kWs + tid];
+        H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[o.ws + tid];
     }
     if (tid < 32) {
         const int r = 256 + tid;
@@ -134,15 +141,15 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1)
         H[r * 4 + 0] = real ? P[r][0] : 0.f; H[r * 4 + 1] = real ? P[r][1] : 0.f; H[r * 4 + 2] = real ? P[r][2] : 0.f; H[r * 4 + 3] = 0.f;
     }
     if (tid < 3) {
-        float c = w[kBc + tid];
-        for (int j = 0; j < 256; ++j) c += w[kBf + j] * P[j][tid];
-        for (int k = 0; k < 128; ++k) c += w[kBr + k] * wc[k][tid];
-        w[kHeadBiasOff + tid] = c;
+        float c = w[o.bc + tid];
+        for (int j = 0; j < 256; ++j) c += w[o.bf + j] * P[j][tid];
+        for (int k = 0; k < 128; ++k) c += w[o.br + k] * wc[k][tid];
+        w[o.head_bias + tid] = c;
     }
-    if (tid == 3) w[kHeadBiasOff + 3] = w[kBs];
+    if (tid == 3) w[o.head_bias + 3] = w[o.bs];
 }
-hipError_t launch_head_compose(float* w0, float* w1, hipStream_t stream) {
-    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1);
+hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, hipStream_t stream) {
+    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params);
     return hipGetLastError();
 }
 
@@ -153,54 +160,55 @@ hipError_t launch_head_compose(float* w0, float* w1, hipStream_t stream) {
 //   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
 // -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
 // evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
-struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; };
+struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l; };
 __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
+    const HeadOff o(a.off_l);
     __shared__ float M[283][3], s_[3], P1[256][3], Q[256][3], wc[128][3];
     const int tid = threadIdx.x;
     for (int i = tid; i < 283 * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
     if (tid < 3) s_[tid] = aux[kAuxS + tid];
-    for (int i = tid; i < 128 * 3; i += 1024) wc[i / 3][i % 3] = w[kWc + i];
+    for (int i = tid; i < 128 * 3; i += 1024) wc[i / 3][i % 3] = w[o.wc + i];
     __syncthreads();
     for (int i = tid; i < kAuxCount; i += 1024) aux[i] = 0.f;
     if (tid < 256) {            // P1 row tid
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wr = w + kWr + (size_t)tid * 128;
+        const float* wr = w + o.wr + (size_t)tid * 128;
         for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
         P1[tid][0] = a0; P1[tid][1] = a1; P1[tid][2] = a2;
     } else if (tid < 512) {     // Q row j: column j of W_f against M1 (coalesced over j)
         const int j = tid - 256;
-        const float bf = w[kBf + j];
+        const float bf = w[o.bf + j];
         float a0 = bf * s_[0], a1 = bf * s_[1], a2 = bf * s_[2];
-        for (int i = 0; i < 256; ++i) { const float v = w[kWf + (size_t)i * 256 + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
+        for (int i = 0; i < 256; ++i) { const float v = w[o.wf + (size_t)i * 256 + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
         Q[j][0] = a0; Q[j][1] = a1; Q[j][2] = a2;
     }
     __syncthreads();
     // features: kernel [256,256] += M1 P1^T, bias += s P1^T
     for (int e = tid; e < 256 * 256; e += 1024) {
         const int i = e >> 8, j = e & 255;
-        grad[kWf + e] += M[i][0] * P1[j][0] + M[i][1] * P1[j][1] + M[i][2] * P1[j][2];
+        grad[o.wf + e] += M[i][0] * P1[j][0] + M[i][1] * P1[j][1] + M[i][2] * P1[j][2];
     }
-    if (tid < 256) grad[kBf + tid] += s_[0] * P1[tid][0] + s_[1] * P1[tid][1] + s_[2] * P1[tid][2];
+    if (tid < 256) grad[o.bf + tid] += s_[0] * P1[tid][0] + s_[1] * P1[tid][1] + s_[2] * P1[tid][2];
     // rgb_features: kernel [283,128] += [Q ; M2] W_c^T, bias += s W_c^T
     for (int e = tid; e < 283 * 128; e += 1024) {
         const int r = e >> 7, k = e & 127;
         const float* v = r < 256 ? Q[r] : M[r];
-        grad[kWr + e] += v[0] * wc[k][0] + v[1] * wc[k][1] + v[2] * wc[k][2];
+        grad[o.wr + e] += v[0] * wc[k][0] + v[1] * wc[k][1] + v[2] * wc[k][2];
     }
-    if (tid < 128) grad[kBr + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
+    if (tid < 128) grad[o.br + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
     // rgb: kernel [128,3] += W_r1^T Q + W_r2^T M2 + b_r (x) s, bias += s
     if (tid < 384) {
         const int k = tid / 3, c = tid % 3;
-        float a = w[kBr + k] * s_[c];
-        for (int j = 0; j < 256; ++j) a += w[kWr + (size_t)j * 128 + k] * Q[j][c];
-        for (int m = 256; m < 283; ++m) a += w[kWr + (size_t)m * 128 + k] * M[m][c];
-        grad[kWc + tid] += a;
+        float a = w[o.br + k] * s_[c];
+        for (int j = 0; j < 256; ++j) a += w[o.wr + (size_t)j * 128 + k] * Q[j][c];
+        for (int m = 256; m < 283; ++m) a += w[o.wr + (size_t)m * 128 + k] * M[m][c];
+        grad[o.wc + tid] += a;
     }
-    if (tid < 3) grad[kBc + tid] += s_[tid];
+    if (tid < 3) grad[o.bc + tid] += s_[tid];
 }
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, hipStream_t stream) {
-    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}};
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, hipStream_t stream) {
+    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params};
     hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }

@@ -16,7 +16,7 @@ __device__ __forceinline__ int list_lower_bound(const int* list, int n, int t) {
 // NET only names the instantiation (0 = coarse pass, 1 = fine pass) so that profiler summaries list the two launch sizes
 // separately (profiles/*kernel_stats*.csv against bench.py's wgrad_coarse / wgrad_fine).  LIST: the tiles come from the
 // compacted list of live tiles (dead-tile skipping) instead of the contiguous range.
-template <int NET, bool LIST>
+template <class S, int NET, bool LIST>
 __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef KNERF_WGRAD_STAMPS
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
     const WgradPlan pl = reinterpret_cast<const WgradPlan*>(a.plan)[blockIdx.x];
     if constexpr (!LIST) {
         const ContigSeq seq{(int)(a.n_tiles * pl.split / pl.nsplit), (int)(a.n_tiles * (pl.split + 1) / pl.nsplit)};
-        wgrad_dispatch(a, pl.job, seq, smem);
+        wgrad_dispatch<S>(a, pl.job, seq, smem);
     } else {
         // plain loads, before any LDS-DMA copy is in flight (hipcc waits for them with its own vmcnt)
         int n = __builtin_amdgcn_readfirstlane(*a.n_live);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void wgrad_kernel(WgradArgs a) {
             seq.i1 = list_lower_bound(a.live, n, (int)(a.n_tiles * (pl.split + 1) / pl.nsplit));
         }
         seq.i0 = __builtin_amdgcn_readfirstlane(seq.i0); seq.i1 = __builtin_amdgcn_readfirstlane(seq.i1);
-        wgrad_dispatch(a, pl.job, seq, smem);
+        wgrad_dispatch<S>(a, pl.job, seq, smem);
     }
 #ifdef KNERF_WGRAD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -51,12 +51,13 @@ extern "C" int knerf_debug_wgrad_stamps(unsigned long long* host, int n) {
 }
 #endif
 
-hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+template <class S>
+hipError_t launch_wgrad_t(const WgradArgs& a, hipStream_t stream) {
     const size_t lds = 160 * 1024;
     static AttrOnce once;
     hipError_t ae = once([&]() -> hipError_t {
-        const void* fns[4] = {reinterpret_cast<const void*>(wgrad_kernel<0, false>), reinterpret_cast<const void*>(wgrad_kernel<1, false>),
-                              reinterpret_cast<const void*>(wgrad_kernel<0, true>), reinterpret_cast<const void*>(wgrad_kernel<1, true>)};
+        const void* fns[4] = {reinterpret_cast<const void*>(wgrad_kernel<S, 0, false>), reinterpret_cast<const void*>(wgrad_kernel<S, 1, false>),
+                              reinterpret_cast<const void*>(wgrad_kernel<S, 0, true>), reinterpret_cast<const void*>(wgrad_kernel<S, 1, true>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -66,13 +67,28 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     if (ae != hipSuccess) return ae;
     const dim3 g(a.n_plan), b(kWgThreads);
     if (a.live) {
-        if (a.net == 0) hipLaunchKernelGGL((wgrad_kernel<0, true>), g, b, lds, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<1, true>), g, b, lds, stream, a);
+        if (a.net == 0) hipLaunchKernelGGL((wgrad_kernel<S, 0, true>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<S, 1, true>), g, b, lds, stream, a);
     } else {
-        if (a.net == 0) hipLaunchKernelGGL((wgrad_kernel<0, false>), g, b, lds, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<1, false>), g, b, lds, stream, a);
+        if (a.net == 0) hipLaunchKernelGGL((wgrad_kernel<S, 0, false>), g, b, lds, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<S, 1, false>), g, b, lds, stream, a);
     }
     return hipGetLastError();
+}
+
+// explicit instantiation of this translation unit's shape(s), `extern template` for the others (layout.h KNERF_FUSED_SHAPES)
+#define KNERF_X(I, NL, SK) KNERF_PICK(I, template, extern template) hipError_t launch_wgrad_t<Shape<NL, SK>>(const WgradArgs&, hipStream_t);
+KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+
+#if KNERF_HAS_DISPATCH
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+    switch (a.shape) {
+#define KNERF_X(I, NL, SK) case I: return launch_wgrad_t<Shape<NL, SK>>(a, stream);
+        KNERF_FUSED_SHAPES(KNERF_X)
+#undef KNERF_X
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // ---- deterministic mode: ordered second pass over the per-workgroup slabs (wgrad_body.h flush_acc / flush_bias) ------------------
@@ -90,12 +106,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, const in
     if (d < 0) return;
     float s = 0.f;
     for (int wg = job_wg0[job]; wg < job_wg0[job + 1]; ++wg) s += a.partial[(size_t)wg * kWgradPartialStride + e];
-    float* p = d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase);
+    float* p = d < a.aux_base ? a.grad + d : a.aux + (d - a.aux_base);
     *p += s;
 }
 hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0, hipStream_t stream) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kWgradPartialStride + 255) / 256, kWgradJobs), dim3(256), 0, stream, a, job_wg0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kWgradPartialStride + 255) / 256, a.n_jobs), dim3(256), 0, stream, a, job_wg0);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace knerf

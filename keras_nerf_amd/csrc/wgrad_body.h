@@ -89,7 +89,7 @@ __device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, in
 #ifdef KNERF_WGRAD_ABLATE_FLUSH      // timing experiment only: what the atomic flush costs
         asm volatile("" ::"v"(acc[i]), "v"(d[i]));
 #else
-        if (d[i] >= 0) atomicAdd(d[i] < kAuxBase ? a.grad + d[i] : a.aux + (d[i] - kAuxBase), acc[i]);
+        if (d[i] >= 0) atomicAdd(d[i] < a.aux_base ? a.grad + d[i] : a.aux + (d[i] - a.aux_base), acc[i]);
 #endif
     }
 }
@@ -101,7 +101,7 @@ __device__ __forceinline__ void flush_bias(const WgradArgs& a, const int* dst, i
         return;
     }
     const int d = dst[idx];
-    if (d >= 0 && hh == 0) atomicAdd(d < kAuxBase ? a.grad + d : a.aux + (d - kAuxBase), v);
+    if (d >= 0 && hh == 0) atomicAdd(d < a.aux_base ? a.grad + d : a.aux + (d - a.aux_base), v);
 }
 
 // 8 consecutive samples (k-step kk of the tile, MFMA half h) of feature (lane&31) of tile-pair `pair` in a staged
@@ -168,8 +168,10 @@ __device__ __forceinline__ int wait_barrier_next(const Seq& seq, int idx) {
     }
 }
 
-template <int NI, int NO, class Seq>
-__device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int dz_blk,
+// act_blk: first act block of input tiles 0..7; act_blk2 + 16: first block of tiles 8.. (a concat layer's encoding: directly behind
+// its h for the first concat layer of a shape -- act_blk2 == act_blk, one contiguous range -- elsewhere for later ones)
+template <class S, int NI, int NO, class Seq>
+__device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int act_blk2, const int dz_blk,
                                                const Seq seq, char* smem) {
     constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
     constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
@@ -214,20 +216,20 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 #ifdef KNERF_LIST_GUARD     // diagnostic build: a list entry outside the launch is counted and replaced instead of faulting
         if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
 #endif
-        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_blk * kSavedBlockStride + lane * 16;
-        const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)dz_blk * kSavedBlockStride + lane * 16;
+        const char* tile_in = a.act + act_tile_off<S>((size_t)t) + lane * 16;
+        const char* src_dz = a.dz + dz_tile_off<S>((size_t)t) + (size_t)dz_blk * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
+            const int blk = (ok ? b : 0) + ((ok && b >= 16) ? act_blk2 : act_blk);         // block of the tile's act run
 #ifdef KNERF_ABLATE_ENC_IO     // timing experiment only: the enc / dir blocks come from tile 0 (L2 hits) -- what wgrad would gain if it re-derived them for free
-            const int blk = act_blk + (ok ? b : 0);
-            const bool is_enc = (blk >= kActEnc && blk < kActEnc + 4) || blk >= kActDir;
-            const char* base = is_enc ? a.act + (size_t)act_blk * kSavedBlockStride + lane * 16 : src_in;
-            glds16(base + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
+            const bool is_enc = (blk >= S::kActEnc && blk < S::kActEnc + 4) || blk >= S::kActDir;
+            const char* base = is_enc ? a.act + lane * 16 : tile_in;
+            glds16(base + (size_t)blk * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
 #else
-            glds16(src_in + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
+            glds16(tile_in + (size_t)blk * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
 #endif
         }
 #pragma unroll
@@ -346,7 +348,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
 // permutation (only the per-lane offsets of the transposed reads change; the bank pattern stays conflict-free: 32 q + 128
 // (h ^ par) covers the 64 banks in two passes).  W_0's fragments are the forward stream's own layer_0 blocks: an A fragment of
 // W^T and a B fragment of W hold the same registers (layout.h: the 32x32x16 operand maps are symmetric).
-template <class Seq>
+template <class S, class Seq>
 __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq seq, char* smem) {
     constexpr int NI = 8, BLK_IN = 4, BLK_DZ = 16;
     constexpr int TILE_BYTES = (BLK_IN + BLK_DZ) * 1024;
@@ -387,11 +389,11 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
         if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
 #endif
 #ifdef KNERF_ABLATE_ENC_IO
-        const char* src_in = a.act + (size_t)kActEnc * kSavedBlockStride + lane * 16;
+        const char* src_in = a.act + (size_t)S::kActEnc * kSavedBlockStride + lane * 16;
 #else
-        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)kActEnc * kSavedBlockStride + lane * 16;
+        const char* src_in = a.act + act_tile_off<S>((size_t)t) + (size_t)S::kActEnc * kSavedBlockStride + lane * 16;
 #endif
-        const char* src_dz = a.dz + dz_tile_off((size_t)t) + (size_t)16 * kSavedBlockStride + lane * 16;
+        const char* src_dz = a.dz + dz_tile_off<S>((size_t)t) + (size_t)16 * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
         const bool ok = wave < BLK_IN;
         glds16(src_in + (ok ? wave : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
@@ -407,7 +409,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    static_assert((kActEnc & 1) == 0, "enc block parity");
+    static_assert((S::kActEnc & 1) == 0, "enc block parity");
 
     // my tile of h0 for the sample tile staged in `reg`: acc = b_0, += enc(ks) . W_0(ks), relu, bf16 (the forward's own order of
     // operations, mlp_fwd.hip), published as the two A-operand fragments of h0 tile `wave`
@@ -479,14 +481,14 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
 // sample permutation as in wgrad_l1_recompute.  H's fragment is the dgrad stream's own block `wo` (stage B0).
 // The recompute of tile i+1 runs inside tile i's MFMA sequence (its VALU selects and conversions issue between MFMAs), so
 // the strip is a register operand by the time the tile's own products start.
-template <class Seq>
-__device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq seq, char* smem) {
+template <class S, class Seq>
+__device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const Seq seq, char* smem) {
     constexpr int NI = 8, BLK_IN = 16, BLK_X = 2;           // x: [0] dz_head block, [1] mask7 block
     constexpr int TILE_BYTES = (BLK_IN + BLK_X) * 1024;
     constexpr int G = 3;                                     // 2 h6 copies + 1 (dz_head / mask / padding) per wave and tile
     constexpr int NS = 8;                                    // 18 KiB tiles: eight slots, six tiles in flight behind the two in use
     static_assert(NS * TILE_BYTES + kWgScratch <= 160 * 1024, "LDS budget");
-    constexpr int job = 7, NACC = NI + 1, NCOLS = 256;
+    constexpr int job = S::NL - 1, NACC = NI + 1, NCOLS = 256;      // the last trunk layer
 
     const int cnt = seq.count();
     if (cnt <= 0) return;
@@ -512,21 +514,21 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq
         moff = hf * 32 * 16 + (wo >> 1) * 4;
         mbit = (wo & 1) * 8 + (i >> 1) + 16 * (i & 1);
     }
-    static_assert((kDzHead & 1) == 0, "dz_head block parity");
+    static_assert((S::kDzHead & 1) == 0, "dz_head block parity");
     auto tile_at = [&](int i) { return seq.tile(i < cnt ? i : cnt - 1); };
     auto issue = [&](int t, int slot, bool late = false) {
 #ifdef KNERF_LIST_GUARD
         if (t < 0 || t >= a.n_tiles) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.stats) + 3, 1ull); t = 0; }
 #endif
-        const char* src_in = a.act + act_tile_off((size_t)t) + (size_t)act_h(6) * kSavedBlockStride + lane * 16;
+        const char* src_in = a.act + act_tile_off<S>((size_t)t) + (size_t)S::act_h(S::NL - 2) * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int b = r * kWgWaves + wave;
             glds16(src_in + b * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
         }
-        const char* src_x = wave == 1 ? a.mask + mask_tile_off((size_t)t) + 7 * kSavedBlockStride + lane * 16
-                                      : a.dz + dz_tile_off((size_t)t) + (size_t)kDzHead * kSavedBlockStride + lane * 16;
+        const char* src_x = wave == 1 ? a.mask + mask_tile_off<S>((size_t)t) + (S::NL - 1) * kSavedBlockStride + lane * 16
+                                      : a.dz + dz_tile_off<S>((size_t)t) + (size_t)S::kDzHead * kSavedBlockStride + lane * 16;
         glds16(src_x, __builtin_amdgcn_readfirstlane(wave < 2 ? dst + (BLK_IN + wave) * 1024 : scratch), late);
     };
     const int hh = lane >> 5;
@@ -603,21 +605,22 @@ __device__ __forceinline__ void wgrad_l7_recompute(const WgradArgs& a, const Seq
     }
 }
 
-// one job of the plan over the given tile range
-template <class Seq>
+// one job of the plan over the given tile range: job j = trunk layer j, job NL = the head; the body follows from the job's kind
+// (layout.h wgrad_job): every branch below is resolved at compile time but the uniform `job == j`
+template <class S, class Seq>
 __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, const Seq& seq, char* smem) {
-    switch (job) {
-        case 0: wgrad_job_body<2, 8>(a, 0, kActEnc, 0, seq, smem); break;
-        case 1: wgrad_l1_recompute(a, seq, smem); break;                                  // h0 recomputed from enc
-        case 2: wgrad_job_body<8, 8>(a, 2, act_h(1), 16 * 2, seq, smem); break;
-        case 3: wgrad_job_body<8, 8>(a, 3, act_h(2), 16 * 3, seq, smem); break;
-        case 4: wgrad_job_body<8, 8>(a, 4, act_h(3), 16 * 4, seq, smem); break;
-        case 5: wgrad_job_body<10, 8>(a, 5, kActH4, 16 * 5, seq, smem); break;
-        case 6: wgrad_job_body<8, 8>(a, 6, act_h(5), 16 * 6, seq, smem); break;
-        case 7: wgrad_l7_recompute(a, seq, smem); break;                                  // dz7 recomputed from dz_head and the mask
-        case 8: wgrad_job_body<9, 1>(a, 8, kActH7, kDzHead, seq, smem); break;      // head: [h7 ; dir] x (r, g, b, sigma)
-        default: break;
-    }
+    static_for<S::kWgradJobs>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        constexpr WgradJob J = wgrad_job<S>(j);
+        if (job == j) {
+            if constexpr (J.kind == 0) wgrad_job_body<S, 2, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);
+            else if constexpr (J.kind == 1) wgrad_l1_recompute<S>(a, seq, smem);                               // h0 recomputed from enc
+            else if constexpr (J.kind == 2) wgrad_job_body<S, 8, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);
+            else if constexpr (J.kind == 3) wgrad_job_body<S, 10, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);   // [h ; enc]
+            else if constexpr (J.kind == 4) wgrad_last_recompute<S>(a, seq, smem);                             // dz recomputed from dz_head and the mask
+            else wgrad_job_body<S, 9, 1>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);                    // head: [h ; dir] x (r, g, b, sigma)
+        }
+    });
 }
 
 }  // namespace knerf

@@ -1,0 +1,127 @@
+"""The fused chain kernels for trunk shapes other than the reference's default (round 3; csrc/layout.h KNERF_FUSED_SHAPES: the same
+kernel source instantiated per shape): `NeRF(n_layers=, skip_layer=)` variants of width 256 with the reference's encodings
+(train_single.py:34-36), against the oracle at the default shape's tolerances, against the general-shape kernels, bit-reproducible
+in deterministic mode and exact under dead-tile skipping.
+
+  8 x 256 / skip 2   THREE concats ([h ; xyz_enc] into layers 3, 5, 7): the later two read their encoding from a second block range;
+                     the last trunk layer is a concat layer, so dgrad writes its dZ and its weight-gradient job is the plain one
+  6 x 256 / skip 3   one concat (layer 4); fewer layers
+  4 x 256 / skip 2   the shortest covered: layer 3 is first concat AND last layer
+  12 x 256 / skip 4  two concats (layers 5 and 9), twelve mask blocks per tile, the longest weight streams"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from tests.problem import make_problem
+from tests.test_gpu_forward import log_stats
+from tests.test_gpu_train import flat, per_tensor_err
+from keras_nerf_amd.debug import debug_buffer
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 2), (6, 3), (4, 2), (12, 4)]
+
+
+def _cfg(nl, sk):
+    return O.NerfConfig(n_layers=nl, dense_units=256, skip_layer=sk)
+
+
+def _ctx(P, **kw):
+    from keras_nerf_amd.runtime import KnerfContext
+    c = P["cfg"]
+    ctx = KnerfContext(n_layers=c.n_layers, dense_units=c.dense_units, skip_layer=c.skip_layer, white_background=True, **kw)
+    assert ctx.param_count == O.param_count(c)
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    return ctx
+
+
+@pytest.mark.parametrize("nl,sk", SHAPES)
+def test_fused_shape_against_oracle_and_general_path(nl, sk):
+    cfg = _cfg(nl, sk)
+    # glorot x 1.5 as in the other parity tests; plain glorot for the 12-layer trunk: twelve x1.5-gain layers amplify the rounding
+    # differences between ANY two bf16 implementations (fused 1.6e-2 / 3.6e-2 against the oracle's emulation there, decreasing
+    # smoothly from layer_0 to layer_11; 4.8e-3 at gain 1, the same as the general-shape kernels: tools/shape_diag.py)
+    P = make_problem(n_images=1, wh=16, weight_scale=1.0 if nl >= 12 else 1.5, bias_std=0.05, cfg=cfg)
+    o, d, t, u, img = flat(P)
+    res = {}
+    for force in (False, True):
+        ctx = _ctx(P, force_generic=force)
+        assert ctx.get_option("general_shape_path") == float(force)          # the shape runs on the fused kernels unless forced off them
+        loss = torch.zeros(2, device="cuda")
+        ci = torch.empty((P["N"], 3), device="cuda"); fi = torch.empty_like(ci)
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
+        torch.cuda.synchronize()
+        S = cfg.n_coarse + cfg.n_fine
+        t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:P["N"] * S].reshape(P["N"], S).copy()
+        res[force] = (ctx.grads_view().cpu().numpy().copy(), loss.cpu().numpy().copy(), ci.cpu().numpy().copy(), fi.cpu().numpy().copy(), t_fine)
+        ctx.close()
+    g, loss, ci, fi, t_fine = res[False]
+    n = g.size // 2
+    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
+    rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=O.FUSED)
+    ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
+    log_stats(f"fused_shape_{nl}x256_skip{sk}", coarse_worst=ec[0], fine_worst=ef[0], loss_c=abs(float(loss[0]) - float(lc)),
+              loss_f=abs(float(loss[1]) - float(lf)), img_c=float(np.abs(ci - rc["image"]).max()), img_f=float(np.abs(fi - rf["image"]).max()))
+    # the general-shape kernels on the same problem against the same oracle, for the log
+    gg, lg = res[True][0], res[True][1]
+    rf_g = O.chunk_loss_and_grads(P["fp"], o, d, res[True][4], img, cfg, True, emulate_bf16=O.FUSED)
+    gc_err = per_tensor_err(gg[:n], O.flatten_params(gc), cfg)[0]
+    gf_err = per_tensor_err(gg[n:], O.flatten_params(rf_g[2]), cfg)[0]
+    log_stats(f"fused_shape_{nl}x256_skip{sk}_general_path_vs_oracle", coarse_worst=gc_err, fine_worst=gf_err)
+    tol = 1.5e-2
+    assert ec[0] < tol, ec
+    assert ef[0] < tol, ef
+    assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
+    np.testing.assert_allclose(ci, rc["image"], atol=1e-2)
+    np.testing.assert_allclose(fi, rf["image"], atol=1e-2)
+    # ... and directly against each other (different kernels, same numerics contract)
+    e2 = per_tensor_err(gg[:n], g[:n], cfg)[0]
+    assert e2 < 4e-2, e2
+    assert np.abs(lg - loss).max() < 2e-3
+
+
+@pytest.mark.parametrize("nl,sk", [(8, 2), (4, 2)])
+def test_fused_shape_deterministic_and_skipping_exact(nl, sk):
+    """two deterministic launches bit-identical; with sigma's bias lowered (dead tiles) skipping on = off, bit for bit"""
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = _cfg(nl, sk)
+    P = make_problem(n_images=2, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    names = [x[0] for x in O.layer_shapes(cfg)]
+    si = 2 * names.index("sigma") + 1
+    P["cp"][si] = P["cp"][si] - np.float32(0.6); P["fp"][si] = P["fp"][si] - np.float32(0.6)
+    N = 512
+    data = [torch.as_tensor(P[k].reshape(P["N"], -1)[:N].copy(), device="cuda") for k in ("o", "d", "t", "img", "u")]
+    out = {}
+    for skip in (0, 1, 1):
+        ctx = _ctx(P, options=dict(deterministic=1, skip_dead_tiles=skip))
+        loss = torch.zeros(2, device="cuda")
+        ctx.zero_grads()
+        ctx.train_batch(data[0], data[1], data[2], data[3], data[4], ray_chunks=128, loss=loss)
+        torch.cuda.synchronize()
+        g = ctx.grads_view().clone()
+        live, total = ctx.tile_stats()
+        key = (skip, len([k for k in out if k[0] == skip]))
+        out[key] = (g, loss.clone(), live, total)
+        ctx.close()
+    g0, l0 = out[0, 0][:2]
+    assert float(g0.abs().max()) > 0
+    for key in ((1, 0), (1, 1)):
+        g, l, live, total = out[key]
+        assert torch.equal(g.view(torch.int32), g0.view(torch.int32)), (key, float((g - g0).abs().max()))
+        assert torch.equal(l.view(torch.int32), l0.view(torch.int32))
+    dead = 1.0 - out[1, 0][2] / out[1, 0][3]
+    log_stats(f"fused_shape_{nl}x256_skip{sk}_dead_tiles", dead=dead)
+    assert 0.01 < dead < 0.99, dead
+
+
+def test_shapes_outside_the_fused_set_use_the_general_path():
+    from keras_nerf_amd.runtime import KnerfContext
+    for kw in (dict(n_layers=8, dense_units=128, skip_layer=4), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
+               dict(n_layers=8, dense_units=256, skip_layer=4, pos_emb_xyz=6), dict(n_layers=7, dense_units=256, skip_layer=3)):
+        ctx = KnerfContext(white_background=True, **kw)
+        assert ctx.get_option("general_shape_path") == 1.0, kw
+        ctx.close()
+    ctx = KnerfContext(white_background=True)
+    assert ctx.get_option("general_shape_path") == 0.0
+    ctx.close()

@@ -49,7 +49,8 @@ def _asm(name):
     out = os.path.join(tempfile.gettempdir(), f"knerf_isa_{name}_{h.hexdigest()[:16]}.s")
     if not os.path.exists(out):
         tmp = out + f".{os.getpid()}"
-        subprocess.run([HIPCC, *_flags(), "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", tmp,
+        # slice 0 = the reference's default trunk shape (layout.h KNERF_FUSED_SHAPES): the object build.py links for it
+        subprocess.run([HIPCC, *_flags(), "-DKNERF_SHAPE_SLICE=0", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", tmp,
                         os.path.join(CSRC, name + ".hip")], check=True, capture_output=True)
         os.replace(tmp, out)
     return open(out).read()
@@ -81,10 +82,11 @@ def isa():
 
 EXPECT = {
     # kernel-name fragment: (file, instantiation tags, {mnemonic: count})
-    "mlp_fwd_kernelILb1E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 127}),
-    "mlp_fwd_kernelILb0E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 1}),
-    "mlp_bwd_kernel": ("mlp_bwd", 2, {"v_mfma_f32_32x32x16_bf16": 904, "global_load_lds_dwordx4": 234, "global_store_dwordx4": 113}),
-    "wgrad_kernel": ("wgrad", 4, {"v_mfma_f32_32x32x16_bf16": 150, "global_load_lds_dwordx4": 168}),
+    # (kernels are templates on the trunk shape: Shape<8, 4> = "5ShapeILi8ELi4EEE" in the mangled names)
+    "mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb1E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 127}),
+    "mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb0E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 1}),
+    "mlp_bwd_kernelINS_5ShapeILi8ELi4EEE": ("mlp_bwd", 2, {"v_mfma_f32_32x32x16_bf16": 904, "global_load_lds_dwordx4": 234, "global_store_dwordx4": 113}),
+    "wgrad_kernelINS_5ShapeILi8ELi4EEE": ("wgrad", 4, {"v_mfma_f32_32x32x16_bf16": 150, "global_load_lds_dwordx4": 168}),
 }
 
 
@@ -107,7 +109,7 @@ def test_counted_waits_still_match_the_emitted_instructions(isa, frag):
 def test_chain_kernels_wait_with_counted_immediates(isa):
     """the counted waits are really there (a refactoring that drops back to vmcnt(0) / lgkmcnt(0) everywhere would pass the count
     test above and lose 10-20 % speed): the training forward has dozens of distinct vmcnt immediates"""
-    for frag, fname in (("mlp_fwd_kernelILb1E", "mlp_fwd"), ("mlp_bwd_kernel", "mlp_bwd")):
+    for frag, fname in (("mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb1E", "mlp_fwd"), ("mlp_bwd_kernelINS_5ShapeILi8ELi4EEE", "mlp_bwd")):
         for name, (body, _) in isa[fname].items():
             if frag not in name:
                 continue

@@ -31,7 +31,7 @@ def main():
     ctx.train_chunk(o, d, t, tgt, u)
     torch.cuda.synchronize()
     n_tiles = 4096 * 192 // 32
-    for name, which, stride in (("act", 0, 118 * 1024 + 256), ("mask", 1, 8 * 1024 + 256), ("dz", 2, 130 * 1024 + 256)):
+    for name, which, stride in () if os.environ.get("KNERF_DIGEST_NO_BUFFERS") else (("act", 0, 118 * 1024 + 256), ("mask", 1, 8 * 1024 + 256), ("dz", 2, 130 * 1024 + 256)):
         out[name] = digest(debug_buffer(ctx, which)[:n_tiles * stride])
     out["grads"] = digest(ctx.grads_view())          # deterministic mode: a function of the kernels' arithmetic only
     print(json.dumps(out))

@@ -16,6 +16,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
 ap.add_argument("--save-grads", default=None, help="write the gradient of one train chunk (fixed inputs and Philox seed) to this .npy")
 ap.add_argument("--check-grads", default=None, help="compare that gradient with a saved one (A/B builds must compute the same thing)")
+ap.add_argument("--skip-dead-tiles", type=int, default=0, help="kernel timings are quoted with dead-tile skipping OFF (every tile goes through dgrad and wgrad); 1 = the library default")
 ap.add_argument("--shape", default="8,256,4,10,4", help="n_layers,dense_units,skip_layer,pos_emb_xyz,pos_emb_dir (non-default: general-shape path)")
 args = ap.parse_args()
 if args.lib:
@@ -28,7 +29,8 @@ from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
 from keras_nerf_amd.model.nerf.mlp import NeRFMLP
 
 NL, NU, SK, LX, LD = (int(v) for v in args.shape.split(","))
-ctx = KnerfContext(white_background=True, n_layers=NL, dense_units=NU, skip_layer=SK, pos_emb_xyz=LX, pos_emb_dir=LD)
+ctx = KnerfContext(white_background=True, n_layers=NL, dense_units=NU, skip_layer=SK, pos_emb_xyz=LX, pos_emb_dir=LD,
+                   options=dict(skip_dead_tiles=args.skip_dead_tiles))
 for net in (0, 1):
     m = NeRFMLP(NL, NU, SK, seed=net, xyz_dim=3 + 6 * LX, dir_dim=3 + 6 * LD); m.build(); ctx.set_weights(net, m.get_flat_weights())
 wh = 128
