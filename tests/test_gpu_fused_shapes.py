@@ -112,7 +112,7 @@ def test_fused_shape_deterministic_and_skipping_exact(nl, sk):
         assert torch.equal(l.view(torch.int32), l0.view(torch.int32))
     dead = 1.0 - out[1, 0][2] / out[1, 0][3]
     log_stats(f"fused_shape_{nl}x256_skip{sk}_dead_tiles", dead=dead)
-    assert 0.01 < dead < 0.99, dead
+    assert 0.003 < dead < 0.99, dead           # measured 1.5 % (8/2), 5.0 % (4/2): there are dead tiles to skip
 
 
 def test_shapes_outside_the_fused_set_use_the_general_path():
