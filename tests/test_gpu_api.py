@@ -331,3 +331,37 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal():
     if torch.cuda.device_count() < 2:
         r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=base)
         assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr
+
+
+def test_loader_resident_and_staged_paths_yield_the_same_batches(tmp_path):
+    """DatasetLoader feeds the GPU from a device-resident copy of the dataset, or -- when it exceeds `device_cache_gb` -- through two
+    pinned staging buffers on a side stream (data/loader.py).  Both must deliver the batches of the reference's pipeline
+    (loader.py:97-113: shuffle buffer of batch_size, batches of batch_size, remainder dropped): same images and poses in the
+    same order, over two passes (the second pass of the resident path reads the device copy only); and a monitor's private
+    view must not advance the dataset's own shuffle generator."""
+    import numpy as np
+    from keras_nerf_amd.data.loader import DatasetLoader
+    from tests.synthetic_scene import write
+    root = write(str(tmp_path / "scene"), n=(7, 2, 2), wh=20)
+    seen = {}
+    for name, budget in (("resident", 64.0), ("staged", 0.0)):
+        tr = DatasetLoader(root, white_background=True).load_dataset(2, 16, 16, 2.0, 6.0, 64)[0]
+        tr.device_cache_gb = budget
+        passes = []
+        for _ in range(2):
+            passes.append([(imgs.cpu().numpy().copy(), o.cpu().numpy().copy(), d.cpu().numpy().copy(), t.cpu().numpy().copy()) for imgs, (o, d, t) in tr])
+        seen[name] = passes
+        assert len(passes[0]) == 3 and passes[0][0][0].shape == (2, 16, 16, 4)          # 7 images, batches of 2, remainder dropped
+        assert (tr._shared["dev"] is not None) == (name == "resident")
+    for p in range(2):
+        for (ia, oa, da, ta), (ib, ob, db, tb) in zip(seen["resident"][p], seen["staged"][p]):
+            np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(oa, ob); np.testing.assert_array_equal(da, db)
+            assert ta.shape == tb.shape and ta.min() >= 2.0 and ta.max() <= 6.0          # the jitter stream is redrawn per call: values differ
+    # a private view iterates without touching the parent's generator
+    tr = DatasetLoader(root, white_background=True).load_dataset(2, 16, 16, 2.0, 6.0, 64)[0]
+    state = tr._rng.bit_generator.state
+    view = tr.private_view(seed=5)
+    for _ in range(2):
+        assert len(list(view)) == 3
+    assert tr._rng.bit_generator.state == state
+    assert view._shared is tr._shared                                                     # ... while sharing the decoded / resident images
