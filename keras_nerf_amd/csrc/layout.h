@@ -83,8 +83,8 @@ using DefaultShape = Shape<8, 4>;
 // one more instantiation of the three big kernels: build.py compiles mlp_fwd / mlp_bwd / wgrad once per entry with
 // -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
 // instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
-#define KNERF_FUSED_SHAPES(X) X(0, 8, 4) X(1, 8, 2) X(2, 6, 3) X(3, 4, 2) X(4, 12, 4)
-constexpr int kNumFusedShapes = 5;
+#define KNERF_FUSED_SHAPES(X) X(0, 8, 4) X(1, 8, 2) X(2, 6, 3) X(3, 4, 2) X(4, 12, 4) X(5, 8, 3) X(6, 8, 5) X(7, 6, 2) X(8, 6, 4) X(9, 10, 5)
+constexpr int kNumFusedShapes = 10;
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
 constexpr int fused_shape_id(int n_layers, int skip_layer) {
 #define KNERF_X(I, NL, SK) if (n_layers == NL && skip_layer == SK) return I;
@@ -118,6 +118,31 @@ constexpr int fused_shape_id(int n_layers, int skip_layer) {
 #define KNERF_SLICE_4(DEF, EXT) DEF
 #else
 #define KNERF_SLICE_4(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(5)
+#define KNERF_SLICE_5(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_5(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(6)
+#define KNERF_SLICE_6(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_6(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(7)
+#define KNERF_SLICE_7(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_7(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(8)
+#define KNERF_SLICE_8(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_8(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(9)
+#define KNERF_SLICE_9(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_9(DEF, EXT) EXT
 #endif
 #define KNERF_PICK(I, DEF, EXT) KNERF_SLICE_##I(DEF, EXT)
 #define KNERF_HAS_DISPATCH KNERF_SLICE_OWNS(0)
