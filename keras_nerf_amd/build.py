@@ -20,7 +20,7 @@ SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.
 # per shape with -DKNERF_SHAPE_SLICE=<index> (that translation unit then defines the kernels of its shape only; slice 0 also holds
 # the run-time dispatchers), so the shapes build in parallel and the default shape's object is what it was before the others existed.
 SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
-N_SHAPE_SLICES = 10     # = kNumFusedShapes (knerf_api.hip static_asserts it)
+N_SHAPE_SLICES = 12     # = kNumFusedShapes (knerf_api.hip static_asserts it)
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]

@@ -21,7 +21,7 @@ template <class S>
 constexpr StoreSched<S::kBwdStages> make_bwd_stores() {
     StoreSched<S::kBwdStages> t{};
     for (int st = 0; st < S::kBwdStages; ++st)
-        t.st[st] = StoreStage{S::bwd_b0(st), st == 0 ? 1 : 16, 8, (st == 0 && !S::kSaveLastDz) ? 0 : 2, 0, 0};
+        t.st[st] = StoreStage{S::bwd_b0(st), st == 0 ? 1 : S::kKs, S::kOt, (st == 0 && !S::kSaveLastDz) ? 0 : 2, 0, 0};
     t.initial = 0;
     return t;
 }
@@ -96,7 +96,8 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
     pf.start<S::kBwdBlocks>(ring, lane);
     BwdWait<S> waits;
 
-    bf16x8 x[16], y[16];
+    constexpr int K = S::kKs, T = S::kOt;
+    bf16x8 x[K], y[K];
     auto zero_init = [](int) { return zero_acc(); };
     // masked epilogue: dz_l = dh_l * [h_l > 0], applied to the packed bf16 pairs with the forward's bit mask
     // (tile ot -> word ot>>1, byte lane ot&1; chain.h relu_mask_bits / apply_mask_packed)
@@ -110,18 +111,18 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
             // from the dz_head block and the mask block (wgrad_body.h wgrad_last_recompute) -- unless that job is the two-range
             // one of a concat layer (Shape::kSaveLastDz)
             if (layer != S::NL - 1 || S::kSaveLastDz) {
-                store_block(dz, 16 * layer + 2 * ot, lane, out[2 * ot]);
-                store_block(dz, 16 * layer + 2 * ot + 1, lane, out[2 * ot + 1]);
+                store_block(dz, K * layer + 2 * ot, lane, out[2 * ot]);
+                store_block(dz, K * layer + 2 * ot + 1, lane, out[2 * ot + 1]);
             }
         };
     };
     // B0: dz_head (r, g, b, sigma) -> dh_{NL-1} -> dz_{NL-1} (y)
-    dense_stage<0, 1, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zhead; }, mask_epi(y, S::NL - 1));
+    dense_stage<0, 1, T, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int) { return zhead; }, mask_epi(y, S::NL - 1));
     // Bq: dz_l -> dz_{l-1}, l = NL-q; odd stages read y and write x, even stages the other way round
     static_for<S::NL - 1>([&](auto q_) {
         constexpr int q = decltype(q_)::value + 1;
-        if constexpr (q % 2) dense_stage<S::bwd_b0(q), 16, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, S::NL - 1 - q));
-        else dense_stage<S::bwd_b0(q), 16, 8, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, S::NL - 1 - q));
+        if constexpr (q % 2) dense_stage<S::bwd_b0(q), K, T, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return y[ks]; }, mask_epi(x, S::NL - 1 - q));
+        else dense_stage<S::bwd_b0(q), K, T, S::kBwdBlocks>(ring, pf, lane, grp, waits, zero_init, [&](int ks) { return x[ks]; }, mask_epi(y, S::NL - 1 - q));
     });
     ring_finish<S::kBwdBlocks>(ring, grp);
 }

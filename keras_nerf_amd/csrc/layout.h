@@ -22,7 +22,6 @@
 
 namespace knerf {
 
-constexpr int kUnits = 256;
 constexpr int kLx = 10, kLd = 4;
 constexpr int kXyzDim = 63, kDirDim = 27;
 
@@ -32,46 +31,54 @@ constexpr int kXyzDim = 63, kDirDim = 27;
 // Shape<8, 4> is the reference's default and the shape every number in DESIGN.md is quoted for; the other instantiations
 // (knerf_api.hip kFusedShapes) share every line of kernel code with it.  Not covered (-> general-shape path, generic.hip): other
 // widths or encodings, fewer than 3 layers, a concat behind the LAST layer (the head would take [h ; xyz_enc ; dir_enc]).
-template <int NL_, int SK_>
+template <int NL_, int SK_, int U_ = 256>
 struct Shape {
-    static constexpr int NL = NL_, SK = SK_;
+    static constexpr int NL = NL_, SK = SK_, U = U_;
+    static constexpr int kKs = U / 16, kOt = U / 32;        // k-steps / out tiles of a U-wide layer: 16 / 8 at 256, 8 / 4 at 128
     static constexpr bool concat_in(int l) { return l >= 2 && l < NL && (l - 1) % SK == 0; }
     static constexpr bool kConcatBehindLast = (NL - 1) % SK == 0 && NL - 1 > 0;
-    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast;
+    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128);
     static constexpr int first_concat() { for (int l = 2; l < NL; ++l) if (concat_in(l)) return l; return 0; }
     static constexpr int kFirstConcat = first_concat();
-    // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias
-    static constexpr int fan_in(int l) { return l == 0 ? kXyzDim : (concat_in(l) ? kUnits + kXyzDim : kUnits); }
-    static constexpr int trunk_params() { int n = 0; for (int l = 0; l < NL; ++l) n += fan_in(l) * kUnits + kUnits; return n; }
+    // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias; behind the trunk
+    // sigma [U,1], features [U,U], rgb_features [U+27, U/2], rgb [U/2, 3]
+    static constexpr int fan_in(int l) { return l == 0 ? kXyzDim : (concat_in(l) ? U + kXyzDim : U); }
+    static constexpr int trunk_params() { int n = 0; for (int l = 0; l < NL; ++l) n += fan_in(l) * U + U; return n; }
     static constexpr int kTrunkParams = trunk_params();      // = offset of the sigma kernel
-    static constexpr int kParamCount = kTrunkParams + (256 + 1) + (256 * 256 + 256) + (283 * 128 + 128) + (128 * 3 + 3);
+    static constexpr int kHeadReal = U + kDirDim;            // rows of the rgb_features kernel = real rows of the composed head matrix
+    static constexpr int kParamCount = kTrunkParams + (U + 1) + (U * U + U) + (kHeadReal * (U / 2) + U / 2) + ((U / 2) * 3 + 3);
     // forward stream: stage st = trunk layer st (st < NL) or the head (st == NL); order: stage, out tile, k-step
     static constexpr int kFwdStages = NL + 1;
-    static constexpr int fwd_nks(int st) { return st == 0 ? 4 : st == NL ? 18 : (concat_in(st) ? 20 : 16); }
-    static constexpr int fwd_not(int st) { return st == NL ? 1 : 8; }
+    static constexpr int fwd_nks(int st) { return st == 0 ? 4 : st == NL ? kKs + 2 : (concat_in(st) ? kKs + 4 : kKs); }
+    static constexpr int fwd_not(int st) { return st == NL ? 1 : kOt; }
     static constexpr int fwd_b0(int st) { int n = 0; for (int q = 0; q < st; ++q) n += fwd_nks(q) * fwd_not(q); return n; }
     static constexpr int kFwdBlocks = fwd_b0(NL + 1);
-    static constexpr int kFwdBiasTiles = 8 * NL + 1;         // tiles of 32 fp32: 8 per trunk layer, 1 for the head
-    // backward (dgrad) stream: stage 0 = the head (1 k-step x 8 tiles), stage q = layer NL-q (16 x 8), q = 1 .. NL-1
+    static constexpr int kFwdBiasTiles = kOt * NL + 1;       // tiles of 32 fp32: kOt per trunk layer, 1 for the head
+    // backward (dgrad) stream: stage 0 = the head (1 k-step x kOt tiles), stage q = layer NL-q (kKs x kOt), q = 1 .. NL-1
     static constexpr int kBwdStages = NL;
-    static constexpr int bwd_b0(int st) { return st == 0 ? 0 : 8 + (st - 1) * 128; }
+    static constexpr int bwd_b0(int st) { return st == 0 ? 0 : kOt + (st - 1) * kKs * kOt; }
     static constexpr int kBwdBlocks = bwd_b0(NL);
-    // saved runs (see "saved tensors" below).  act: h1 .. h_{NL-1} (16 blocks each; h0 is recomputed), the 4 enc blocks directly
-    // behind h_{c-1} for the FIRST concat layer c (its weight-gradient job then reads ONE contiguous range; later concat layers read
-    // two), in front of everything when there is no concat layer, and the 2 dir blocks at the end, directly behind h_{NL-1} (the
-    // head job's range).  dz: dz_0 .. dz_{NL-1} (16 each), dz_head (2).
-    static constexpr int kActEnc = kFirstConcat ? 16 * (kFirstConcat - 1) : 0;
-    static constexpr int act_h(int l) { return 16 * (l - 1) + ((kFirstConcat == 0 || l >= kFirstConcat) ? 4 : 0); }   // l = 1 .. NL-1
-    static constexpr int kActDir = 16 * (NL - 1) + 4, kActBlocks = kActDir + 2;
-    static constexpr int kDzHead = 16 * NL, kDzBlocks = kDzHead + 2;
-    // dz of the last trunk layer is mask * (H dz_head) with 4 input channels: its weight-gradient job recomputes it (wgrad_body.h
-    // wgrad_last_recompute) and dgrad does not write it -- unless that layer takes [h ; xyz_enc] (then the job is the plain
-    // two-range one and dgrad writes the block run like any other)
-    static constexpr bool kSaveLastDz = concat_in(NL - 1);
+    // Two recomputations instead of saved tensors exist for the 256-wide trunk only (their weight-gradient jobs are written for 8
+    // waves = 8 column strips): h0 from the encoding (layer_1's job) and the last layer's dZ from dz_head.  At width 128 the forward
+    // saves h0 and dgrad writes the last dZ like any other.
+    static constexpr bool kSaveH0 = U != 256;
+    // saved runs (see "saved tensors" below).  act: [h0] h1 .. h_{NL-1} (kKs blocks each), the 4 enc blocks directly behind
+    // h_{c-1} for the FIRST concat layer c (its weight-gradient job then reads ONE contiguous range; later concat layers read two), in
+    // front of everything when there is no concat layer, and the 2 dir blocks at the end, directly behind h_{NL-1} (the head job's
+    // range).  dz: dz_0 .. dz_{NL-1} (kKs each), dz_head (2).
+    static constexpr int kFirstSaved = kSaveH0 ? 0 : 1;
+    static constexpr int kActEnc = kFirstConcat ? kKs * (kFirstConcat - kFirstSaved) : 0;
+    static constexpr int act_h(int l) { return kKs * (l - kFirstSaved) + ((kFirstConcat == 0 || l >= kFirstConcat) ? 4 : 0); }   // l = kFirstSaved .. NL-1
+    static constexpr int kActDir = kKs * (NL - kFirstSaved) + 4, kActBlocks = kActDir + 2;
+    static constexpr int kDzHead = kKs * NL, kDzBlocks = kDzHead + 2;
+    // dz of the last trunk layer is mask * (H dz_head) with 4 input channels: at width 256 its weight-gradient job recomputes it
+    // (wgrad_body.h wgrad_last_recompute) and dgrad does not write it -- unless that layer takes [h ; xyz_enc] (then the job is the
+    // plain two-range one and dgrad writes the block run like any other)
+    static constexpr bool kSaveLastDz = concat_in(NL - 1) || U != 256;
     static constexpr int kMaskBlocks = NL;                   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
     static constexpr int kWgradJobs = NL + 1, kHeadJob = NL; // job j = trunk layer j; the last one = the head
-    // collapsed head (below): 256 h features + 32 dir slots (27 real)
-    static constexpr int kHeadRows = 288;
+    // collapsed head (below): U h features + 32 dir slots (27 real)
+    static constexpr int kHeadRows = U + 32;
     static constexpr int kHeadOff = kParamCount;             // H[row][c], c = 0..2 rgb, 3 sigma
     static constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
     static constexpr int kExtParamCount = kHeadBiasOff + 4;  // floats in a net's weight buffer
@@ -79,15 +86,16 @@ struct Shape {
     static_assert(kSupported, "trunk shape not covered by the fused kernels");
 };
 using DefaultShape = Shape<8, 4>;
-// The trunk shapes the library is built for, X(index, n_layers, skip_layer); index 0 is the reference's default.  Every entry costs
+// The trunk shapes the library is built for, X(index, n_layers, skip_layer, dense_units); index 0 is the reference's default.  Every entry costs
 // one more instantiation of the three big kernels: build.py compiles mlp_fwd / mlp_bwd / wgrad once per entry with
 // -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
 // instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
-#define KNERF_FUSED_SHAPES(X) X(0, 8, 4) X(1, 8, 2) X(2, 6, 3) X(3, 4, 2) X(4, 12, 4) X(5, 8, 3) X(6, 8, 5) X(7, 6, 2) X(8, 6, 4) X(9, 10, 5)
-constexpr int kNumFusedShapes = 10;
+#define KNERF_FUSED_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
+    X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128)
+constexpr int kNumFusedShapes = 12;
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
-constexpr int fused_shape_id(int n_layers, int skip_layer) {
-#define KNERF_X(I, NL, SK) if (n_layers == NL && skip_layer == SK) return I;
+constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256) {
+#define KNERF_X(I, NL, SK, U) if (n_layers == NL && skip_layer == SK && dense_units == U) return I;
     KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
     return -1;
@@ -144,6 +152,16 @@ constexpr int fused_shape_id(int n_layers, int skip_layer) {
 #else
 #define KNERF_SLICE_9(DEF, EXT) EXT
 #endif
+#if KNERF_SLICE_OWNS(10)
+#define KNERF_SLICE_10(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_10(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(11)
+#define KNERF_SLICE_11(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_11(DEF, EXT) EXT
+#endif
 #define KNERF_PICK(I, DEF, EXT) KNERF_SLICE_##I(DEF, EXT)
 #define KNERF_HAS_DISPATCH KNERF_SLICE_OWNS(0)
 constexpr int kParamCount = DefaultShape::kParamCount;      // 595,844: knerf_param_count()
@@ -156,8 +174,8 @@ inline std::vector<TensorInfo> tensor_table() {
     std::vector<TensorInfo> t;
     int off = 0;
     auto add = [&](int fi, int fo) { t.push_back({off, fi, fo}); off += fi * fo; t.push_back({off, 1, fo}); off += fo; };
-    for (int l = 0; l < S::NL; ++l) add(S::fan_in(l), kUnits);
-    add(256, 1); add(256, 256); add(283, 128); add(128, 3);       // sigma, features, rgb_features, rgb
+    for (int l = 0; l < S::NL; ++l) add(S::fan_in(l), S::U);
+    add(S::U, 1); add(S::U, S::U); add(S::kHeadReal, S::U / 2); add(S::U / 2, 3);       // sigma, features, rgb_features, rgb
     return t;
 }
 // index of a tensor in the table: trunk layer l -> l; then sigma, features, rgb_features, rgb
@@ -174,7 +192,7 @@ template <class S> constexpr int LSIG = S::NL;
 // packing tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
 // the same identity) from M = [h ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
 // in an auxiliary buffer (optim.hip head_expand).
-// auxiliary gradient buffer of one net: M[row][c] (row = 0..255 h, 256..282 dir; c = 0..2), then s[c]
+// auxiliary gradient buffer of one net: M[row][c] (row = 0..U-1 h, U..U+26 dir; c = 0..2), then s[c] at kAuxS (sized for U = 256)
 constexpr int kAuxM = 0, kAuxS = 283 * 3, kAuxCount = 864;
 
 // ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
@@ -213,21 +231,22 @@ struct PackTables {
 };
 
 // row of the head matrix for k-step ks of the HEAD stage: h features, then the dir encoding slots
+template <class S>
 inline int head_in_row(int ks, int h, int j) {
-    if (ks < 16) return hid_feature(ks, h, j);
-    const int e = enc_feature(ks - 16, h, j, kLd);
-    return e < 0 ? -1 : 256 + e;
+    if (ks < S::kKs) return hid_feature(ks, h, j);
+    const int e = enc_feature(ks - S::kKs, h, j, kLd);
+    return e < 0 ? -1 : S::U + e;
 }
-template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= 283 || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
+template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= S::kHeadReal || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
 
 // input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
 template <class S>
 inline int fwd_in_row(int st, int ks, int h, int j) {
     if (st == 0) return enc_feature(ks, h, j, kLx);                          // layer_0: 63 inputs in 4 k-steps
-    if (st == S::NL) return head_in_row(ks, h, j);
-    if (ks < 16) return hid_feature(ks, h, j);                               // 256-wide
-    const int e = enc_feature(ks - 16, h, j, kLx);                           // concat layer: [h(256), xyz_enc(63)] (mlp.py:36-38)
-    return e < 0 ? -1 : 256 + e;
+    if (st == S::NL) return head_in_row<S>(ks, h, j);
+    if (ks < S::kKs) return hid_feature(ks, h, j);                           // U-wide
+    const int e = enc_feature(ks - S::kKs, h, j, kLx);                       // concat layer: [h(U), xyz_enc(63)] (mlp.py:36-38)
+    return e < 0 ? -1 : S::U + e;
 }
 
 template <class S>
@@ -266,8 +285,8 @@ inline void build_bwd(PackTables& pt) {
     pt.bwd.assign((size_t)S::kBwdBlocks * 512, -1);
     size_t blk = 0;
     for (int st = 0; st < S::kBwdStages; ++st) {
-        const int nks = st == 0 ? 1 : 16;
-        for (int ot = 0; ot < 8; ++ot)
+        const int nks = st == 0 ? 1 : S::kKs;
+        for (int ot = 0; ot < S::kOt; ++ot)
             for (int ks = 0; ks < nks; ++ks, ++blk)
                 for (int l = 0; l < 64; ++l) {
                     int r = l & 31, h = l >> 5, row = 32 * ot + r;   // row = input feature of the layer
@@ -335,12 +354,13 @@ struct WgradJob {
 };
 template <class S>
 constexpr WgradJob wgrad_job(int j) {
-    if (j == 0) return {0, S::kActEnc, S::kActEnc, 2, 0, 8, 0};
-    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), 9, S::kDzHead, 1, -1};          // [h ; dir] x (r,g,b,sigma): dir sits behind h
-    if (j == 1) return {1, S::kActEnc, S::kActEnc, 8, 16, 8, 1};                                       // the table rows are h0 features
-    if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - 16, 10, 16 * j, 8, j};                // tile 8 + k -> block act_blk2 + 16 + 2k
-    if (j == S::NL - 1) return {4, S::act_h(j - 1), S::act_h(j - 1), 8, 16 * j, 8, j};
-    return {2, S::act_h(j - 1), S::act_h(j - 1), 8, 16 * j, 8, j};
+    constexpr int K = S::kKs, T = S::kOt;
+    if (j == 0) return {0, S::kActEnc, S::kActEnc, 2, 0, T, 0};
+    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), T + 1, S::kDzHead, 1, -1};   // [h ; dir] x (r,g,b,sigma): dir sits behind h
+    if (j == 1 && !S::kSaveH0) return {1, S::kActEnc, S::kActEnc, T, K, T, 1};                        // h0 recomputed: the table rows are h0 features
+    if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - K, T + 2, K * j, T, j};             // input tile T + k -> block act_blk2 + K + 2k
+    if (j == S::NL - 1 && !S::kSaveLastDz) return {4, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
+    return {2, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
 }
 // in_row of job jb for tile-row index tr (0..32*n_it-1) in *natural tr-read order*: the transposed read un-permutes
 // hidden tensors (row = feature), and presents enc/dir blocks in slot order (q = tr>>4, c16 = tr&15 ->
@@ -352,8 +372,8 @@ inline int wgrad_in_row(int jb, int tr) {
     auto encrow = [](int tr_, int L) { int q = tr_ >> 4, c = tr_ & 15; return enc_feature(q, slot_from_c16_h(c), slot_from_c16_j(c), L); };
     const int kind = wgrad_job<S>(jb).kind;
     if (kind == 0) return encrow(tr, kLx);
-    if (kind == 3) return tr < 256 ? tr : (encrow(tr - 256, kLx) < 0 ? -1 : 256 + encrow(tr - 256, kLx));
-    if (kind == 5) return tr < 256 ? tr : (encrow(tr - 256, kLd) < 0 ? -1 : 256 + encrow(tr - 256, kLd));
+    if (kind == 3) return tr < S::U ? tr : (encrow(tr - S::U, kLx) < 0 ? -1 : S::U + encrow(tr - S::U, kLx));
+    if (kind == 5) return tr < S::U ? tr : (encrow(tr - S::U, kLd) < 0 ? -1 : S::U + encrow(tr - S::U, kLd));
     return tr;
 }
 // destination of wgrad output element (tile-row tr, column tc): index into the flat gradient, kAuxBase + index into the
@@ -366,7 +386,7 @@ inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) 
         if (tr == -2) return tc == 3 ? bidx(tt, LSIG<S>, 0) : S::kAuxBase + kAuxS + tc;
         const int row = wgrad_in_row<S>(jb, tr);
         if (row < 0) return -1;
-        if (tc == 3) return row < 256 ? kidx(tt, LSIG<S>, row, 0) : -1;
+        if (tc == 3) return row < S::U ? kidx(tt, LSIG<S>, row, 0) : -1;
         return S::kAuxBase + kAuxM + row * 3 + tc;
     }
     if (tr == -2) return bidx(tt, J.layer, tc);
@@ -375,7 +395,7 @@ inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) 
 
 // ---- run-time view of a shape (host): what knerf_api.hip needs to size buffers and pick instantiations
 struct ShapeInfo {
-    int id, n_layers, skip;
+    int id, n_layers, skip, units;
     int param_count, ext_param_count, trunk_params, head_off, head_bias_off;
     int fwd_blocks, fwd_bias_tiles, bwd_blocks;
     int act_blocks, dz_blocks, mask_blocks;
@@ -385,7 +405,7 @@ struct ShapeInfo {
 template <class S>
 inline ShapeInfo make_shape_info(int id) {
     ShapeInfo i{};
-    i.id = id; i.n_layers = S::NL; i.skip = S::SK;
+    i.id = id; i.n_layers = S::NL; i.skip = S::SK; i.units = S::U;
     i.param_count = S::kParamCount; i.ext_param_count = S::kExtParamCount; i.trunk_params = S::kTrunkParams;
     i.head_off = S::kHeadOff; i.head_bias_off = S::kHeadBiasOff;
     i.fwd_blocks = S::kFwdBlocks; i.fwd_bias_tiles = S::kFwdBiasTiles; i.bwd_blocks = S::kBwdBlocks;
@@ -396,7 +416,7 @@ inline ShapeInfo make_shape_info(int id) {
 }
 inline const ShapeInfo& shape_info(int id) {
     static const ShapeInfo all[kNumFusedShapes] = {
-#define KNERF_X(I, NL, SK) make_shape_info<Shape<NL, SK>>(I),
+#define KNERF_X(I, NL, SK, U) make_shape_info<Shape<NL, SK, U>>(I),
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
     };

@@ -56,7 +56,7 @@ template <class S>
 constexpr StoreSched<S::kFwdStages> make_fwd_stores() {
     StoreSched<S::kFwdStages> t{};
     for (int st = 0; st < S::kFwdStages; ++st)
-        t.st[st] = StoreStage{S::fwd_b0(st), S::fwd_nks(st), S::fwd_not(st), (st == 0 || st == S::NL) ? 0 : 2,
+        t.st[st] = StoreStage{S::fwd_b0(st), S::fwd_nks(st), S::fwd_not(st), (st == S::NL || (st == 0 && !S::kSaveH0)) ? 0 : 2,
                               st == S::NL ? 0 : (st == S::NL - 1 ? 3 : 1), 0};
     t.initial = 4;
     return t;
@@ -133,9 +133,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     std::conditional_t<SAVE, FwdWaitSave<S>, FwdWaitPlain<S>> waits;
 #endif
 
-    bf16x8 x[16], y[16];
+    constexpr int K = S::kKs, T = S::kOt;        // k-steps and out tiles of a U-wide layer (16 / 8 at width 256)
+    bf16x8 x[K], y[K];
     // relu epilogue of a trunk layer: out -> y (or x), activations + mask saved in training
-    auto relu_epi = [&](bf16x8 (&out)[16], int layer, unsigned (&mbits)[4]) {
+    auto relu_epi = [&](bf16x8 (&out)[K], int layer, unsigned (&mbits)[4]) {
         return [&, layer](int ot, f32x16 acc) {
             pack_acc(acc, out[2 * ot], out[2 * ot + 1]);
             out[2 * ot] = relu_packed(out[2 * ot]);
@@ -143,37 +144,37 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
             if (SAVE) {
                 // two blocks per out tile, right behind it (h0 is not saved at all: the layer_1 wgrad job recomputes it from enc,
                 // layout.h); longer bursts per wave were measured in round 2 and are slower
-                if (layer > 0) {
+                if (layer > 0 || S::kSaveH0) {
                     store_block(act, S::act_h(layer) + 2 * ot, lane, out[2 * ot]);
                     store_block(act, S::act_h(layer) + 2 * ot + 1, lane, out[2 * ot + 1]);
                 }
                 // mask word of tile ot in byte lanes: even tile -> bits 0-7 / 16-23, odd tile -> bits 8-15 / 24-31
                 const unsigned m = relu_mask_bits(out[2 * ot], out[2 * ot + 1]);
                 if (ot & 1) mbits[ot >> 1] |= m << 8; else mbits[ot >> 1] = m;
-                if (ot == 7) store16_wt(maskp, (unsigned)(layer * kSavedBlockStride + lane * 16), u32x4{mbits[0], mbits[1], mbits[2], mbits[3]});
+                if (ot == T - 1) store16_wt(maskp, (unsigned)(layer * kSavedBlockStride + lane * 16), u32x4{mbits[0], mbits[1], mbits[2], mbits[3]});
             }
         };
     };
-    unsigned mb[4];
+    unsigned mb[4] = {0u, 0u, 0u, 0u};      // T / 2 words carry bits (width 128: two of the four)
     auto bias_init = [&](int base) { return [&, base](int ot) { return bias_acc(bias_lds, base + ot, h); }; };
 
     // layer_0: 63 -> 256, into x
-    dense_stage<0, 4, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
+    dense_stage<0, 4, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
     // layers 1 .. NL-1, ping-pong x -> y -> x ...: even layers write x, odd layers y.  A concat layer takes [h, xyz_enc] (skip concat:
     // h first, input second; mlp.py:36-38) -- the encoding is recomputed where it is consumed instead of pinning 16 VGPRs
     // across the trunk: 42 v_sin per re-encode vs ~1000 MFMAs per tile
     static_for<S::NL - 1>([&](auto l_) {
         constexpr int l = decltype(l_)::value + 1;
-        auto run = [&](bf16x8 (&in)[16], bf16x8 (&out)[16]) {
+        auto run = [&](bf16x8 (&in)[K], bf16x8 (&out)[K]) {
             if constexpr (S::concat_in(l)) {
                 bf16x8 encc[4];
                 encode<kLx, 4>(px, py, pz, h, encc);
-                dense_stage<S::fwd_b0(l), 20, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * l),
-                                                                [&](int ks) { return ks < 16 ? in[ks < 16 ? ks : 0] : encc[ks >= 16 ? ks - 16 : 0]; },
-                                                                relu_epi(out, l, mb));
+                dense_stage<S::fwd_b0(l), K + 4, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * l),
+                                                                   [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : encc[ks >= K ? ks - K : 0]; },
+                                                                   relu_epi(out, l, mb));
             } else {
-                dense_stage<S::fwd_b0(l), 16, 8, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * l), [&](int ks) { return in[ks]; },
-                                                                relu_epi(out, l, mb));
+                dense_stage<S::fwd_b0(l), K, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * l), [&](int ks) { return in[ks]; },
+                                                               relu_epi(out, l, mb));
             }
         };
         if constexpr (l % 2) run(x, y); else run(y, x);
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         for (int q = 0; q < 2; ++q) store_block(act, S::kActDir + q, lane, dirc[q]);
     }
 #endif
-    auto head = [&](bf16x8 (&in)[16]) {
-        dense_stage<S::fwd_b0(S::NL), 18, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(8 * S::NL),
-                                [&](int ks) { return ks < 16 ? in[ks < 16 ? ks : 0] : dirc[ks >= 16 ? ks - 16 : 0]; },
+    auto head = [&](bf16x8 (&in)[K]) {
+        dense_stage<S::fwd_b0(S::NL), K + 2, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * S::NL),
+                                [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : dirc[ks >= K ? ks - K : 0]; },
                                 [&](int, f32x16 acc) {
                                     if (valid && h == 0) {
                                         f32x4 r;
@@ -250,14 +251,14 @@ hipError_t launch_mlp_fwd_t(const FwdArgs& a, bool save, hipStream_t stream) {
 }
 
 // explicit instantiation of this translation unit's shape(s), `extern template` for the others (layout.h KNERF_FUSED_SHAPES)
-#define KNERF_X(I, NL, SK) KNERF_PICK(I, template, extern template) hipError_t launch_mlp_fwd_t<Shape<NL, SK>>(const FwdArgs&, bool, hipStream_t);
+#define KNERF_X(I, NL, SK, U) KNERF_PICK(I, template, extern template) hipError_t launch_mlp_fwd_t<Shape<NL, SK, U>>(const FwdArgs&, bool, hipStream_t);
 KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
 
 #if KNERF_HAS_DISPATCH
 hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
     switch (a.shape) {
-#define KNERF_X(I, NL, SK) case I: return launch_mlp_fwd_t<Shape<NL, SK>>(a, save, stream);
+#define KNERF_X(I, NL, SK, U) case I: return launch_mlp_fwd_t<Shape<NL, SK, U>>(a, save, stream);
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
         default: return hipErrorInvalidValue;

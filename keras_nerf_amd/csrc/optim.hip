@@ -98,117 +98,121 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // Offsets of the six tensors behind the trunk in the flat parameter vector (Keras order: sigma, features, rgb_features, rgb)
 namespace {
 // the six tensors behind the trunk, from the offset of the first float behind the last trunk layer (layout.h Shape::kTrunkParams)
+// and the trunk width U: sigma [U,1], features [U,U], rgb_features [U+27, U/2], rgb [U/2, 3]
 struct HeadOff {
     int ws, bs, wf, bf, wr, br, wc, bc, head, head_bias;
-    __device__ explicit HeadOff(int off_l) {
-        ws = off_l; bs = ws + 256;                     // sigma kernel [256,1], bias [1]
-        wf = bs + 1; bf = wf + 256 * 256;              // features kernel [256,256], bias [256]
-        wr = bf + 256; br = wr + 283 * 128;            // rgb_features kernel [283,128], bias [128]
-        wc = br + 128; bc = wc + 128 * 3;              // rgb kernel [128,3], bias [3]
-        head = bc + 3; head_bias = head + 288 * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
+    __device__ HeadOff(int off_l, int U) {
+        ws = off_l; bs = ws + U;
+        wf = bs + 1; bf = wf + U * U;
+        wr = bf + U; br = wr + (U + 27) * (U / 2);
+        wc = br + U / 2; bc = wc + (U / 2) * 3;
+        head = bc + 3; head_bias = head + (U + 32) * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
     }
 };
 static_assert(DefaultShape::kTrunkParams + 257 + 256 * 257 + 283 * 128 + 128 + 128 * 3 + 3 == DefaultShape::kParamCount && DefaultShape::kHeadRows == 288, "head tensor offsets");
+constexpr int kMaxU = 256;
 }  // namespace
 
-// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < 256);  H[256+m][0..2] = (W_r2 W_c)[m], H[256+m][3] = 0 (m < 27);
-// bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP.
-__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l) {
+// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < U);  H[U+m][0..2] = (W_r2 W_c)[m], H[U+m][3] = 0 (m < 27);
+// bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP at U = 256.
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l, int U) {
     float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
-    const HeadOff o(off_l);
-    __shared__ float P[283][3];          // W_r W_c : rows 0..255 = W_r1 W_c, 256..282 = W_r2 W_c
-    __shared__ float wc[128][3];
+    const HeadOff o(off_l, U);
+    const int U2 = U / 2, R = U + 27;
+    __shared__ float P[kMaxU + 27][3];   // W_r W_c : rows 0..U-1 = W_r1 W_c, U..U+26 = W_r2 W_c
+    __shared__ float wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 128 * 3; i += 256) wc[i / 3][i % 3] = w[o.wc + i];
+    for (int i = tid; i < U2 * 3; i += 256) wc[i / 3][i % 3] = w[o.wc + i];
     __syncthreads();
-    for (int r = tid; r < 283; r += 256) {
+    for (int r = tid; r < R; r += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wr = w + o.wr + (size_t)r * 128;
-        for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
+        const float* wr = w + o.wr + (size_t)r * U2;
+        for (int k = 0; k < U2; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
         P[r][0] = a0; P[r][1] = a1; P[r][2] = a2;
     }
     __syncthreads();
     float* H = w + o.head;
-    {   // row tid of A = W_f P1
+    if (tid < U) {   // row tid of A = W_f P1
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wf = w + o.wf + (size_t)tid * 256;
-        for (int j = 0; j < 256; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
+        const float* wf = w + o.wf + (size_t)tid * U;
+        for (int j = 0; j < U; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
         H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[o.ws + tid];
     }
     if (tid < 32) {
-        const int r = 256 + tid;
+        const int r = U + tid;
         const bool real = tid < 27;
         H[r * 4 + 0] = real ? P[r][0] : 0.f; H[r * 4 + 1] = real ? P[r][1] : 0.f; H[r * 4 + 2] = real ? P[r][2] : 0.f; H[r * 4 + 3] = 0.f;
     }
     if (tid < 3) {
         float c = w[o.bc + tid];
-        for (int j = 0; j < 256; ++j) c += w[o.bf + j] * P[j][tid];
-        for (int k = 0; k < 128; ++k) c += w[o.br + k] * wc[k][tid];
+        for (int j = 0; j < U; ++j) c += w[o.bf + j] * P[j][tid];
+        for (int k = 0; k < U2; ++k) c += w[o.br + k] * wc[k][tid];
         w[o.head_bias + tid] = c;
     }
     if (tid == 3) w[o.head_bias + 3] = w[o.bs];
 }
-hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, hipStream_t stream) {
-    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params);
+hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, hipStream_t stream) {
+    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units);
     return hipGetLastError();
 }
 
-// aux: M[row][c] = sum_s [h7 ; dir][s][row] dz_rgb[s][c] (row < 283), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..255,
-// M2 = rows 256..282, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
+// aux: M[row][c] = sum_s [h ; dir][s][row] dz_rgb[s][c] (row < U + 27), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..U-1,
+// M2 = rows U..U+26, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
 //   d rgb/kernel          = W_r1^T Q + W_r2^T M2 + b_r (x) s        d rgb/bias          = s
 //   d rgb_features/kernel = [Q ; M2] W_c^T                          d rgb_features/bias = s W_c^T
 //   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
 // -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
 // evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
-struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l; };
+struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l, U; };
 __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
-    const HeadOff o(a.off_l);
-    __shared__ float M[283][3], s_[3], P1[256][3], Q[256][3], wc[128][3];
+    const int U = a.U, U2 = U / 2, R = U + 27;
+    const HeadOff o(a.off_l, U);
+    __shared__ float M[kMaxU + 27][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 283 * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
+    for (int i = tid; i < R * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
     if (tid < 3) s_[tid] = aux[kAuxS + tid];
-    for (int i = tid; i < 128 * 3; i += 1024) wc[i / 3][i % 3] = w[o.wc + i];
+    for (int i = tid; i < U2 * 3; i += 1024) wc[i / 3][i % 3] = w[o.wc + i];
     __syncthreads();
     for (int i = tid; i < kAuxCount; i += 1024) aux[i] = 0.f;
-    if (tid < 256) {            // P1 row tid
+    if (tid < U) {              // P1 row tid
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wr = w + o.wr + (size_t)tid * 128;
-        for (int k = 0; k < 128; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
+        const float* wr = w + o.wr + (size_t)tid * U2;
+        for (int k = 0; k < U2; ++k) { const float v = wr[k]; a0 += v * wc[k][0]; a1 += v * wc[k][1]; a2 += v * wc[k][2]; }
         P1[tid][0] = a0; P1[tid][1] = a1; P1[tid][2] = a2;
-    } else if (tid < 512) {     // Q row j: column j of W_f against M1 (coalesced over j)
+    } else if (tid >= 256 && tid < 256 + U) {     // Q row j: column j of W_f against M1 (coalesced over j)
         const int j = tid - 256;
         const float bf = w[o.bf + j];
         float a0 = bf * s_[0], a1 = bf * s_[1], a2 = bf * s_[2];
-        for (int i = 0; i < 256; ++i) { const float v = w[o.wf + (size_t)i * 256 + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
+        for (int i = 0; i < U; ++i) { const float v = w[o.wf + (size_t)i * U + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
         Q[j][0] = a0; Q[j][1] = a1; Q[j][2] = a2;
     }
     __syncthreads();
-    // features: kernel [256,256] += M1 P1^T, bias += s P1^T
-    for (int e = tid; e < 256 * 256; e += 1024) {
-        const int i = e >> 8, j = e & 255;
+    // features: kernel [U,U] += M1 P1^T, bias += s P1^T
+    for (int e = tid; e < U * U; e += 1024) {
+        const int i = e / U, j = e - i * U;
         grad[o.wf + e] += M[i][0] * P1[j][0] + M[i][1] * P1[j][1] + M[i][2] * P1[j][2];
     }
-    if (tid < 256) grad[o.bf + tid] += s_[0] * P1[tid][0] + s_[1] * P1[tid][1] + s_[2] * P1[tid][2];
-    // rgb_features: kernel [283,128] += [Q ; M2] W_c^T, bias += s W_c^T
-    for (int e = tid; e < 283 * 128; e += 1024) {
-        const int r = e >> 7, k = e & 127;
-        const float* v = r < 256 ? Q[r] : M[r];
+    if (tid < U) grad[o.bf + tid] += s_[0] * P1[tid][0] + s_[1] * P1[tid][1] + s_[2] * P1[tid][2];
+    // rgb_features: kernel [U+27, U/2] += [Q ; M2] W_c^T, bias += s W_c^T
+    for (int e = tid; e < R * U2; e += 1024) {
+        const int r = e / U2, k = e - r * U2;
+        const float* v = r < U ? Q[r] : M[r];
         grad[o.wr + e] += v[0] * wc[k][0] + v[1] * wc[k][1] + v[2] * wc[k][2];
     }
-    if (tid < 128) grad[o.br + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
-    // rgb: kernel [128,3] += W_r1^T Q + W_r2^T M2 + b_r (x) s, bias += s
-    if (tid < 384) {
+    if (tid < U2) grad[o.br + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
+    // rgb: kernel [U/2,3] += W_r1^T Q + W_r2^T M2 + b_r (x) s, bias += s
+    if (tid < U2 * 3) {
         const int k = tid / 3, c = tid % 3;
         float a = w[o.br + k] * s_[c];
-        for (int j = 0; j < 256; ++j) a += w[o.wr + (size_t)j * 128 + k] * Q[j][c];
-        for (int m = 256; m < 283; ++m) a += w[o.wr + (size_t)m * 128 + k] * M[m][c];
+        for (int j = 0; j < U; ++j) a += w[o.wr + (size_t)j * U2 + k] * Q[j][c];
+        for (int m = U; m < R; ++m) a += w[o.wr + (size_t)m * U2 + k] * M[m][c];
         grad[o.wc + tid] += a;
     }
     if (tid < 3) grad[o.bc + tid] += s_[tid];
 }
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, hipStream_t stream) {
-    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params};
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, hipStream_t stream) {
+    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units};
     hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }

@@ -168,7 +168,7 @@ __device__ __forceinline__ int wait_barrier_next(const Seq& seq, int idx) {
     }
 }
 
-// act_blk: first act block of input tiles 0..7; act_blk2 + 16: first block of tiles 8.. (a concat layer's encoding: directly behind
+// act_blk: first act block of the input's h tiles; act_blk2 + S::kKs: first block of the tiles behind them (a concat layer's encoding: directly behind
 // its h for the first concat layer of a shape -- act_blk2 == act_blk, one contiguous range -- elsewhere for later ones)
 template <class S, int NI, int NO, class Seq>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int act_blk2, const int dz_blk,
@@ -223,7 +223,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
-            const int blk = (ok ? b : 0) + ((ok && b >= 16) ? act_blk2 : act_blk);         // block of the tile's act run
+            const int blk = (ok ? b : 0) + ((ok && b >= S::kKs) ? act_blk2 : act_blk);     // block of the tile's act run (h: S::kKs blocks)
 #ifdef KNERF_ABLATE_ENC_IO     // timing experiment only: the enc / dir blocks come from tile 0 (L2 hits) -- what wgrad would gain if it re-derived them for free
             const bool is_enc = (blk >= S::kActEnc && blk < S::kActEnc + 4) || blk >= S::kActDir;
             const char* base = is_enc ? a.act + lane * 16 : tile_in;
@@ -613,12 +613,10 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradArgs& a, int job, cons
         constexpr int j = decltype(j_)::value;
         constexpr WgradJob J = wgrad_job<S>(j);
         if (job == j) {
-            if constexpr (J.kind == 0) wgrad_job_body<S, 2, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);
-            else if constexpr (J.kind == 1) wgrad_l1_recompute<S>(a, seq, smem);                               // h0 recomputed from enc
-            else if constexpr (J.kind == 2) wgrad_job_body<S, 8, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);
-            else if constexpr (J.kind == 3) wgrad_job_body<S, 10, 8>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);   // [h ; enc]
-            else if constexpr (J.kind == 4) wgrad_last_recompute<S>(a, seq, smem);                             // dz recomputed from dz_head and the mask
-            else wgrad_job_body<S, 9, 1>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);                    // head: [h ; dir] x (r, g, b, sigma)
+            if constexpr (J.kind == 1) wgrad_l1_recompute<S>(a, seq, smem);                                    // h0 recomputed from enc (width 256)
+            else if constexpr (J.kind == 4) wgrad_last_recompute<S>(a, seq, smem);                             // dz recomputed from dz_head and the mask (width 256)
+            // first layer <2, T>, plain <T, T>, concat <T + 2, T>, head <T + 1, 1>  (T = U / 32 tiles: <2,8> <8,8> <10,8> <9,1> at width 256)
+            else wgrad_job_body<S, J.n_it, J.n_ot>(a, j, J.act_blk, J.act_blk2, J.dz_blk, seq, smem);
         }
     });
 }

@@ -163,6 +163,6 @@ def test_invalid_architecture_fails_loudly():
     for bad in (dict(dense_units=1), dict(n_layers=0), dict(skip_layer=0), dict(pos_emb_xyz=-1), dict(n_coarse=1), dict(n_coarse=300, n_fine=300)):
         with pytest.raises(ValueError):
             KnerfContext(**bad)
-    ctx = KnerfContext(dense_units=128)          # non-default shapes run on the general-shape kernels (test_gpu_generic.py)
+    ctx = KnerfContext(dense_units=128)          # other shapes: further fused instantiations (test_gpu_fused_shapes.py) or the general-shape kernels (test_gpu_generic.py)
     assert ctx.param_count != KnerfContext().param_count
     ctx.close()

@@ -1,5 +1,5 @@
 """The fused chain kernels for trunk shapes other than the reference's default (round 3; csrc/layout.h KNERF_FUSED_SHAPES: the same
-kernel source instantiated per shape): `NeRF(n_layers=, skip_layer=)` variants of width 256 with the reference's encodings
+kernel source instantiated per shape): `NeRF(n_layers=, skip_layer=, dense_units=)` variants of width 256 and 128 with the reference's encodings
 (train_single.py:34-36), against the oracle at the default shape's tolerances, against the general-shape kernels, bit-reproducible
 in deterministic mode and exact under dead-tile skipping.
 
@@ -8,7 +8,9 @@ in deterministic mode and exact under dead-tile skipping.
   6 x 256 / skip 3   one concat (layer 4); fewer layers
   4 x 256 / skip 2   the shortest covered: layer 3 is first concat AND last layer
   12 x 256 / skip 4  two concats (layers 5 and 9), twelve mask blocks per tile, the longest weight streams
-  8/3, 8/5, 6/2, 6/4, 10/5   further pairs of the built-in list (csrc/layout.h KNERF_FUSED_SHAPES)"""
+  8/3, 8/5, 6/2, 6/4, 10/5   further pairs of the built-in list (csrc/layout.h KNERF_FUSED_SHAPES)
+  8 x 128 / skip 4, 4 x 128 / skip 2   HALF the width: four output tiles and eight k-steps per layer, a 160-row head, h0 and the
+                     last layer's dZ saved instead of recomputed (the two recomputing weight-gradient jobs are width-256 code)"""
 import numpy as np
 import pytest
 import torch
@@ -21,11 +23,11 @@ from keras_nerf_amd.debug import debug_buffer
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(8, 2), (6, 3), (4, 2), (12, 4), (8, 3), (8, 5), (6, 2), (6, 4), (10, 5)]
+SHAPES = [(8, 2, 256), (6, 3, 256), (4, 2, 256), (12, 4, 256), (8, 3, 256), (8, 5, 256), (6, 2, 256), (6, 4, 256), (10, 5, 256), (8, 4, 128), (4, 2, 128)]
 
 
-def _cfg(nl, sk):
-    return O.NerfConfig(n_layers=nl, dense_units=256, skip_layer=sk)
+def _cfg(nl, sk, units=256):
+    return O.NerfConfig(n_layers=nl, dense_units=units, skip_layer=sk)
 
 
 def _ctx(P, **kw):
@@ -37,9 +39,9 @@ def _ctx(P, **kw):
     return ctx
 
 
-@pytest.mark.parametrize("nl,sk", SHAPES)
-def test_fused_shape_against_oracle_and_general_path(nl, sk):
-    cfg = _cfg(nl, sk)
+@pytest.mark.parametrize("nl,sk,units", SHAPES)
+def test_fused_shape_against_oracle_and_general_path(nl, sk, units):
+    cfg = _cfg(nl, sk, units)
     # glorot x 1.5 as in the other parity tests; plain glorot for the 12-layer trunk: twelve x1.5-gain layers amplify the rounding
     # differences between ANY two bf16 implementations (fused 1.6e-2 / 3.6e-2 against the oracle's emulation there, decreasing
     # smoothly from layer_0 to layer_11; 4.8e-3 at gain 1, the same as the general-shape kernels: tools/shape_diag.py)
@@ -62,14 +64,14 @@ def test_fused_shape_against_oracle_and_general_path(nl, sk):
     rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
     rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=O.FUSED)
     ec, ef = per_tensor_err(g[:n], O.flatten_params(gc), cfg), per_tensor_err(g[n:], O.flatten_params(gf), cfg)
-    log_stats(f"fused_shape_{nl}x256_skip{sk}", coarse_worst=ec[0], fine_worst=ef[0], loss_c=abs(float(loss[0]) - float(lc)),
+    log_stats(f"fused_shape_{nl}x{units}_skip{sk}", coarse_worst=ec[0], fine_worst=ef[0], loss_c=abs(float(loss[0]) - float(lc)),
               loss_f=abs(float(loss[1]) - float(lf)), img_c=float(np.abs(ci - rc["image"]).max()), img_f=float(np.abs(fi - rf["image"]).max()))
     # the general-shape kernels on the same problem against the same oracle, for the log
     gg, lg = res[True][0], res[True][1]
     rf_g = O.chunk_loss_and_grads(P["fp"], o, d, res[True][4], img, cfg, True, emulate_bf16=O.FUSED)
     gc_err = per_tensor_err(gg[:n], O.flatten_params(gc), cfg)[0]
     gf_err = per_tensor_err(gg[n:], O.flatten_params(rf_g[2]), cfg)[0]
-    log_stats(f"fused_shape_{nl}x256_skip{sk}_general_path_vs_oracle", coarse_worst=gc_err, fine_worst=gf_err)
+    log_stats(f"fused_shape_{nl}x{units}_skip{sk}_general_path_vs_oracle", coarse_worst=gc_err, fine_worst=gf_err)
     # the default shape's tolerance -- or, where the problem instance itself is ill-conditioned (the general-shape kernels, a
     # different bf16 implementation of the same contract, are just as far from the oracle's emulation: 8/3 1.8e-2 / 2.3e-2,
     # 6/4 1.4e-2), that distance with a margin
@@ -85,11 +87,11 @@ def test_fused_shape_against_oracle_and_general_path(nl, sk):
     assert np.abs(lg - loss).max() < 2e-3
 
 
-@pytest.mark.parametrize("nl,sk", [(8, 2), (4, 2)])
-def test_fused_shape_deterministic_and_skipping_exact(nl, sk):
+@pytest.mark.parametrize("nl,sk,units", [(8, 2, 256), (4, 2, 256), (8, 4, 128)])
+def test_fused_shape_deterministic_and_skipping_exact(nl, sk, units):
     """two deterministic launches bit-identical; with sigma's bias lowered (dead tiles) skipping on = off, bit for bit"""
     from keras_nerf_amd.runtime import KnerfContext
-    cfg = _cfg(nl, sk)
+    cfg = _cfg(nl, sk, units)
     P = make_problem(n_images=2, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
     names = [x[0] for x in O.layer_shapes(cfg)]
     si = 2 * names.index("sigma") + 1
@@ -115,13 +117,13 @@ def test_fused_shape_deterministic_and_skipping_exact(nl, sk):
         assert torch.equal(g.view(torch.int32), g0.view(torch.int32)), (key, float((g - g0).abs().max()))
         assert torch.equal(l.view(torch.int32), l0.view(torch.int32))
     dead = 1.0 - out[1, 0][2] / out[1, 0][3]
-    log_stats(f"fused_shape_{nl}x256_skip{sk}_dead_tiles", dead=dead)
+    log_stats(f"fused_shape_{nl}x{units}_skip{sk}_dead_tiles", dead=dead)
     assert 0.003 < dead < 0.99, dead           # measured 1.5 % (8/2), 5.0 % (4/2): there are dead tiles to skip
 
 
 def test_shapes_outside_the_fused_set_use_the_general_path():
     from keras_nerf_amd.runtime import KnerfContext
-    for kw in (dict(n_layers=8, dense_units=128, skip_layer=4), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
+    for kw in (dict(n_layers=8, dense_units=64, skip_layer=4), dict(n_layers=6, dense_units=128, skip_layer=3), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
                dict(n_layers=8, dense_units=256, skip_layer=4, pos_emb_xyz=6), dict(n_layers=7, dense_units=256, skip_layer=3)):
         ctx = KnerfContext(white_background=True, **kw)
         assert ctx.get_option("general_shape_path") == 1.0, kw

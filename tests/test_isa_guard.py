@@ -82,11 +82,11 @@ def isa():
 
 EXPECT = {
     # kernel-name fragment: (file, instantiation tags, {mnemonic: count})
-    # (kernels are templates on the trunk shape: Shape<8, 4> = "5ShapeILi8ELi4EEE" in the mangled names)
-    "mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb1E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 127}),
-    "mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb0E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 1}),
-    "mlp_bwd_kernelINS_5ShapeILi8ELi4EEE": ("mlp_bwd", 2, {"v_mfma_f32_32x32x16_bf16": 904, "global_load_lds_dwordx4": 234, "global_store_dwordx4": 113}),
-    "wgrad_kernelINS_5ShapeILi8ELi4EEE": ("wgrad", 4, {"v_mfma_f32_32x32x16_bf16": 150, "global_load_lds_dwordx4": 168}),
+    # (kernels are templates on the trunk shape: Shape<8, 4, 256> = "5ShapeILi8ELi4ELi256EEE" in the mangled names)
+    "mlp_fwd_kernelINS_5ShapeILi8ELi4ELi256EEELb1E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 127}),
+    "mlp_fwd_kernelINS_5ShapeILi8ELi4ELi256EEELb0E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 978, "global_load_lds_dwordx4": 254, "global_store_dwordx4": 1}),
+    "mlp_bwd_kernelINS_5ShapeILi8ELi4ELi256EEE": ("mlp_bwd", 2, {"v_mfma_f32_32x32x16_bf16": 904, "global_load_lds_dwordx4": 234, "global_store_dwordx4": 113}),
+    "wgrad_kernelINS_5ShapeILi8ELi4ELi256EEE": ("wgrad", 4, {"v_mfma_f32_32x32x16_bf16": 150, "global_load_lds_dwordx4": 168}),
 }
 
 
@@ -109,7 +109,7 @@ def test_counted_waits_still_match_the_emitted_instructions(isa, frag):
 def test_chain_kernels_wait_with_counted_immediates(isa):
     """the counted waits are really there (a refactoring that drops back to vmcnt(0) / lgkmcnt(0) everywhere would pass the count
     test above and lose 10-20 % speed): the training forward has dozens of distinct vmcnt immediates"""
-    for frag, fname in (("mlp_fwd_kernelINS_5ShapeILi8ELi4EEELb1E", "mlp_fwd"), ("mlp_bwd_kernelINS_5ShapeILi8ELi4EEE", "mlp_bwd")):
+    for frag, fname in (("mlp_fwd_kernelINS_5ShapeILi8ELi4ELi256EEELb1E", "mlp_fwd"), ("mlp_bwd_kernelINS_5ShapeILi8ELi4ELi256EEE", "mlp_bwd")):
         for name, (body, _) in isa[fname].items():
             if frag not in name:
                 continue
