@@ -96,7 +96,7 @@ for k, (ms, n) in res.items():
     S = R * (64 if k.endswith("coarse") else 192)
     fl = FWD if "fwd" in k else DG if "bwd" in k else WG if "wgrad" in k else 0
     out[k] = {"ms": round(avg, 4), "TFLOPs": round(fl * S / (avg * 1e-3) / 1e12, 1) if fl else None}
-    if "wgrad" in k:
+    if "wgrad" in k and args.shape == "8,256,4,10,4":       # 242 KiB per tile is the default shape's wgrad read
         out[k]["TBs"] = round(S / 32 * 242 * 1024 / (avg * 1e-3) / 1e12, 2)
 tot = sum(v["ms"] for k, v in out.items() if k.startswith("train_"))
 print(json.dumps({"tag": args.tag, "rays": R, "train_chunk_ms": round(tot, 3), "Mrs_per_s": round(R * 256 / tot / 1e3, 1), "kernels": out}))
