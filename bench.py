@@ -218,19 +218,20 @@ def pmc_traffic(kernel):
     in KiB).  Counters cannot be read from inside the benched process, so the line names its source; (None, None) when no
     summary of this layout is committed."""
     import glob
-    name = {"wgrad_fine": ("wgrad_kernel", max), "wgrad_coarse": ("wgrad_kernel", min), "mlp_fwd_fine": ("mlp_fwd_kernel<true", max),
-            "mlp_fwd_coarse": ("mlp_fwd_kernel<true", min), "mlp_bwd_fine": ("mlp_bwd_kernel", max),
-            "mlp_bwd_coarse": ("mlp_bwd_kernel", min)}.get(kernel)
+    # (name prefix, template argument that must be present, which of the two nets' launches)
+    name = {"wgrad_fine": ("wgrad_kernel", "", max), "wgrad_coarse": ("wgrad_kernel", "", min), "mlp_fwd_fine": ("mlp_fwd_kernel<", "true", max),
+            "mlp_fwd_coarse": ("mlp_fwd_kernel<", "true", min), "mlp_bwd_fine": ("mlp_bwd_kernel", "", max),
+            "mlp_bwd_coarse": ("mlp_bwd_kernel", "", min)}.get(kernel)
     if not name:
         return None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         rep = json.load(open(f))
         if rep.get("_layout", "act158_dz156") != LAYOUT_TAG:
             continue
-        rows = [v for k, v in rep.items() if k.startswith(name[0]) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+        rows = [v for k, v in rep.items() if k.startswith(name[0]) and name[1] in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
         if not rows:
             continue
-        val = max(r["hbm_bytes_per_launch"] for r in rows) if name[1] is max else min(r["hbm_bytes_per_launch_min"] for r in rows)
+        val = max(r["hbm_bytes_per_launch"] for r in rows) if name[2] is max else min(r["hbm_bytes_per_launch_min"] for r in rows)
         return val, os.path.relpath(f, ROOT)
     return None, None
 
