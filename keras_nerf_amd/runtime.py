@@ -68,7 +68,7 @@ class KnerfContext:
             if env.get(key):
                 opts[name] = float(env[key])
         if env.get("KNERF_WGRAD_COSTS"):
-            for j, v in enumerate(env["KNERF_WGRAD_COSTS"].split(",")[:9]):
+            for j, v in enumerate(env["KNERF_WGRAD_COSTS"].split(",")[:17]):
                 opts[f"wgrad_cost{j}"] = float(v)
         opts.update(options or {})
         for k, v in opts.items():
