@@ -33,14 +33,14 @@ typedef enum knerf_status {
 typedef struct knerf_config {
     int32_t n_coarse, n_fine;          /* 64, 128 */
     int32_t pos_emb_xyz, pos_emb_dir;  /* 10, 4   */
-    int32_t n_layers, dense_units, skip_layer; /* 8, 256, 4 : the shape of the fused kernels; others use csrc/generic.hip */
+    int32_t n_layers, dense_units, skip_layer; /* 8, 256, 4; fused kernels: the triples of csrc/layout.h KNERF_FUSED_SHAPES (widths 256, 128); others: csrc/generic.hip */
     int32_t white_background;          /* compile(white_background=...) */
     int32_t oob_clamp;                 /* 0: out-of-range mid-point gather yields 0 (tf.gather on GPU); 1: clamp */
     float lr, beta1, beta2, epsilon;   /* 1e-3, 0.9, 0.999, 1e-7 */
     int32_t flags;                     /* KNERF_FLAG_* */
 } knerf_config;
 
-/* run the default NeRFMLP shape through the general-shape kernels too (tests compare the two paths) */
+/* run a shape the fused kernels cover through the general-shape kernels too (tests compare the two paths) */
 enum { KNERF_FLAG_FORCE_GENERIC = 1 };
 
 enum { KNERF_COARSE = 0, KNERF_FINE = 1 };
@@ -48,7 +48,7 @@ enum { KNERF_COARSE = 0, KNERF_FINE = 1 };
 /* number of trainable scalars per MLP (595,844 for the default shape; reference mlp.py:11-27) */
 size_t knerf_param_count(void);
 /* the same for any NeRFMLP(n_layers, dense_units, skip_layer) with pos_emb_xyz / pos_emb_dir (mlp.py:11-27); 0 = invalid.
- * Shapes other than the default run on the general-shape kernels (csrc/generic.hip): same API, same numerics contract. */
+ * Shapes outside csrc/layout.h KNERF_FUSED_SHAPES run on the general-shape kernels (csrc/generic.hip): same API, same numerics contract. */
 size_t knerf_param_count_for(const knerf_config* cfg);
 
 int knerf_create(const knerf_config* cfg, knerf_ctx** out);
