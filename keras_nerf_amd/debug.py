@@ -39,9 +39,11 @@ def load() -> C.CDLL:
     return _probe
 
 
-def debug_table(kind: int):
+def debug_table(kind: int, shape: int = 0):
+    """host-side packing / destination table `kind` of built-in trunk shape `shape` (see include/knerf_debug.h)"""
     import numpy as np
     lib = load()
+    kind = int(kind) + 16 * int(shape)
     n = C.c_size_t(0)
     if lib.knerf_debug_table(kind, None, C.byref(n)) != 0:
         raise _lib.KnerfError("knerf_debug_table failed")
