@@ -62,19 +62,25 @@ def _cases():
     for i, (nc, nf) in enumerate(((64, 128), (32, 64), (96, 32), (33, 95))):
         out.append(dict(n_coarse=nc, n_fine=nf, rays=int(rng.integers(1, 200)), white=bool(i & 1), oob=["zero", "clamp"][i >> 1 & 1],
                         seed=int(rng.integers(0, 1 << 30)), det=int(i != 2), skip=1))
+    # ... and on other built-in trunk shapes of the fused kernels (csrc/layout.h KNERF_FUSED_SHAPES): half width, several concats
+    for i, (shape, nc, nf) in enumerate((((8, 4, 128), 33, 95), ((4, 2, 128), 64, 128), ((8, 2, 256), 17, 40), ((8, 4, 128), 96, 32))):
+        out.append(dict(n_coarse=nc, n_fine=nf, rays=int(rng.integers(1, 200)), white=bool(i & 1), oob=["zero", "clamp"][i >> 1 & 1],
+                        seed=int(rng.integers(0, 1 << 30)), det=int(i == 1), skip=int(i != 2), shape=shape))
     return out
 
 
-@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"nc{c['n_coarse']}_nf{c['n_fine']}_r{c['rays']}_{'w' if c['white'] else 'b'}_{c['oob']}" + ("_det" if c.get("det") else "") + ("_skip" if c.get("skip") else ""))
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"nc{c['n_coarse']}_nf{c['n_fine']}_r{c['rays']}_{'w' if c['white'] else 'b'}_{c['oob']}" + ("_det" if c.get("det") else "") + ("_skip" if c.get("skip") else "") + ("_%dx%ds%d" % (c["shape"][0], c["shape"][2], c["shape"][1]) if c.get("shape") else ""))
 def test_random_configuration_matches_oracle(case):
     from keras_nerf_amd.runtime import KnerfContext
-    cfg = O.NerfConfig(n_coarse=case["n_coarse"], n_fine=case["n_fine"])
+    nl, sk, units = case.get("shape", (8, 4, 256))
+    cfg = O.NerfConfig(n_coarse=case["n_coarse"], n_fine=case["n_fine"], n_layers=nl, skip_layer=sk, dense_units=units)
     P = make_problem(n_images=1, wh=16, seed=case["seed"], weight_scale=1.5, bias_std=0.05, cfg=cfg)
     R = case["rays"]
     o, d, t, img = (P[k].reshape(P["N"], -1)[:R].copy() for k in ("o", "d", "t", "img"))
     u = P["u"].reshape(P["N"], -1)[:R].copy() if case["n_fine"] else None
-    ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, white_background=case["white"], oob=case["oob"],
-                       options=dict(deterministic=case.get("det", 0), skip_dead_tiles=case.get("skip", 0)))
+    ctx = KnerfContext(n_coarse=cfg.n_coarse, n_fine=cfg.n_fine, n_layers=nl, skip_layer=sk, dense_units=units, white_background=case["white"],
+                       oob=case["oob"], options=dict(deterministic=case.get("det", 0), skip_dead_tiles=case.get("skip", 0)))
+    assert ctx.get_option("general_shape_path") == 0.0
     if case.get("skip"):
         assert ctx.get_option("skip_dead_tiles_active") == float(cfg.n_coarse % 32 == 0 and (cfg.n_coarse + cfg.n_fine) % 32 == 0)
     ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
