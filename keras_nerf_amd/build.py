@@ -3,6 +3,12 @@
 libknerf_hip.so    the product: the C ABI of include/knerf.h
 libknerf_probe.so  diagnostics for tests/ and tools/ (include/knerf_debug.h): layout-table introspection, workspace views,
                    hardware-fact and bandwidth probes.  Links against libknerf_hip.so; the product never loads it.
+
+    python keras_nerf_amd/build.py [--force] [-DNAME[=VALUE] ...] [--variant=NAME] [--add-shape=NL,SK,U ...]
+
+--add-shape (or KNERF_ADD_SHAPES="NL,SK,U;NL,SK,U" in the environment): further NeRF(n_layers, skip_layer, dense_units) trunk shapes for
+the fused kernels beside the built-in list of csrc/layout.h (dense_units 256 or 128, reference encodings); three more hipcc runs
+and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
 """
 from __future__ import annotations
 
@@ -20,7 +26,8 @@ SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.
 # per shape with -DKNERF_SHAPE_SLICE=<index> (that translation unit then defines the kernels of its shape only; slice 0 also holds
 # the run-time dispatchers), so the shapes build in parallel and the default shape's object is what it was before the others existed.
 SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
-N_SHAPE_SLICES = 12     # = kNumFusedShapes (knerf_api.hip static_asserts it)
+N_BUILTIN_SHAPES = 12   # = kNumBuiltinShapes (csrc/layout.h static_asserts it); knerf_api.hip checks the total against KNERF_N_SHAPE_SLICES
+MAX_EXTRA_SHAPES = 12
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]
@@ -33,15 +40,36 @@ def _newer(a: str, b: str) -> bool:
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def _compile(hipcc, sources, objdir, flags, force, verbose):
+def parse_shapes(specs) -> list:
+    """["NL,SK,U", ...] (also ';'-separated inside one string) -> [(NL, SK, U), ...]; raises ValueError with the offending entry"""
+    out = []
+    for spec in specs:
+        for item in str(spec).split(";"):
+            if not item.strip():
+                continue
+            try:
+                nl, sk, u = (int(v) for v in item.split(","))
+            except ValueError:
+                raise ValueError(f"--add-shape wants n_layers,skip_layer,dense_units, got {item!r}") from None
+            if u not in (128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0:
+                raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 128 or 256, 3 <= n_layers <= 16, "
+                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0)")
+            if (nl, sk, u) not in out:
+                out.append((nl, sk, u))
+    if len(out) > MAX_EXTRA_SHAPES:
+        raise ValueError(f"at most {MAX_EXTRA_SHAPES} extra shapes")
+    return out
+
+
+def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
     jobs = []
     for src in sources:
         if src in SLICED:
-            jobs += [(src, src.replace(".hip", f"_s{k}.o"), [f"-DKNERF_SHAPE_SLICE={k}", f"-DKNERF_N_SHAPE_SLICES={N_SHAPE_SLICES}"]) for k in range(N_SHAPE_SLICES)]
+            jobs += [(src, src.replace(".hip", f"_s{k}.o"), [f"-DKNERF_SHAPE_SLICE={k}", f"-DKNERF_N_SHAPE_SLICES={n_slices}"]) for k in range(n_slices)]
         else:
-            jobs.append((src, src.replace(".hip", ".o"), [f"-DKNERF_N_SHAPE_SLICES={N_SHAPE_SLICES}"]))
+            jobs.append((src, src.replace(".hip", ".o"), [f"-DKNERF_N_SHAPE_SLICES={n_slices}"]))
     todo = []
     for src, obj, extra in jobs:
         s = os.path.join(CSRC, src)
@@ -66,16 +94,31 @@ def _compile(hipcc, sources, objdir, flags, force, verbose):
     return objs, bool(procs)
 
 
-def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "") -> str:
-    """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py"""
+def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "", add_shapes=None) -> str:
+    """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py.
+    add_shapes: ["NL,SK,U", ...] further trunk shapes for the fused kernels (default: $KNERF_ADD_SHAPES)"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if add_shapes is None:
+        add_shapes = [os.environ["KNERF_ADD_SHAPES"]] if os.environ.get("KNERF_ADD_SHAPES") else []
+    extra = parse_shapes(add_shapes)
+    n_slices = N_BUILTIN_SHAPES + len(extra)
+    if extra:       # a function-like macro on the command line: KNERF_EXTRA_SHAPES(X) = X(12, NL, SK, U) X(13, ...) ...
+        defines = tuple(defines) + ("KNERF_EXTRA_SHAPES(X)=" + " ".join(f"X({N_BUILTIN_SHAPES + i}, {nl}, {sk}, {u})" for i, (nl, sk, u) in enumerate(extra)),)
     objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")
     probe = PROBE_LIB if not variant else os.path.join(HERE, f"libknerf_probe_{variant}.so")
     flags = FLAGS + ["-D" + d for d in defines]
     os.makedirs(objdir, exist_ok=True)
-    objs, changed = _compile(hipcc, SOURCES, objdir, flags, force, verbose)
-    pobjs, pchanged = _compile(hipcc, PROBE_SOURCES, objdir, flags, force, verbose)
+    # objects are reused by modification time; a change of the flags (defines, extra shapes) rebuilds everything
+    sig_file, sig = os.path.join(objdir, "flags.txt"), "\n".join(flags + [str(n_slices)])
+    if not os.path.exists(sig_file) or open(sig_file).read() != sig:
+        force = force or any(f.endswith(".o") for f in os.listdir(objdir))
+        for f in os.listdir(objdir):          # objects of slices that no longer exist must not linger
+            if f.endswith(".o"):
+                os.remove(os.path.join(objdir, f))
+    objs, changed = _compile(hipcc, SOURCES, objdir, flags, force, verbose, n_slices)
+    pobjs, pchanged = _compile(hipcc, PROBE_SOURCES, objdir, flags, force, verbose, n_slices)
+    open(sig_file, "w").write(sig)
     if changed or not os.path.exists(lib):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
@@ -94,4 +137,5 @@ def build(force: bool = False, verbose: bool = True, defines=(), variant: str = 
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     var = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")), "")
-    build(force="--force" in sys.argv, defines=defs, variant=var)
+    shapes = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--add-shape=")]
+    build(force="--force" in sys.argv, defines=defs, variant=var, add_shapes=shapes or None)

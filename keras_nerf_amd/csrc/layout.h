@@ -90,9 +90,20 @@ using DefaultShape = Shape<8, 4>;
 // one more instantiation of the three big kernels: build.py compiles mlp_fwd / mlp_bwd / wgrad once per entry with
 // -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
 // instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
-#define KNERF_FUSED_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
+#define KNERF_BUILTIN_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
     X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128)
-constexpr int kNumFusedShapes = 12;
+// Further entries chosen at BUILD time: `python keras_nerf_amd/build.py --add-shape=NL,SK,U ...` defines KNERF_EXTRA_SHAPES(X) as
+// X(12, NL, SK, U) X(13, ...) ... (indices continue the built-in list, at most 12 of them: KNERF_SLICE_12 .. 23 below).  A triple the
+// kernels do not cover fails to compile on Shape's static_assert; one that repeats an earlier entry is never selected.
+#ifndef KNERF_EXTRA_SHAPES
+#define KNERF_EXTRA_SHAPES(X)
+#endif
+#define KNERF_FUSED_SHAPES(X) KNERF_BUILTIN_SHAPES(X) KNERF_EXTRA_SHAPES(X)
+#define KNERF_X(I, NL, SK, U) +1
+constexpr int kNumBuiltinShapes = 0 KNERF_BUILTIN_SHAPES(KNERF_X);
+constexpr int kNumFusedShapes = 0 KNERF_FUSED_SHAPES(KNERF_X);
+#undef KNERF_X
+static_assert(kNumBuiltinShapes == 12 && kNumFusedShapes <= 24, "the slice macros below cover indices 0 .. 23");
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
 constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256) {
 #define KNERF_X(I, NL, SK, U) if (n_layers == NL && skip_layer == SK && dense_units == U) return I;
@@ -161,6 +172,66 @@ constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256
 #define KNERF_SLICE_11(DEF, EXT) DEF
 #else
 #define KNERF_SLICE_11(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(12)
+#define KNERF_SLICE_12(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_12(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(13)
+#define KNERF_SLICE_13(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_13(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(14)
+#define KNERF_SLICE_14(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_14(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(15)
+#define KNERF_SLICE_15(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_15(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(16)
+#define KNERF_SLICE_16(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_16(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(17)
+#define KNERF_SLICE_17(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_17(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(18)
+#define KNERF_SLICE_18(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_18(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(19)
+#define KNERF_SLICE_19(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_19(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(20)
+#define KNERF_SLICE_20(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_20(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(21)
+#define KNERF_SLICE_21(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_21(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(22)
+#define KNERF_SLICE_22(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_22(DEF, EXT) EXT
+#endif
+#if KNERF_SLICE_OWNS(23)
+#define KNERF_SLICE_23(DEF, EXT) DEF
+#else
+#define KNERF_SLICE_23(DEF, EXT) EXT
 #endif
 #define KNERF_PICK(I, DEF, EXT) KNERF_SLICE_##I(DEF, EXT)
 #define KNERF_HAS_DISPATCH KNERF_SLICE_OWNS(0)

@@ -35,3 +35,23 @@ def test_compiler_tracked_fragment_loads_give_identical_bits():
     a, b = _digests(), _digests(lib)
     assert a == b, [k for k in a if a[k] != b[k]]
     assert len(a) >= 10
+
+
+def test_build_time_extra_shapes_run_on_the_fused_kernels():
+    """`build.py --add-shape=NL,SK,U` (csrc/layout.h KNERF_EXTRA_SHAPES): a library built with 6/3/128 and 8/2/128 beside the built-in
+    list runs NeRF(n_layers=6, skip_layer=3, dense_units=128) and 8/2/128 on the fused kernels, at the built-in shapes' tolerances."""
+    from keras_nerf_amd import build as B
+    lib = B.build(verbose=False, variant="xshape", add_shapes=["6,3,128", "8,2,128"])
+    env = dict(os.environ, KNERF_LIB=lib, KNERF_PROBE_LIB=lib.replace("libknerf_hip_", "libknerf_probe_"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_check.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert [tuple(x["shape"]) for x in rows] == [(6, 3, 128), (8, 2, 128)]
+    for x in rows:
+        assert x["info"][:3] == x["shape"] and x["general_shape_path"] == 0.0, x
+        assert x["coarse_worst"] < 1.5e-2 and x["fine_worst"] < 1.5e-2 and x["loss_err"] < 2e-3 and x["img_err"] < 1e-2, x
+    # the default library does not know them: same constructor arguments, general-shape kernels
+    from keras_nerf_amd.runtime import KnerfContext
+    ctx = KnerfContext(n_layers=6, dense_units=128, skip_layer=3, white_background=True)
+    assert ctx.get_option("general_shape_path") == 1.0
+    ctx.close()
