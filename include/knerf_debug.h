@@ -18,7 +18,7 @@ extern "C" {
  * composed head matrix [288][4] and its bias [4]; csrc/layout.h) or are -1; entries of 3 index the flat gradient, or
  * param_count + i for element i of the head accumulator, or are -1.  kind + 16 k: the same for entry k of the built-in trunk shapes
  * (csrc/layout.h KNERF_FUSED_SHAPES; composed head [dense_units + 32][4]); kind 5 + 16 k: {n_layers, skip_layer, dense_units,
- * param_count} of entry k; an index behind the last entry fails.  Pass out=NULL to query the length.  No device needed. */
+ * param_count, pos_emb_xyz, pos_emb_dir} of entry k; an index behind the last entry fails.  Pass out=NULL to query the length.  No device needed. */
 int knerf_debug_table(int kind, int32_t* out, size_t* n);
 /* the general-shape path's layer program for a config (no device needed): 16 int32 per Dense layer in Keras order =
  * {kernel offset, bias offset, fan_in, fan_out, padded input width, padded output width, n_seg, seg0 (buffer col0, width,

@@ -4,11 +4,11 @@ libknerf_hip.so    the product: the C ABI of include/knerf.h
 libknerf_probe.so  diagnostics for tests/ and tools/ (include/knerf_debug.h): layout-table introspection, workspace views,
                    hardware-fact and bandwidth probes.  Links against libknerf_hip.so; the product never loads it.
 
-    python keras_nerf_amd/build.py [--force] [-DNAME[=VALUE] ...] [--variant=NAME] [--add-shape=NL,SK,U ...]
+    python keras_nerf_amd/build.py [--force] [-DNAME[=VALUE] ...] [--variant=NAME] [--add-shape=NL,SK,U[,LX,LD] ...]
 
---add-shape (or KNERF_ADD_SHAPES="NL,SK,U;NL,SK,U" in the environment): further NeRF(n_layers, skip_layer, dense_units) trunk shapes for
-the fused kernels beside the built-in list of csrc/layout.h (dense_units 256 or 128, reference encodings); three more hipcc runs
-and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
+--add-shape (or KNERF_ADD_SHAPES="NL,SK,U;NL,SK,U,LX,LD" in the environment): further NeRF(n_layers, skip_layer, dense_units [, pos_emb_xyz,
+pos_emb_dir]) shapes for the fused kernels beside the built-in list of csrc/layout.h (dense_units 256 or 128; encodings: the reference's
+10 / 4 unless given, pos_emb_dir <= 4); three more hipcc runs and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
 """
 from __future__ import annotations
 
@@ -41,24 +41,48 @@ def _newer(a: str, b: str) -> bool:
 
 
 def parse_shapes(specs) -> list:
-    """["NL,SK,U", ...] (also ';'-separated inside one string) -> [(NL, SK, U), ...]; raises ValueError with the offending entry"""
+    """["NL,SK,U" | "NL,SK,U,LX,LD", ...] (also ';'-separated inside one string) -> [(NL, SK, U) | (NL, SK, U, LX, LD), ...]; raises
+    ValueError with the offending entry.  LX, LD = pos_emb_xyz, pos_emb_dir (omitted: the reference's 10, 4)"""
     out = []
     for spec in specs:
         for item in str(spec).split(";"):
             if not item.strip():
                 continue
             try:
-                nl, sk, u = (int(v) for v in item.split(","))
+                v = tuple(int(x) for x in item.split(","))
             except ValueError:
-                raise ValueError(f"--add-shape wants n_layers,skip_layer,dense_units, got {item!r}") from None
-            if u not in (128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0:
+                v = ()
+            if len(v) not in (3, 5):
+                raise ValueError(f"--add-shape wants n_layers,skip_layer,dense_units[,pos_emb_xyz,pos_emb_dir], got {item!r}")
+            nl, sk, u = v[:3]
+            lx, ld = v[3:] if len(v) == 5 else (10, 4)
+            if u not in (128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0 or not 1 <= lx <= 16 or not 1 <= ld <= 4:
                 raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 128 or 256, 3 <= n_layers <= 16, "
-                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0)")
-            if (nl, sk, u) not in out:
-                out.append((nl, sk, u))
+                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0), 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 4")
+            if (lx, ld) == (10, 4):
+                v = v[:3]
+            if v not in out:
+                out.append(v)
     if len(out) > MAX_EXTRA_SHAPES:
         raise ValueError(f"at most {MAX_EXTRA_SHAPES} extra shapes")
     return out
+
+
+def _spill_report(name: str, remarks: str):
+    """None, or what is wrong: a kernel of this object uses scratch memory or spills vector registers (hipcc's kernel-resource-usage
+    remarks).  Scalar-register spills are tolerated: they go to lanes of a vector register (v_writelane / v_readlane, ScratchSize stays
+    0), not to memory, so they do not enter the vmcnt the kernels count (the 12-layer weight-gradient kernel has six of them)."""
+    import re
+    kernel, n_kernels = "?", 0
+    for ln in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", ln)
+        if m:
+            kernel, n_kernels = m.group(1), n_kernels + 1
+        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", ln)
+        if m and int(m.group(2)) != 0:
+            return (f"{name}: kernel {kernel} reports {m.group(1)} = {m.group(2)}: the hand-counted waits of the fused kernels do not "
+                    f"allow spills to memory (a shape given with --add-shape may simply be too large for the register file)")
+    return None if n_kernels else f"{name}: hipcc printed no kernel-resource-usage remarks, the spill check cannot run"
 
 
 def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
@@ -76,34 +100,52 @@ def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
         o = os.path.join(objdir, obj)
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdr_paths):
-            todo.append((obj, [hipcc, *flags, *extra, "-c", s, "-o", o]))
+            # the three big kernels wait on hand-counted vmcnt / lgkmcnt values (chain.h StoreSched, frag_wait): a register spill --
+            # scratch traffic counts in vmcnt -- would break them silently, so every instantiation's resource report is checked
+            guard = ["-Rpass-analysis=kernel-resource-usage"] if src in SLICED else []
+            todo.append((obj, [hipcc, *flags, *extra, *guard, "-c", s, "-o", o], bool(guard)))
     limit = max(1, min(len(todo), (os.cpu_count() or 8)))      # hipcc processes in flight
     running = []
     while todo or running:
         while todo and len(running) < limit:
-            name, cmd = todo.pop(0)
+            name, cmd, guarded = todo.pop(0)
             if verbose:
                 print(" ".join(cmd), flush=True)
-            running.append((name, subprocess.Popen(cmd)))
+            running.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE if guarded else None, text=True), guarded))
             procs.append(name)
-        name, p = running.pop(0)
-        if p.wait() != 0:
-            for _, q in running:
+        name, p, guarded = running.pop(0)
+        err = p.communicate()[1] if guarded else None      # (communicate waits)
+        if not guarded:
+            p.wait()
+        bad = None
+        if p.returncode != 0:
+            bad = f"hipcc failed on {name}"
+        elif guarded:
+            bad = _spill_report(name, err)
+        if guarded and err:          # pass hipcc's own diagnostics through, without the resource remarks
+            rest = [ln for ln in err.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^")) and "__global__" not in ln]
+            if rest and (verbose or bad):
+                print("\n".join(rest), file=sys.stderr)
+        if bad:
+            for _, q, _g in running:
                 q.kill()
-            raise RuntimeError(f"hipcc failed on {name}")
+            obj_path = os.path.join(objdir, name)
+            if os.path.exists(obj_path):
+                os.remove(obj_path)
+            raise RuntimeError(bad)
     return objs, bool(procs)
 
 
 def build(force: bool = False, verbose: bool = True, defines=(), variant: str = "", add_shapes=None) -> str:
     """defines/variant: experimental builds (-DNAME=VALUE ...) into libknerf_hip_<variant>.so, used by tools/kbench.py.
-    add_shapes: ["NL,SK,U", ...] further trunk shapes for the fused kernels (default: $KNERF_ADD_SHAPES)"""
+    add_shapes: ["NL,SK,U" | "NL,SK,U,LX,LD", ...] further trunk shapes for the fused kernels (default: $KNERF_ADD_SHAPES)"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if add_shapes is None:
         add_shapes = [os.environ["KNERF_ADD_SHAPES"]] if os.environ.get("KNERF_ADD_SHAPES") else []
     extra = parse_shapes(add_shapes)
     n_slices = N_BUILTIN_SHAPES + len(extra)
     if extra:       # a function-like macro on the command line: KNERF_EXTRA_SHAPES(X) = X(12, NL, SK, U) X(13, ...) ...
-        defines = tuple(defines) + ("KNERF_EXTRA_SHAPES(X)=" + " ".join(f"X({N_BUILTIN_SHAPES + i}, {nl}, {sk}, {u})" for i, (nl, sk, u) in enumerate(extra)),)
+        defines = tuple(defines) + ("KNERF_EXTRA_SHAPES(X)=" + " ".join(f"X({N_BUILTIN_SHAPES + i}, {', '.join(str(x) for x in v)})" for i, v in enumerate(extra)),)
     objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")
     probe = PROBE_LIB if not variant else os.path.join(HERE, f"libknerf_probe_{variant}.so")

@@ -49,7 +49,7 @@ inline const Tables& host_tables_of() {
 }
 inline const Tables& host_tables(int shape_id = 0) {      // layout.h fused_shape_id
     switch (shape_id) {
-#define KNERF_X(I, NL, SK, U) case I: return host_tables_of<Shape<NL, SK, U>>();
+#define KNERF_X(I, ...) case I: return host_tables_of<KNERF_SHAPE_T(__VA_ARGS__)>();
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
         default: return host_tables_of<DefaultShape>();

@@ -33,12 +33,12 @@ int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n) {
 
 int knerf_debug_table(int kind, int32_t* out, size_t* n) {
     if (!n || kind < 0) return KNERF_ERR_INVALID;
-    const int shape = kind >> 4;        // kind + 16 * (index in csrc/layout.h KNERF_FUSED_SHAPES); kind 5: {n_layers, skip_layer, dense_units, param_count} of that shape
+    const int shape = kind >> 4;        // kind + 16 * (index in csrc/layout.h KNERF_FUSED_SHAPES); kind 5: {n_layers, skip_layer, dense_units, param_count, pos_emb_xyz, pos_emb_dir} of that shape
     kind &= 15;
     if (shape >= kNumFusedShapes) return KNERF_ERR_INVALID;
     const Tables& t = host_tables(shape);
     const ShapeInfo& si = shape_info(shape);
-    const std::vector<int32_t> info = {si.n_layers, si.skip, si.units, si.param_count};
+    const std::vector<int32_t> info = {si.n_layers, si.skip, si.units, si.param_count, si.lx, si.ld};
     const std::vector<int32_t>* v = nullptr;
     switch (kind) {
         case 5: v = &info; break;

@@ -80,7 +80,7 @@ int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
         HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n], s));
         return KNERF_OK;
     }
-    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, ctx->si.trunk_params, ctx->si.units, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
+    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
     HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)ctx->si.fwd_blocks * 512, s));
     HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)ctx->si.bwd_blocks * 512, s));
     HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)ctx->si.fwd_bias_tiles * 32, s));
@@ -331,7 +331,7 @@ int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
         for (int n = 0; n < 2; ++n) HIPCHK(gen::expand_head(ctx->gplan, ctx->gnet[n], ctx->net[n].w, ctx->net[n].g, s));
         return KNERF_OK;
     }
-    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, ctx->si.trunk_params, ctx->si.units, s));
+    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));
     return KNERF_OK;
 }
 
@@ -414,9 +414,9 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
         return fail(nullptr, KNERF_ERR_NODEVICE, std::string("libknerf_hip is built for gfx950 only; device is ") + prop.gcnArchName);
     ctx = new knerf_ctx();
     ctx->cfg = *cfg;
-    // the fused kernels cover the trunk shapes of layout.h KNERF_FUSED_SHAPES (widths 256 and 128) with the reference's encodings; everything
+    // the fused kernels cover the trunk shapes of layout.h KNERF_FUSED_SHAPES (widths 256 and 128; the reference's encodings unless the build added others); everything
     // else -- and, for tests, any shape under KNERF_FLAG_FORCE_GENERIC -- runs on the general-shape kernels
-    const int sid = (cfg->pos_emb_xyz == kLx && cfg->pos_emb_dir == kLd) ? fused_shape_id(cfg->n_layers, cfg->skip_layer, cfg->dense_units) : -1;
+    const int sid = fused_shape_id(cfg->n_layers, cfg->skip_layer, cfg->dense_units, cfg->pos_emb_xyz, cfg->pos_emb_dir);
     ctx->generic = sid < 0 || (cfg->flags & KNERF_FLAG_FORCE_GENERIC) != 0;
     if (ctx->generic) {
         ctx->gplan = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
@@ -711,7 +711,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         a.lr_t = ctx->d_lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
     }
-    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, ctx->si.trunk_params, ctx->si.units, s));      // both nets' heads in one launch
+    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));      // both nets' heads in one launch
     for (int n = 0; n < 2; ++n)
         if (int r = repack(ctx, n, s, false)) return r;
     HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, ctx->d_step, ctx->d_lr_t, AdamHyper{ctx->cfg.lr, ctx->cfg.beta1, ctx->cfg.beta2}, s));

@@ -22,22 +22,29 @@
 
 namespace knerf {
 
-constexpr int kLx = 10, kLd = 4;
-constexpr int kXyzDim = 63, kDirDim = 27;
+constexpr int kLx = 10, kLd = 4;               // the reference's defaults (nerf.py:11-14): 63-d / 27-d encodings
 
 // ---- trunk shape ---------------------------------------------------------------------------------------------------------
 // The fused kernels cover NeRFMLP(n_layers = NL, dense_units = 256, skip_layer = SK) with 63-d / 27-d encodings (mlp.py:5-50):
 // layer l (l >= 2) takes [h_{l-1} ; xyz_enc] when the reference concatenated behind layer l-1, i.e. (l-1) % SK == 0 (mlp.py:36-38).
 // Shape<8, 4> is the reference's default and the shape every number in DESIGN.md is quoted for; the other instantiations
 // (knerf_api.hip kFusedShapes) share every line of kernel code with it.  Not covered (-> general-shape path, generic.hip): other
-// widths or encodings, fewer than 3 layers, a concat behind the LAST layer (the head would take [h ; xyz_enc ; dir_enc]).
-template <int NL_, int SK_, int U_ = 256>
-struct Shape {
-    static constexpr int NL = NL_, SK = SK_, U = U_;
+// widths, fewer than 3 layers, a concat behind the LAST layer (the head would take [h ; xyz_enc ; dir_enc]).
+// ShapeImpl carries every constant; Shape<NL, SK, U> = the reference's encodings (the names the built-in kernels are mangled with),
+// ShapeL<NL, SK, U, LX, LD> = other positional-encoding depths (NeRF(pos_emb_xyz=LX, pos_emb_dir=LD), build-time entries only).
+template <int NL_, int SK_, int U_, int LX_, int LD_>
+struct ShapeImpl {
+    static constexpr int NL = NL_, SK = SK_, U = U_, LX = LX_, LD = LD_;
     static constexpr int kKs = U / 16, kOt = U / 32;        // k-steps / out tiles of a U-wide layer: 16 / 8 at 256, 8 / 4 at 128
+    // encodings: 3 + 6 L features in slots of 16 per k-step (8 per lane half: x, y | z, pad, then sin | cos of 2^i p_c), the k-step
+    // count rounded up to EVEN -- the weight-gradient kernel takes its inputs in tiles of 32 rows = two blocks
+    static constexpr int kXyzDim = 3 + 6 * LX, kDirDim = 3 + 6 * LD;
+    static constexpr int enc_q(int L) { return ((2 + 3 * L + 7) / 8 + 1) / 2 * 2; }
+    static constexpr int kEncQ = enc_q(LX), kDirQ = enc_q(LD);          // 4 and 2 for the reference's L = 10 / 4
     static constexpr bool concat_in(int l) { return l >= 2 && l < NL && (l - 1) % SK == 0; }
     static constexpr bool kConcatBehindLast = (NL - 1) % SK == 0 && NL - 1 > 0;
-    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128);
+    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128) &&
+                                       LX >= 1 && LX <= 16 && LD >= 1 && LD <= 4;      // LD: the head accumulator holds U + 27 rows (kAuxS)
     static constexpr int first_concat() { for (int l = 2; l < NL; ++l) if (concat_in(l)) return l; return 0; }
     static constexpr int kFirstConcat = first_concat();
     // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias; behind the trunk
@@ -49,7 +56,7 @@ struct Shape {
     static constexpr int kParamCount = kTrunkParams + (U + 1) + (U * U + U) + (kHeadReal * (U / 2) + U / 2) + ((U / 2) * 3 + 3);
     // forward stream: stage st = trunk layer st (st < NL) or the head (st == NL); order: stage, out tile, k-step
     static constexpr int kFwdStages = NL + 1;
-    static constexpr int fwd_nks(int st) { return st == 0 ? 4 : st == NL ? kKs + 2 : (concat_in(st) ? kKs + 4 : kKs); }
+    static constexpr int fwd_nks(int st) { return st == 0 ? kEncQ : st == NL ? kKs + kDirQ : (concat_in(st) ? kKs + kEncQ : kKs); }
     static constexpr int fwd_not(int st) { return st == NL ? 1 : kOt; }
     static constexpr int fwd_b0(int st) { int n = 0; for (int q = 0; q < st; ++q) n += fwd_nks(q) * fwd_not(q); return n; }
     static constexpr int kFwdBlocks = fwd_b0(NL + 1);
@@ -60,16 +67,16 @@ struct Shape {
     static constexpr int kBwdBlocks = bwd_b0(NL);
     // Two recomputations instead of saved tensors exist for the 256-wide trunk only (their weight-gradient jobs are written for 8
     // waves = 8 column strips): h0 from the encoding (layer_1's job) and the last layer's dZ from dz_head.  At width 128 the forward
-    // saves h0 and dgrad writes the last dZ like any other.
-    static constexpr bool kSaveH0 = U != 256;
+    // saves h0 and dgrad writes the last dZ like any other; the h0 job also assumes the reference's four encoding blocks.
+    static constexpr bool kSaveH0 = U != 256 || kEncQ != 4;
     // saved runs (see "saved tensors" below).  act: [h0] h1 .. h_{NL-1} (kKs blocks each), the 4 enc blocks directly behind
     // h_{c-1} for the FIRST concat layer c (its weight-gradient job then reads ONE contiguous range; later concat layers read two), in
     // front of everything when there is no concat layer, and the 2 dir blocks at the end, directly behind h_{NL-1} (the head job's
     // range).  dz: dz_0 .. dz_{NL-1} (kKs each), dz_head (2).
     static constexpr int kFirstSaved = kSaveH0 ? 0 : 1;
     static constexpr int kActEnc = kFirstConcat ? kKs * (kFirstConcat - kFirstSaved) : 0;
-    static constexpr int act_h(int l) { return kKs * (l - kFirstSaved) + ((kFirstConcat == 0 || l >= kFirstConcat) ? 4 : 0); }   // l = kFirstSaved .. NL-1
-    static constexpr int kActDir = kKs * (NL - kFirstSaved) + 4, kActBlocks = kActDir + 2;
+    static constexpr int act_h(int l) { return kKs * (l - kFirstSaved) + ((kFirstConcat == 0 || l >= kFirstConcat) ? kEncQ : 0); }   // l = kFirstSaved .. NL-1
+    static constexpr int kActDir = kKs * (NL - kFirstSaved) + kEncQ, kActBlocks = kActDir + kDirQ;
     static constexpr int kDzHead = kKs * NL, kDzBlocks = kDzHead + 2;
     // dz of the last trunk layer is mask * (H dz_head) with 4 input channels: at width 256 its weight-gradient job recomputes it
     // (wgrad_body.h wgrad_last_recompute) and dgrad does not write it -- unless that layer takes [h ; xyz_enc] (then the job is the
@@ -77,36 +84,44 @@ struct Shape {
     static constexpr bool kSaveLastDz = concat_in(NL - 1) || U != 256;
     static constexpr int kMaskBlocks = NL;                   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
     static constexpr int kWgradJobs = NL + 1, kHeadJob = NL; // job j = trunk layer j; the last one = the head
-    // collapsed head (below): U h features + 32 dir slots (27 real)
-    static constexpr int kHeadRows = U + 32;
+    // collapsed head (below): U h features + 16 kDirQ dir slots (32, 27 of them real, for LD = 4)
+    static constexpr int kHeadRows = U + 16 * kDirQ;
     static constexpr int kHeadOff = kParamCount;             // H[row][c], c = 0..2 rgb, 3 sigma
     static constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
     static constexpr int kExtParamCount = kHeadBiasOff + 4;  // floats in a net's weight buffer
     static constexpr int kAuxBase = kParamCount;             // wgrad destination indices >= kAuxBase address the aux buffer
     static_assert(kSupported, "trunk shape not covered by the fused kernels");
 };
+template <int NL_, int SK_, int U_ = 256> struct Shape : ShapeImpl<NL_, SK_, U_, kLx, kLd> {};
+template <int NL_, int SK_, int U_, int LX_, int LD_> struct ShapeL : ShapeImpl<NL_, SK_, U_, LX_, LD_> {};
 using DefaultShape = Shape<8, 4>;
-// The trunk shapes the library is built for, X(index, n_layers, skip_layer, dense_units); index 0 is the reference's default.  Every entry costs
+// entry arguments -> type: (NL, SK, U) -> Shape<...>, (NL, SK, U, LX, LD) -> ShapeL<...>
+#define KNERF_SHAPE_SEL(a1, a2, a3, a4, a5, NAME, ...) NAME
+#define KNERF_SHAPE_T(...) KNERF_SHAPE_SEL(__VA_ARGS__, ShapeL, ShapeBadArity, Shape, ShapeBadArity, ShapeBadArity)<__VA_ARGS__>
+// The trunk shapes the library is built for, X(index, n_layers, skip_layer, dense_units [, pos_emb_xyz, pos_emb_dir]); index 0 is the reference's default.  Every entry costs
 // one more instantiation of the three big kernels: build.py compiles mlp_fwd / mlp_bwd / wgrad once per entry with
 // -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
 // instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
 #define KNERF_BUILTIN_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
     X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128)
-// Further entries chosen at BUILD time: `python keras_nerf_amd/build.py --add-shape=NL,SK,U ...` defines KNERF_EXTRA_SHAPES(X) as
-// X(12, NL, SK, U) X(13, ...) ... (indices continue the built-in list, at most 12 of them: KNERF_SLICE_12 .. 23 below).  A triple the
+// Further entries chosen at BUILD time: `python keras_nerf_amd/build.py --add-shape=NL,SK,U[,LX,LD] ...` defines KNERF_EXTRA_SHAPES(X) as
+// X(12, NL, SK, U) X(13, NL, SK, U, LX, LD) ... (indices continue the built-in list, at most 12 of them: KNERF_SLICE_12 .. 23 below).  A triple the
 // kernels do not cover fails to compile on Shape's static_assert; one that repeats an earlier entry is never selected.
 #ifndef KNERF_EXTRA_SHAPES
 #define KNERF_EXTRA_SHAPES(X)
 #endif
 #define KNERF_FUSED_SHAPES(X) KNERF_BUILTIN_SHAPES(X) KNERF_EXTRA_SHAPES(X)
-#define KNERF_X(I, NL, SK, U) +1
+#define KNERF_X(I, ...) +1
 constexpr int kNumBuiltinShapes = 0 KNERF_BUILTIN_SHAPES(KNERF_X);
 constexpr int kNumFusedShapes = 0 KNERF_FUSED_SHAPES(KNERF_X);
 #undef KNERF_X
 static_assert(kNumBuiltinShapes == 12 && kNumFusedShapes <= 24, "the slice macros below cover indices 0 .. 23");
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
-constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256) {
-#define KNERF_X(I, NL, SK, U) if (n_layers == NL && skip_layer == SK && dense_units == U) return I;
+template <class S> constexpr bool shape_is(int n_layers, int skip_layer, int dense_units, int lx, int ld) {
+    return n_layers == S::NL && skip_layer == S::SK && dense_units == S::U && lx == S::LX && ld == S::LD;
+}
+constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256, int pos_emb_xyz = kLx, int pos_emb_dir = kLd) {
+#define KNERF_X(I, ...) if (shape_is<KNERF_SHAPE_T(__VA_ARGS__)>(n_layers, skip_layer, dense_units, pos_emb_xyz, pos_emb_dir)) return I;
     KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
     return -1;
@@ -305,7 +320,7 @@ struct PackTables {
 template <class S>
 inline int head_in_row(int ks, int h, int j) {
     if (ks < S::kKs) return hid_feature(ks, h, j);
-    const int e = enc_feature(ks - S::kKs, h, j, kLd);
+    const int e = enc_feature(ks - S::kKs, h, j, S::LD);
     return e < 0 ? -1 : S::U + e;
 }
 template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= S::kHeadReal || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
@@ -313,10 +328,10 @@ template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= S
 // input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
 template <class S>
 inline int fwd_in_row(int st, int ks, int h, int j) {
-    if (st == 0) return enc_feature(ks, h, j, kLx);                          // layer_0: 63 inputs in 4 k-steps
+    if (st == 0) return enc_feature(ks, h, j, S::LX);                        // layer_0: 63 inputs in 4 k-steps (LX = 10)
     if (st == S::NL) return head_in_row<S>(ks, h, j);
     if (ks < S::kKs) return hid_feature(ks, h, j);                           // U-wide
-    const int e = enc_feature(ks - S::kKs, h, j, kLx);                       // concat layer: [h(U), xyz_enc(63)] (mlp.py:36-38)
+    const int e = enc_feature(ks - S::kKs, h, j, S::LX);                     // concat layer: [h(U), xyz_enc] (mlp.py:36-38)
     return e < 0 ? -1 : S::U + e;
 }
 
@@ -426,10 +441,10 @@ struct WgradJob {
 template <class S>
 constexpr WgradJob wgrad_job(int j) {
     constexpr int K = S::kKs, T = S::kOt;
-    if (j == 0) return {0, S::kActEnc, S::kActEnc, 2, 0, T, 0};
-    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), T + 1, S::kDzHead, 1, -1};   // [h ; dir] x (r,g,b,sigma): dir sits behind h
+    if (j == 0) return {0, S::kActEnc, S::kActEnc, S::kEncQ / 2, 0, T, 0};
+    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), T + S::kDirQ / 2, S::kDzHead, 1, -1};   // [h ; dir] x (r,g,b,sigma): dir sits behind h
     if (j == 1 && !S::kSaveH0) return {1, S::kActEnc, S::kActEnc, T, K, T, 1};                        // h0 recomputed: the table rows are h0 features
-    if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - K, T + 2, K * j, T, j};             // input tile T + k -> block act_blk2 + K + 2k
+    if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - K, T + S::kEncQ / 2, K * j, T, j};             // input tile T + k -> block act_blk2 + K + 2k
     if (j == S::NL - 1 && !S::kSaveLastDz) return {4, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
     return {2, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
 }
@@ -442,9 +457,9 @@ template <class S>
 inline int wgrad_in_row(int jb, int tr) {
     auto encrow = [](int tr_, int L) { int q = tr_ >> 4, c = tr_ & 15; return enc_feature(q, slot_from_c16_h(c), slot_from_c16_j(c), L); };
     const int kind = wgrad_job<S>(jb).kind;
-    if (kind == 0) return encrow(tr, kLx);
-    if (kind == 3) return tr < S::U ? tr : (encrow(tr - S::U, kLx) < 0 ? -1 : S::U + encrow(tr - S::U, kLx));
-    if (kind == 5) return tr < S::U ? tr : (encrow(tr - S::U, kLd) < 0 ? -1 : S::U + encrow(tr - S::U, kLd));
+    if (kind == 0) return encrow(tr, S::LX);
+    if (kind == 3) return tr < S::U ? tr : (encrow(tr - S::U, S::LX) < 0 ? -1 : S::U + encrow(tr - S::U, S::LX));
+    if (kind == 5) return tr < S::U ? tr : (encrow(tr - S::U, S::LD) < 0 ? -1 : S::U + encrow(tr - S::U, S::LD));
     return tr;
 }
 // destination of wgrad output element (tile-row tr, column tc): index into the flat gradient, kAuxBase + index into the
@@ -466,7 +481,7 @@ inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) 
 
 // ---- run-time view of a shape (host): what knerf_api.hip needs to size buffers and pick instantiations
 struct ShapeInfo {
-    int id, n_layers, skip, units;
+    int id, n_layers, skip, units, lx, ld, dir_dim, dir_slots;
     int param_count, ext_param_count, trunk_params, head_off, head_bias_off;
     int fwd_blocks, fwd_bias_tiles, bwd_blocks;
     int act_blocks, dz_blocks, mask_blocks;
@@ -476,7 +491,7 @@ struct ShapeInfo {
 template <class S>
 inline ShapeInfo make_shape_info(int id) {
     ShapeInfo i{};
-    i.id = id; i.n_layers = S::NL; i.skip = S::SK; i.units = S::U;
+    i.id = id; i.n_layers = S::NL; i.skip = S::SK; i.units = S::U; i.lx = S::LX; i.ld = S::LD; i.dir_dim = S::kDirDim; i.dir_slots = 16 * S::kDirQ;
     i.param_count = S::kParamCount; i.ext_param_count = S::kExtParamCount; i.trunk_params = S::kTrunkParams;
     i.head_off = S::kHeadOff; i.head_bias_off = S::kHeadBiasOff;
     i.fwd_blocks = S::kFwdBlocks; i.fwd_bias_tiles = S::kFwdBiasTiles; i.bwd_blocks = S::kBwdBlocks;
@@ -487,7 +502,7 @@ inline ShapeInfo make_shape_info(int id) {
 }
 inline const ShapeInfo& shape_info(int id) {
     static const ShapeInfo all[kNumFusedShapes] = {
-#define KNERF_X(I, NL, SK, U) make_shape_info<Shape<NL, SK, U>>(I),
+#define KNERF_X(I, ...) make_shape_info<KNERF_SHAPE_T(__VA_ARGS__)>(I),
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
     };

@@ -26,6 +26,7 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         rh[c] = v[c] * C1;
         rl[c] = __builtin_fmaf(v[c], C1, -rh[c]) + v[c] * C2;
     }
+    static_assert(2 + 3 * L <= NQ * 8, "encode: NQ k-steps hold 8 NQ features per lane half");
     const float phase = h ? 0.25f : 0.0f;
     float e[NQ * 8];
 #pragma unroll
@@ -49,16 +50,16 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
         for (int j = 0; j < 8; ++j) out[q][j] = (__bf16)e[8 * q + j];
 }
 
-// store schedule of the SAVE variant: 4 enc blocks up front; per trunk layer 2 blocks behind every out tile (none for layer_0: h0
-// is not saved) and one mask block at its end, the 2 dir blocks right behind the last trunk layer (counted as that stage's
-// end-of-stage stores); the head stage stores nothing
+// store schedule of the SAVE variant: the kEncQ (4) enc blocks up front; per trunk layer 2 blocks behind every out tile (none for
+// layer_0 where h0 is not saved) and one mask block at its end, the kDirQ (2) dir blocks right behind the last trunk layer (counted as
+// that stage's end-of-stage stores); the head stage stores nothing
 template <class S>
 constexpr StoreSched<S::kFwdStages> make_fwd_stores() {
     StoreSched<S::kFwdStages> t{};
     for (int st = 0; st < S::kFwdStages; ++st)
         t.st[st] = StoreStage{S::fwd_b0(st), S::fwd_nks(st), S::fwd_not(st), (st == S::NL || (st == 0 && !S::kSaveH0)) ? 0 : 2,
-                              st == S::NL ? 0 : (st == S::NL - 1 ? 3 : 1), 0};
-    t.initial = 4;
+                              st == S::NL ? 0 : (st == S::NL - 1 ? 1 + S::kDirQ : 1), 0};
+    t.initial = S::kEncQ;
     return t;
 }
 constexpr StoreSched<1> kNoStores = {{{0, 1, 0, 0, 0, 0}}, 0};
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 
     // the encodings are recomputed where they are consumed (layer_0 and layer_5; rgb_features) instead of pinning 24
     // VGPRs across the trunk: 42 v_sin per re-encode vs ~1200 MFMAs per tile
-    bf16x8 enc[4];
-    encode<kLx, 4>(px, py, pz, h, enc);
+    constexpr int QX = S::kEncQ, QD = S::kDirQ;     // k-steps of the two encodings (4 / 2 for the reference's L = 10 / 4)
+    bf16x8 enc[QX];
+    encode<S::LX, QX>(px, py, pz, h, enc);
 
     char* act = nullptr; char* maskp = nullptr;
     if (SAVE) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         maskp = a.mask + mask_tile_off<S>((size_t)tile);
 #ifndef KNERF_ABLATE_ENC_IO      // timing experiment only (with -DKNERF_CONSERVATIVE_WAIT): the upper bound of re-deriving the encodings in wgrad
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_block(act, S::kActEnc + q, lane, enc[q]);
+        for (int q = 0; q < QX; ++q) store_block(act, S::kActEnc + q, lane, enc[q]);
 #endif
     }
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     auto bias_init = [&](int base) { return [&, base](int ot) { return bias_acc(bias_lds, base + ot, h); }; };
 
     // layer_0: 63 -> 256, into x
-    dense_stage<0, 4, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
+    dense_stage<0, QX, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(0), [&](int ks) { return enc[ks]; }, relu_epi(x, 0, mb));
     // layers 1 .. NL-1, ping-pong x -> y -> x ...: even layers write x, odd layers y.  A concat layer takes [h, xyz_enc] (skip concat:
     // h first, input second; mlp.py:36-38) -- the encoding is recomputed where it is consumed instead of pinning 16 VGPRs
     // across the trunk: 42 v_sin per re-encode vs ~1000 MFMAs per tile
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         constexpr int l = decltype(l_)::value + 1;
         auto run = [&](bf16x8 (&in)[K], bf16x8 (&out)[K]) {
             if constexpr (S::concat_in(l)) {
-                bf16x8 encc[4];
-                encode<kLx, 4>(px, py, pz, h, encc);
-                dense_stage<S::fwd_b0(l), K + 4, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * l),
+                bf16x8 encc[QX];
+                encode<S::LX, QX>(px, py, pz, h, encc);
+                dense_stage<S::fwd_b0(l), K + QX, T, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * l),
                                                                    [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : encc[ks >= K ? ks - K : 0]; },
                                                                    relu_epi(out, l, mb));
             } else {
@@ -181,16 +183,16 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     });
     // head: [h_{NL-1}, dir_enc] -> (r, g, b, sigma) pre-activations, one out tile on the composed matrix (layout.h); lanes of
     // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).
-    bf16x8 dirc[2];
-    encode<kLd, 2>(dx, dy, dz, h, dirc);
+    bf16x8 dirc[QD];
+    encode<S::LD, QD>(dx, dy, dz, h, dirc);
 #ifndef KNERF_ABLATE_ENC_IO
     if (SAVE) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) store_block(act, S::kActDir + q, lane, dirc[q]);
+        for (int q = 0; q < QD; ++q) store_block(act, S::kActDir + q, lane, dirc[q]);
     }
 #endif
     auto head = [&](bf16x8 (&in)[K]) {
-        dense_stage<S::fwd_b0(S::NL), K + 2, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * S::NL),
+        dense_stage<S::fwd_b0(S::NL), K + QD, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * S::NL),
                                 [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : dirc[ks >= K ? ks - K : 0]; },
                                 [&](int, f32x16 acc) {
                                     if (valid && h == 0) {
@@ -251,14 +253,14 @@ hipError_t launch_mlp_fwd_t(const FwdArgs& a, bool save, hipStream_t stream) {
 }
 
 // explicit instantiation of this translation unit's shape(s), `extern template` for the others (layout.h KNERF_FUSED_SHAPES)
-#define KNERF_X(I, NL, SK, U) KNERF_PICK(I, template, extern template) hipError_t launch_mlp_fwd_t<Shape<NL, SK, U>>(const FwdArgs&, bool, hipStream_t);
+#define KNERF_X(I, ...) KNERF_PICK(I, template, extern template) hipError_t launch_mlp_fwd_t<KNERF_SHAPE_T(__VA_ARGS__)>(const FwdArgs&, bool, hipStream_t);
 KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
 
 #if KNERF_HAS_DISPATCH
 hipError_t launch_mlp_fwd(const FwdArgs& a, bool save, hipStream_t stream) {
     switch (a.shape) {
-#define KNERF_X(I, NL, SK, U) case I: return launch_mlp_fwd_t<Shape<NL, SK, U>>(a, save, stream);
+#define KNERF_X(I, ...) case I: return launch_mlp_fwd_t<KNERF_SHAPE_T(__VA_ARGS__)>(a, save, stream);
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
         default: return hipErrorInvalidValue;

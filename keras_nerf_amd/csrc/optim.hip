@@ -98,27 +98,28 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // Offsets of the six tensors behind the trunk in the flat parameter vector (Keras order: sigma, features, rgb_features, rgb)
 namespace {
 // the six tensors behind the trunk, from the offset of the first float behind the last trunk layer (layout.h Shape::kTrunkParams)
-// and the trunk width U: sigma [U,1], features [U,U], rgb_features [U+27, U/2], rgb [U/2, 3]
+// the trunk width U and the width D of the direction encoding (27): sigma [U,1], features [U,U], rgb_features [U+D, U/2], rgb [U/2, 3];
+// DS = direction slots of the composed head (16 per k-step: 32)
 struct HeadOff {
     int ws, bs, wf, bf, wr, br, wc, bc, head, head_bias;
-    __device__ HeadOff(int off_l, int U) {
+    __device__ HeadOff(int off_l, int U, int D, int DS) {
         ws = off_l; bs = ws + U;
         wf = bs + 1; bf = wf + U * U;
-        wr = bf + U; br = wr + (U + 27) * (U / 2);
+        wr = bf + U; br = wr + (U + D) * (U / 2);
         wc = br + U / 2; bc = wc + (U / 2) * 3;
-        head = bc + 3; head_bias = head + (U + 32) * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
+        head = bc + 3; head_bias = head + (U + DS) * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
     }
 };
 static_assert(DefaultShape::kTrunkParams + 257 + 256 * 257 + 283 * 128 + 128 + 128 * 3 + 3 == DefaultShape::kParamCount && DefaultShape::kHeadRows == 288, "head tensor offsets");
 constexpr int kMaxU = 256;
 }  // namespace
 
-// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < U);  H[U+m][0..2] = (W_r2 W_c)[m], H[U+m][3] = 0 (m < 27);
+// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < U);  H[U+m][0..2] = (W_r2 W_c)[m], H[U+m][3] = 0 (m < D; 0 up to DS);
 // bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP at U = 256.
-__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l, int U) {
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l, int U, int D, int DS) {
     float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
-    const HeadOff o(off_l, U);
-    const int U2 = U / 2, R = U + 27;
+    const HeadOff o(off_l, U, D, DS);
+    const int U2 = U / 2, R = U + D;
     __shared__ float P[kMaxU + 27][3];   // W_r W_c : rows 0..U-1 = W_r1 W_c, U..U+26 = W_r2 W_c
     __shared__ float wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
@@ -138,9 +139,9 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
         for (int j = 0; j < U; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
         H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[o.ws + tid];
     }
-    if (tid < 32) {
+    if (tid < DS) {
         const int r = U + tid;
-        const bool real = tid < 27;
+        const bool real = tid < D;
         H[r * 4 + 0] = real ? P[r][0] : 0.f; H[r * 4 + 1] = real ? P[r][1] : 0.f; H[r * 4 + 2] = real ? P[r][2] : 0.f; H[r * 4 + 3] = 0.f;
     }
     if (tid < 3) {
@@ -151,23 +152,24 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
     }
     if (tid == 3) w[o.head_bias + 3] = w[o.bs];
 }
-hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, hipStream_t stream) {
-    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units);
+hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, int dir_dim, int dir_slots, hipStream_t stream) {
+    if (units > kMaxU || dir_dim > 27 || dir_slots > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units, dir_dim, dir_slots);
     return hipGetLastError();
 }
 
-// aux: M[row][c] = sum_s [h ; dir][s][row] dz_rgb[s][c] (row < U + 27), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..U-1,
+// aux: M[row][c] = sum_s [h ; dir][s][row] dz_rgb[s][c] (row < U + D), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..U-1,
 // M2 = rows U..U+26, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
 //   d rgb/kernel          = W_r1^T Q + W_r2^T M2 + b_r (x) s        d rgb/bias          = s
 //   d rgb_features/kernel = [Q ; M2] W_c^T                          d rgb_features/bias = s W_c^T
 //   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
 // -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
 // evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
-struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l, U; };
+struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l, U, D, DS; };
 __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
-    const int U = a.U, U2 = U / 2, R = U + 27;
-    const HeadOff o(a.off_l, U);
+    const int U = a.U, U2 = U / 2, R = U + a.D;
+    const HeadOff o(a.off_l, U, a.D, a.DS);
     __shared__ float M[kMaxU + 27][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
     for (int i = tid; i < R * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
@@ -211,8 +213,10 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     }
     if (tid < 3) grad[o.bc + tid] += s_[tid];
 }
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, hipStream_t stream) {
-    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units};
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int dir_dim, int dir_slots,
+                              hipStream_t stream) {
+    if (units > kMaxU || dir_dim > 27) return hipErrorInvalidValue;
+    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units, dir_dim, dir_slots};
     hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }

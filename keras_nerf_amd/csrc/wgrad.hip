@@ -77,14 +77,14 @@ hipError_t launch_wgrad_t(const WgradArgs& a, hipStream_t stream) {
 }
 
 // explicit instantiation of this translation unit's shape(s), `extern template` for the others (layout.h KNERF_FUSED_SHAPES)
-#define KNERF_X(I, NL, SK, U) KNERF_PICK(I, template, extern template) hipError_t launch_wgrad_t<Shape<NL, SK, U>>(const WgradArgs&, hipStream_t);
+#define KNERF_X(I, ...) KNERF_PICK(I, template, extern template) hipError_t launch_wgrad_t<KNERF_SHAPE_T(__VA_ARGS__)>(const WgradArgs&, hipStream_t);
 KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
 
 #if KNERF_HAS_DISPATCH
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     switch (a.shape) {
-#define KNERF_X(I, NL, SK, U) case I: return launch_wgrad_t<Shape<NL, SK, U>>(a, stream);
+#define KNERF_X(I, ...) case I: return launch_wgrad_t<KNERF_SHAPE_T(__VA_ARGS__)>(a, stream);
         KNERF_FUSED_SHAPES(KNERF_X)
 #undef KNERF_X
         default: return hipErrorInvalidValue;

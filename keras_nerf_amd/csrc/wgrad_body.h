@@ -225,7 +225,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
             const bool ok = b < BLK_IN;
             const int blk = (ok ? b : 0) + ((ok && b >= S::kKs) ? act_blk2 : act_blk);     // block of the tile's act run (h: S::kKs blocks)
 #ifdef KNERF_ABLATE_ENC_IO     // timing experiment only: the enc / dir blocks come from tile 0 (L2 hits) -- what wgrad would gain if it re-derived them for free
-            const bool is_enc = (blk >= S::kActEnc && blk < S::kActEnc + 4) || blk >= S::kActDir;
+            const bool is_enc = (blk >= S::kActEnc && blk < S::kActEnc + S::kEncQ) || blk >= S::kActDir;
             const char* base = is_enc ? a.act + lane * 16 : tile_in;
             glds16(base + (size_t)blk * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + b * 1024 : scratch), late);
 #else

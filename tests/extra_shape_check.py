@@ -1,6 +1,7 @@
 """Helper of tests/test_gpu_variants.py::test_build_time_extra_shapes...: run with KNERF_LIB / KNERF_PROBE_LIB pointing at a library built
-with `build.py --add-shape=6,3,128 --add-shape=8,2,128`; prints one JSON line per shape: where the shape sits in the library's list,
-whether it runs on the fused kernels, and its images / losses / gradients against the oracle (kernel arithmetic)."""
+with `build.py --add-shape=...`; for every entry behind the built-in twelve: the host tables are checked (tests/test_shape_tables.py) and
+one JSON line is printed -- the entry, whether NeRF(...) with those arguments runs on the fused kernels, and its images / losses /
+gradients against the oracle (kernel arithmetic)."""
 import json
 import os
 import sys
@@ -18,12 +19,21 @@ def main():
     from oracle import nerf_oracle as O
     from tests.problem import make_problem
     from tests.test_gpu_train import flat, per_tensor_err
-    for k, (nl, sk, units) in enumerate(((6, 3, 128), (8, 2, 128))):
-        info = [int(v) for v in D.debug_table(5, 12 + k)]
-        cfg = O.NerfConfig(n_layers=nl, dense_units=units, skip_layer=sk)
+    from keras_nerf_amd import _lib
+    from tests.test_shape_tables import _check_tables
+    k = 12
+    while True:
+        try:
+            info = [int(v) for v in D.debug_table(5, k)]
+        except _lib.KnerfError:
+            break
+        _check_tables(k)
+        k += 1
+        nl, sk, units, _, lx, ld = info
+        cfg = O.NerfConfig(n_layers=nl, dense_units=units, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld)
         P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
         o, d, t, u, img = flat(P)
-        ctx = KnerfContext(n_layers=nl, dense_units=units, skip_layer=sk, white_background=True)
+        ctx = KnerfContext(n_layers=nl, dense_units=units, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld, white_background=True)
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         loss = torch.zeros(2, device="cuda")
         ci = torch.empty((P["N"], 3), device="cuda"); fi = torch.empty_like(ci)
@@ -34,7 +44,7 @@ def main():
         g = ctx.grads_view().cpu().numpy(); n = g.size // 2
         rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
         rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=O.FUSED)
-        print(json.dumps({"shape": [nl, sk, units], "info": info, "general_shape_path": ctx.get_option("general_shape_path"),
+        print(json.dumps({"shape": [nl, sk, units, lx, ld], "info": info, "general_shape_path": ctx.get_option("general_shape_path"),
                           "coarse_worst": float(per_tensor_err(g[:n], O.flatten_params(gc), cfg)[0]),
                           "fine_worst": float(per_tensor_err(g[n:], O.flatten_params(gf), cfg)[0]),
                           "loss_err": max(abs(float(loss[0]) - float(lc)), abs(float(loss[1]) - float(lf))),

@@ -19,10 +19,10 @@ using namespace knerf;
 int main() {
     std::printf("%d %d\n", kNumBuiltinShapes, kNumFusedShapes);
     const int ids[4] = {fused_shape_id(6, 3, 128), fused_shape_id(8, 2, 128), fused_shape_id(8, 4, 256), fused_shape_id(7, 3, 256)};
-    std::printf("%d %d %d %d\n", ids[0], ids[1], ids[2], ids[3]);
+    std::printf("%d %d %d %d %d %d\n", ids[0], ids[1], ids[2], ids[3], fused_shape_id(8, 4, 256, 12, 3), fused_shape_id(8, 4, 256, 12, 4));
     for (int k = 12; k < kNumFusedShapes; ++k) {
         const ShapeInfo& s = shape_info(k);
-        std::printf("%d %d %d %d %d %d %d\n", s.n_layers, s.skip, s.units, s.param_count, s.fwd_blocks, s.bwd_blocks, s.n_jobs);
+        std::printf("%d %d %d %d %d %d %d %d %d %d\n", s.n_layers, s.skip, s.units, s.param_count, s.fwd_blocks, s.bwd_blocks, s.n_jobs, s.lx, s.ld, s.act_blocks);
     }
     PackTables pt;
     build_fwd<Shape<6, 3, 128>>(pt); build_bwd<Shape<6, 3, 128>>(pt);
@@ -35,7 +35,8 @@ int main() {
 def test_parse_shapes_accepts_covered_triples_and_names_the_others():
     assert B.parse_shapes(["6,3,128", "8,2,128;6,4,256", "6,3,128"]) == [(6, 3, 128), (8, 2, 128), (6, 4, 256)]
     assert B.parse_shapes([]) == [] and B.parse_shapes([""]) == []
-    for bad in ("8,4,64", "2,1,256", "9,4,256", "4,3,256", "8,4", "a,b,c", "8,0,256"):     # width, depth, concat behind the last layer (x2), arity, type, skip
+    assert B.parse_shapes(["8,4,256,6,2;8,4,128,10,4"]) == [(8, 4, 256, 6, 2), (8, 4, 128)]           # the reference's encodings need no ShapeL entry
+    for bad in ("8,4,64", "2,1,256", "9,4,256", "4,3,256", "8,4", "a,b,c", "8,0,256", "8,4,256,10", "8,4,256,17,4", "8,4,256,10,5", "8,4,256,0,4"):     # width, depth, concat behind the last layer (x2), arity, type, skip, arity, encodings (x3)
         with pytest.raises(ValueError):
             B.parse_shapes([bad])
     with pytest.raises(ValueError):
@@ -46,18 +47,30 @@ def test_layout_header_with_extra_shapes(tmp_path):
     src = tmp_path / "shapes.cpp"
     src.write_text(PROG)
     exe = tmp_path / "shapes"
-    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(12, 6, 3, 128) X(13, 8, 2, 128)",
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(12, 6, 3, 128) X(13, 8, 2, 128) X(14, 8, 4, 256, 12, 3)",
                         str(src), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
-    assert out[0].split() == ["12", "14"]
-    assert out[1].split() == ["12", "13", "0", "-1"]
-    for line, (nl, sk, u) in zip(out[2:4], ((6, 3, 128), (8, 2, 128))):
+    assert out[0].split() == ["12", "15"]
+    assert out[1].split() == ["12", "13", "0", "-1", "14", "-1"]
+    for line, (nl, sk, u, lx, ld, qx, qd) in zip(out[2:5], ((6, 3, 128, 10, 4, 4, 2), (8, 2, 128, 10, 4, 4, 2), (8, 4, 256, 12, 3, 6, 2))):
         v = [int(x) for x in line.split()]
-        cfg = O.NerfConfig(n_layers=nl, dense_units=u, skip_layer=sk)
-        n_concat = sum(1 for name, i, o in O.layer_shapes(cfg) if name.startswith("layer_") and i == u + 63)
+        cfg = O.NerfConfig(n_layers=nl, dense_units=u, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld)
+        n_concat = sum(1 for name, i, o in O.layer_shapes(cfg) if name.startswith("layer_") and i == u + 3 + 6 * lx)
         ks, ot = u // 16, u // 32
-        assert v[:3] == [nl, sk, u] and v[3] == O.param_count(cfg)
-        assert v[4] == 4 * ot + (nl - 1) * ks * ot + n_concat * 4 * ot + ks + 2
+        assert v[:3] == [nl, sk, u] and v[3] == O.param_count(cfg) and v[7:9] == [lx, ld]
+        assert v[4] == qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + ks + qd          # six encoding k-steps for pos_emb_xyz = 12
         assert v[5] == ot + (nl - 1) * ks * ot and v[6] == nl + 1
-    assert [int(x) for x in out[4].split()] == [(4 * 4 + 5 * 8 * 4 + 1 * 4 * 4 + 8 + 2) * 512, (4 * 6 + 1) * 32, (4 + 5 * 8 * 4) * 512]
+        saves_h0 = u != 256 or qx != 4
+        assert v[9] == ks * (nl - 1 + saves_h0) + qx + qd
+    assert [int(x) for x in out[5].split()] == [(4 * 4 + 5 * 8 * 4 + 1 * 4 * 4 + 8 + 2) * 512, (4 * 6 + 1) * 32, (4 + 5 * 8 * 4) * 512]
+
+
+def test_spill_report_of_the_build_guard():
+    """build.py refuses an instantiation of the three big kernels that spills (their waits are hand-counted)"""
+    ok = "a.hip:1:1: remark: Function Name: _Zk [-R]\na.hip:1:1: remark:     VGPRs Spill: 0 [-R]\na.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-R]\n"
+    assert B._spill_report("x.o", ok) is None
+    assert "VGPRs Spill = 3" in B._spill_report("x.o", ok.replace("VGPRs Spill: 0", "VGPRs Spill: 3"))
+    assert "ScratchSize" in B._spill_report("x.o", ok.replace("lane]: 0", "lane]: 16"))
+    assert "cannot run" in B._spill_report("x.o", "")
+    assert B._spill_report("x.o", ok + "a.hip:1:1: remark:     SGPRs Spill: 6 [-R]\n") is None      # to vector-register lanes, not to memory

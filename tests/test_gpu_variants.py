@@ -37,21 +37,28 @@ def test_compiler_tracked_fragment_loads_give_identical_bits():
     assert len(a) >= 10
 
 
+XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3"]
+
+
 def test_build_time_extra_shapes_run_on_the_fused_kernels():
-    """`build.py --add-shape=NL,SK,U` (csrc/layout.h KNERF_EXTRA_SHAPES): a library built with 6/3/128 and 8/2/128 beside the built-in
-    list runs NeRF(n_layers=6, skip_layer=3, dense_units=128) and 8/2/128 on the fused kernels, at the built-in shapes' tolerances."""
+    """`build.py --add-shape=NL,SK,U[,LX,LD]` (csrc/layout.h KNERF_EXTRA_SHAPES): a library built with two more width-128 trunks and four
+    shapes with other positional-encoding depths (pos_emb_xyz 6 / 12 / 5 / 16, pos_emb_dir 2 / 4 / 1 / 3: four, six, four and eight
+    encoding k-steps; h0 recomputed or saved) runs them on the fused kernels: host tables consistent, images / losses / gradients at
+    the built-in shapes' tolerances against the oracle."""
     from keras_nerf_amd import build as B
-    lib = B.build(verbose=False, variant="xshape", add_shapes=["6,3,128", "8,2,128"])
+    lib = B.build(verbose=False, variant="xshape", add_shapes=XSHAPES)
     env = dict(os.environ, KNERF_LIB=lib, KNERF_PROBE_LIB=lib.replace("libknerf_hip_", "libknerf_probe_"))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_check.py")], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_check.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert [tuple(x["shape"]) for x in rows] == [(6, 3, 128), (8, 2, 128)]
+    want = [tuple(int(v) for v in x.split(",")) for x in XSHAPES]
+    assert [tuple(x["shape"]) for x in rows] == [w if len(w) == 5 else w + (10, 4) for w in want]
     for x in rows:
-        assert x["info"][:3] == x["shape"] and x["general_shape_path"] == 0.0, x
+        assert x["info"][:3] == x["shape"][:3] and x["info"][4:] == x["shape"][3:] and x["general_shape_path"] == 0.0, x
         assert x["coarse_worst"] < 1.5e-2 and x["fine_worst"] < 1.5e-2 and x["loss_err"] < 2e-3 and x["img_err"] < 1e-2, x
     # the default library does not know them: same constructor arguments, general-shape kernels
     from keras_nerf_amd.runtime import KnerfContext
-    ctx = KnerfContext(n_layers=6, dense_units=128, skip_layer=3, white_background=True)
-    assert ctx.get_option("general_shape_path") == 1.0
-    ctx.close()
+    for kw in (dict(n_layers=6, dense_units=128, skip_layer=3), dict(pos_emb_xyz=6, pos_emb_dir=2)):
+        ctx = KnerfContext(white_background=True, **kw)
+        assert ctx.get_option("general_shape_path") == 1.0
+        ctx.close()

@@ -35,15 +35,25 @@ def test_the_list_has_the_default_shape_first_and_both_widths():
 
 @pytest.mark.parametrize("k", range(12))
 def test_tables_of_shape(k):
-    nl, sk, U, n = (int(v) for v in D.debug_table(5, k))
-    cfg = O.NerfConfig(n_layers=nl, dense_units=U, skip_layer=sk)
+    _check_tables(k)
+
+
+def _enc_q(L):
+    """k-steps of an encoding of depth L: 2 + 3 L features per lane half, 8 per k-step, rounded up to even (csrc/layout.h enc_q)"""
+    return ((2 + 3 * L + 7) // 8 + 1) // 2 * 2
+
+
+def _check_tables(k):
+    nl, sk, U, n, lx, ld = (int(v) for v in D.debug_table(5, k))
+    cfg = O.NerfConfig(n_layers=nl, dense_units=U, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld)
+    xd, dd, qx, qd = 3 + 6 * lx, 3 + 6 * ld, _enc_q(lx), _enc_q(ld)
     assert n == O.param_count(cfg)
     shapes = O.layer_shapes(cfg)
     n_trunk = sum(i * o + o for name, i, o in shapes if name.startswith("layer_"))
     fwd, bias, bwd = D.debug_table(0, k), D.debug_table(1, k), D.debug_table(2, k)
-    n_concat = sum(1 for name, i, o in shapes if name.startswith("layer_") and i == U + 63)
+    n_concat = sum(1 for name, i, o in shapes if name.startswith("layer_") and i == U + xd)
     ks, ot = U // 16, U // 32
-    assert fwd.size == (4 * ot + (nl - 1) * ks * ot + n_concat * 4 * ot + (ks + 2)) * 512       # layer_0, U-wide layers, concat extras, head
+    assert fwd.size == (qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + (ks + qd)) * 512       # layer_0, U-wide layers, concat extras, head
     assert bias.size == (ot * nl + 1) * 32
     assert bwd.size == (ot + (nl - 1) * ks * ot) * 512
     # forward stream + bias: every trunk parameter once, nothing of the four tensors behind the trunk, the composed head behind n
@@ -52,7 +62,7 @@ def test_tables_of_shape(k):
     np.add.at(used, bias[(bias >= 0) & (bias < n)], 1)
     assert (used[:n_trunk] == 1).all() and not used[n_trunk:].any()
     head = np.concatenate([fwd[fwd >= n], bias[bias >= n]]) - n
-    assert sorted(head) == sorted([r * 4 + c for r in range(U + 27) for c in range(4)] + [(U + 32) * 4 + c for c in range(4)])
+    assert sorted(head) == sorted([r * 4 + c for r in range(U + dd) for c in range(4)] + [(U + 16 * qd) * 4 + c for c in range(4)])
     # dgrad stream: layers 1 .. NL-1 (their first U input rows: no gradient flows into the encodings) and the head's h rows, each once
     vals, counts = np.unique(bwd[bwd >= 0], return_counts=True)
     assert counts.max() == 1
@@ -70,5 +80,5 @@ def test_tables_of_shape(k):
     g = dst[(dst >= 0) & (dst < n)]
     assert np.array_equal(np.sort(g), np.arange(n_trunk + U + 1))
     aux = np.sort(dst[dst >= n] - n)
-    assert np.array_equal(aux, np.concatenate([np.arange((U + 27) * 3), AUX_S + np.arange(3)]))
+    assert np.array_equal(aux, np.concatenate([np.arange((U + dd) * 3), AUX_S + np.arange(3)]))
     assert dst.min() >= -1
