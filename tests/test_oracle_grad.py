@@ -38,6 +38,23 @@ def test_chunk_grads_match_autograd_fp64(white):
     assert sum(float(np.abs(g).sum()) for g in grads) > 0
 
 
+@pytest.mark.parametrize("nl,sk,units,lx,ld", [(8, 2, 16, 4, 2), (6, 3, 32, 3, 1), (4, 2, 16, 5, 2), (12, 4, 16, 2, 3), (10, 5, 16, 6, 4)])
+def test_chunk_grads_match_autograd_for_other_trunk_shapes(nl, sk, units, lx, ld):
+    """the trunk shapes the fused GPU kernels are tested on against THIS oracle (tests/test_gpu_fused_shapes.py, test_gpu_variants.py:
+    several concat layers, a concat layer in last position, other encoding depths), at small width: hand-written backward == autograd"""
+    cfg = O.NerfConfig(n_coarse=8, n_fine=16, pos_emb_xyz=lx, pos_emb_dir=ld, n_layers=nl, dense_units=units, skip_layer=sk)
+    cfg, o, d, t, u, img, cp, fp = small_problem(seed=nl, cfg=cfg)
+    res, loss, grads = O.chunk_loss_and_grads(cp, o, d, t, img, cfg, True)
+    tp = [torch.tensor(p, requires_grad=True) for p in cp]
+    timg, _, tw = T.chunk_forward(tp, torch.tensor(o), torch.tensor(d), torch.tensor(t), cfg, True)
+    tl = torch.mean((torch.tensor(img) - timg) ** 2)
+    tg = torch.autograd.grad(tl, tp)
+    assert float(tl.detach()) == pytest.approx(float(loss), rel=1e-12)
+    assert len(grads) == 2 * (nl + 4)
+    for g, t_ in zip(grads, tg):
+        np.testing.assert_allclose(g, t_.numpy(), rtol=1e-8, atol=1e-13)
+
+
 def test_fine_sampling_matches_torch_both_modes():
     cfg, o, d, t, u, img, cp, fp = small_problem()
     rng = np.random.default_rng(5)
@@ -105,7 +122,9 @@ def test_collapsed_head_is_the_same_function_and_the_same_gradients(monkeypatch)
     24 gradients, every tensor."""
     monkeypatch.setattr(O, "_rb", lambda x: np.asarray(x))
     for cfg in (O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=4, pos_emb_dir=2, n_layers=4, dense_units=32, skip_layer=2),
-                O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=3, pos_emb_dir=1, n_layers=3, dense_units=16, skip_layer=1)):   # concat after the LAST layer
+                O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=3, pos_emb_dir=1, n_layers=3, dense_units=16, skip_layer=1),    # concat after the LAST layer
+                O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=5, pos_emb_dir=3, n_layers=8, dense_units=16, skip_layer=2),    # three concat layers
+                O.NerfConfig(n_coarse=8, n_fine=8, pos_emb_xyz=6, pos_emb_dir=4, n_layers=12, dense_units=16, skip_layer=4)):
         _check_collapsed_head(cfg)
 
 
