@@ -153,7 +153,8 @@ def dist_fields(world, backend, steps):
 
 def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
     """cfg5: frames/s of the 360-degree render loop of the reference's inference.py:62-114 (theta sweep at phi=-30,
-    radius 4; rays generated on the device; fine image + depth copied to the host per frame as the reference does)."""
+    radius 4; rays generated on the device; fine image + depth copied to the host per frame as the reference does -- pipelined: pinned
+    double buffers on a side stream, the host collects frame i-1 while frame i renders)."""
     from keras_nerf_amd.data.rays import RaysGenerator
     from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
     from keras_nerf_amd.model.nerf.nerf import NeRF
@@ -164,24 +165,46 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
     n_frames = args.steps
     poses = [pose_spherical(360.0 * i / max(n_frames, 1), -30.0, 4.0) for i in range(n_frames + args.warmup)]
 
-    def frame(i):
+    # inference.py:108-114 reads the fine image and depth of every frame back (`.numpy()`).  Here: only those two outputs are
+    # computed (outputs=...: the four [N, S] weight arrays are neither allocated nor written), and the copy of frame i runs on a side
+    # stream into pinned, double-buffered host memory while frame i+1 renders; the host waits for frame i-1's copy, not for the GPU.
+    copy_stream = torch.cuda.Stream()
+    pinned = [(torch.empty((1, wh, wh, 3), pin_memory=True), torch.empty((1, wh, wh), pin_memory=True)) for _ in range(2)]
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    frames_out = []
+
+    def frame(i, k):
         o, d, t = rg(poses[i])
-        _, fine = nerf.predict_and_render_images((o[None], d[None], t[None]))
-        return fine["image"].cpu().numpy(), fine["depth"].cpu().numpy()
+        _, fine = nerf.predict_and_render_images((o[None], d[None], t[None]), outputs=("image", "depth"))
+        rendered = torch.cuda.Event(); rendered.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(rendered)
+            pinned[k][0].copy_(fine["image"], non_blocking=True); pinned[k][1].copy_(fine["depth"], non_blocking=True)
+            fine["image"].record_stream(copy_stream); fine["depth"].record_stream(copy_stream)
+            copied[k].record(copy_stream)
+
+    def collect(k):          # the host-side end of a frame: its pixels are in pageable memory, the pinned pair is free again
+        copied[k].synchronize()
+        frames_out.append((pinned[k][0].numpy().copy(), pinned[k][1].numpy().copy()))
     for i in range(args.warmup):
-        frame(i)
+        frame(i, i & 1); collect(i & 1)
+    frames_out.clear()
     sync(world)
     t0 = time.perf_counter()
     for i in range(n_frames):
-        img, dep = frame(args.warmup + i)
+        frame(args.warmup + i, i & 1)
+        if i:
+            collect((i - 1) & 1)
+    collect((n_frames - 1) & 1)
     sync(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    assert len(frames_out) == n_frames
     fps = world * n_frames / elapsed
     rs = fps * wh * wh * 256
     roofline = None
     if rank == 0:
         nerf._ctx.profile_enable(True); nerf._ctx.profile_read()
-        frame(0)
+        frame(0, 0); collect(0)
         prof = nerf._ctx.profile_read(); nerf._ctx.profile_enable(False)
         ms, cnt = prof["mlp_fwd_fine"]
         avg = ms / max(cnt, 1)
@@ -211,28 +234,34 @@ WGRAD_KIB_PER_TILE = ACT_KIB + DZ_KIB + WGRAD_REREAD_KIB
 STEP_KIB_PER_TILE = 2 * (ACT_KIB + DZ_KIB + MASK_KIB) + WGRAD_REREAD_KIB + 2.5
 
 
-def pmc_traffic(kernel):
-    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary of THIS data layout
-    (profiles/*pmc_traffic*.json, produced by tools/pmc.sh + tools/pmc_report.py on the GPU box: separate rocprofv3 --pmc
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is, both
-    in KiB).  Counters cannot be read from inside the benched process, so the line names its source; (None, None) when no
-    summary of this layout is committed."""
+def pmc_traffic(kernel, skip_dead_tiles):
+    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary of THIS data layout that profiled the
+    INSTANTIATION the bench ran (profiles/*pmc_traffic*.json, produced by tools/pmc.sh + tools/pmc_report.py on the GPU box: separate
+    rocprofv3 --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is,
+    both in KiB).  Counters cannot be read from inside the benched process, so the line names its source.  The weight-gradient kernel
+    has a list-mode instantiation (`wgrad_kernel<Shape, NET, true>`: skip_dead_tiles on, the default) and a contiguous one
+    (`..., false>`); the dgrad kernel takes its list at run time, so for it the summary's recorded `_options` must match.  A summary
+    that holds only the other instantiation is NOT quoted: (None, None)."""
     import glob
-    # (name prefix, template argument that must be present, which of the two nets' launches)
-    name = {"wgrad_fine": ("wgrad_kernel", "", max), "wgrad_coarse": ("wgrad_kernel", "", min), "mlp_fwd_fine": ("mlp_fwd_kernel<", "true", max),
-            "mlp_fwd_coarse": ("mlp_fwd_kernel<", "true", min), "mlp_bwd_fine": ("mlp_bwd_kernel", "", max),
-            "mlp_bwd_coarse": ("mlp_bwd_kernel", "", min)}.get(kernel)
-    if not name:
+    net = "1" if kernel.endswith("fine") else "0"
+    lst = "true" if skip_dead_tiles else "false"
+    # (name prefix, the end of the template argument list that must match)
+    want = {"wgrad": ("wgrad_kernel<", f", {net}, {lst}>"), "mlp_fwd": ("mlp_fwd_kernel<", f", true, {net}>"),
+            "mlp_bwd": ("mlp_bwd_kernel<", f", {net}>")}.get(kernel.rsplit("_", 1)[0])
+    if not want:
         return None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         rep = json.load(open(f))
         if rep.get("_layout", "act158_dz156") != LAYOUT_TAG:
             continue
-        rows = [v for k, v in rep.items() if k.startswith(name[0]) and name[1] in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+        opt = rep.get("_options", {}).get("skip_dead_tiles")          # absent in summaries older than round 4: they profiled skipping off
+        if kernel.startswith("mlp_bwd") and bool(opt) != bool(skip_dead_tiles):
+            continue
+        rows = [v for k, v in rep.items() if k.startswith(want[0]) and k.split(" grid=")[0].endswith(want[1]) and isinstance(v, dict)
+                and "hbm_bytes_per_launch" in v]
         if not rows:
             continue
-        val = max(r["hbm_bytes_per_launch"] for r in rows) if name[2] is max else min(r["hbm_bytes_per_launch_min"] for r in rows)
-        return val, os.path.relpath(f, ROOT)
+        return max(r["hbm_bytes_per_launch"] for r in rows), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -273,8 +302,13 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     if world > 1:
         torch.distributed.barrier()
     train, val, test = DatasetLoader(os.path.join(root, "data"), white_background=True).load_dataset(batch, wh, wh, 2.0, 6.0, 64)
-    nerf = NeRF(seed=0)
-    nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)
+    nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: own initial weights per rank; compile() mirrors rank 0's
+    try:
+        nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)
+    except Exception as e:                     # noqa: BLE001
+        if world > 1:
+            rank_fail(rank, world, torch.cuda.current_device(), backend, "NeRF.compile (weight broadcast)", e)
+        raise
     monitor = NeRFTrainMonitor(test, os.path.join(root, "log"), batch, update_freq=1, plots=False)
     marks = []
 
@@ -329,8 +363,11 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
         live, total = nerf._ctx.tile_stats(reset=True)
         dead_fit = 1.0 - live / max(total, 1) if total else None
     nerf._ctx.set_option("skip_dead_tiles", int(skip_default))
+    drift = {}
+    if args.check_replicas:
+        drift["replica_drift"], drift["weight_checksum"] = replica_drift(nerf, world)
     if rank == 0:
-        print(json.dumps({"metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
+        print(json.dumps({**drift, "metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
                           "unit": "rays*samples/s", "n_gpus": world, "steps": steps * args.epochs, "warmup": steps, "ms_per_step": loop / (steps * args.epochs) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": f"{args.config} through NeRF.fit: {desc}; 100 procedural training views in nerf_synthetic layout, "
@@ -346,6 +383,46 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     shutil.rmtree(root, ignore_errors=True)
 
 
+def dist_env():
+    """The environment every rank needs, whichever way it was started (self-spawned or under an external torch.distributed.run):
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve) and dmabuf IPC (the host driver supports nothing else:
+    without it RCCL fails with `hipIpcGetMemHandle: invalid argument`).  Called before anything touches HIP; existing values win."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def rank_fail(rank, world, device_index, backend, what, exc):
+    """A rank that cannot join or use the process group says so and leaves with exit code 3 -- the launcher then stops the other
+    ranks -- instead of letting them sit in a collective until its time-out.  Never re-execs (the process has initialised the GPU)."""
+    import traceback
+    print(f"[bench rank {rank}/{world}] FAILED in {what} on cuda:{device_index} (backend {backend}): {type(exc).__name__}: {exc}\n"
+          f"{traceback.format_exc()}", file=sys.stderr, flush=True)
+    sys.stderr.flush(); sys.stdout.flush()
+    os._exit(3)
+
+
+def inject(stage, rank):
+    """fault injection for the fail-fast test (tests/test_gpu_api.py): KNERF_BENCH_INJECT_FAILURE="<rank>:<stage>" makes that rank
+    raise at that stage (init | first_all_reduce | compile | warmup)"""
+    spec = os.environ.get("KNERF_BENCH_INJECT_FAILURE", "")
+    if spec and spec == f"{rank}:{stage}":
+        raise RuntimeError(f"injected failure at stage '{stage}'")
+
+
+def replica_drift(nerf, world):
+    """`--check-replicas`: mirrored variables must be IDENTICAL on every rank after identical Adam updates on the all-reduced
+    gradient (train.py:110-148).  An exact 64-bit checksum of both nets' fp32 master weights (their bit patterns summed as
+    integers) is reduced with MAX and MIN; the line carries max - min, which must be 0 under SUM and under mean."""
+    w = torch.cat([nerf._ctx.weights_view(0), nerf._ctx.weights_view(1)])
+    bits = w.view(torch.int32).to(torch.int64)
+    chk = (bits * (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 8191 + 1)).sum().reshape(1)
+    hi, lo = chk.clone(), chk.clone()
+    if world > 1:
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    return float(int(hi[0]) - int(lo[0])), int(chk[0])
+
+
 def spawn_ranks(args, backend, n_dev):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
     rendezvous on 127.0.0.1), wait, exit with their code.  Rank 0's JSON line goes to the inherited stdout.  The parent has
@@ -359,8 +436,7 @@ def spawn_ranks(args, backend, n_dev):
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ)).returncode)      # dist_env() has run: the children inherit it
 
 
 def main():
@@ -376,7 +452,13 @@ def main():
     ap.add_argument("--epochs", type=int, default=2, help="--mode fit: timed epochs")
     ap.add_argument("--skip-dead-tiles", type=int, default=None, help="override the library default of the skip_dead_tiles option (0/1)")
     ap.add_argument("--deterministic", type=int, default=None, help="set the deterministic option (0/1): gradient sums without atomics")
+    ap.add_argument("--check-replicas", type=int, default=None, help="after the timed region: exact weight checksum of every rank reduced "
+                    "with MAX and MIN; `replica_drift` (must be 0.0) goes on the line.  Default: on for N > 1 (two one-word collectives, "
+                    "outside every timed region), off for N = 1")
     args = ap.parse_args()
+    if args.check_replicas is None:
+        args.check_replicas = int(args.gpus > 1)
+    dist_env()                                 # the same environment for self-spawned ranks and for ranks of an external launcher
 
     # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("KNERF_DIST_BACKEND", "nccl")
@@ -401,11 +483,24 @@ def main():
         print(f"[bench rank {rank}/{world}] local_rank {local_rank} -> cuda:{device_index} {pr.name} pci {pci} uuid {getattr(pr, 'uuid', 'n/a')} "
               f"backend {backend} visible_devices {n_dev}", file=sys.stderr, flush=True)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            torch.distributed.init_process_group(backend)
+        import datetime
+        try:
+            inject("init", rank)
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=300))
+            else:
+                torch.distributed.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+        except Exception as e:                 # noqa: BLE001 -- whatever the backend raises: say which rank and leave
+            rank_fail(rank, world, device_index, backend, "init_process_group", e)
+        try:                                   # the first collective creates the communicator (RCCL: ring / tree set-up over xGMI)
+            inject("first_all_reduce", rank)
+            probe = torch.ones(1, device="cuda")
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe[0]) != world:
+                raise RuntimeError(f"all_reduce(1) over {world} ranks returned {float(probe[0])}")
+        except Exception as e:                 # noqa: BLE001
+            rank_fail(rank, world, device_index, backend, "the first all_reduce", e)
 
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
@@ -420,9 +515,15 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    nerf = NeRF(seed=0)
-    nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
-                 white_background=True)
+    nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: every rank draws its OWN initial weights; compile() must mirror rank 0's
+    try:
+        inject("compile", rank)
+        nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
+                     white_background=True)
+    except Exception as e:                     # noqa: BLE001 -- N > 1: the weight broadcast of compile() is the second collective
+        if world > 1:
+            rank_fail(rank, world, device_index, backend, "NeRF.compile (weight broadcast)", e)
+        raise
     if args.skip_dead_tiles is not None:
         nerf._ctx.set_option("skip_dead_tiles", args.skip_dead_tiles)
     if args.deterministic is not None:
@@ -431,9 +532,15 @@ def main():
     n_rays = batch * wh * wh
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
 
-    for _ in range(args.warmup):
-        nerf.train_step(data, with_metrics=False)
-    sync(world)
+    try:
+        inject("warmup", rank)
+        for _ in range(args.warmup):
+            nerf.train_step(data, with_metrics=False)
+        sync(world)
+    except Exception as e:                     # noqa: BLE001 -- N > 1: the first gradient all-reduce (4.77 MB) runs in here
+        if world > 1:
+            rank_fail(rank, world, device_index, backend, "the warm-up steps (first gradient all-reduce)", e)
+        raise
     if world > 1:
         nerf._allreduce_events = []            # HIP events on the compute stream around the gradient all-reduce of every timed step
     t0 = time.perf_counter()
@@ -444,6 +551,8 @@ def main():
     elapsed = max_over_ranks(local_elapsed, world)
     value = world * n_rays * samples_per_ray * args.steps / elapsed
     comm = {}
+    if args.check_replicas:
+        comm["replica_drift"], comm["weight_checksum"] = replica_drift(nerf, world)
     if world > 1:
         ev, nerf._allreduce_events = nerf._allreduce_events, None
         ms = [a.elapsed_time(b_) for a, b_ in ev]
@@ -451,6 +560,10 @@ def main():
         # itself plus the wait for the slowest rank
         comm = {"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
                 "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4}
+    if world > 1:          # every rank: its share of the device (ranks sharing a GPU in a rehearsal must all fit; wgrad_group follows free memory)
+        free_b, total_b = torch.cuda.mem_get_info()
+        print(f"[bench rank {rank}/{world}] device memory free {free_b / 2**30:.1f} GiB of {total_b / 2**30:.1f} GiB; "
+              f"wgrad_group {int(nerf._ctx.get_option('wgrad_group'))} (budget {nerf._ctx.get_option('wgrad_group_gb'):g} GB)", file=sys.stderr, flush=True)
     # what the six logged metrics add to a step (SURVEY.md 8d reports them separately): the same loop with metrics on, still
     # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step), bracketed by the
     # plain loop before (the timed region above) and once more after it, so that clock drift does not pass for a difference
@@ -497,7 +610,7 @@ def main():
         else:
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flop / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flop / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None}
-        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom)
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, bool(nerf._ctx.get_option("skip_dead_tiles_active")))
         if roofline["traffic"] is not None and per_launch_samples != chunk_samples:
             # the committed PMC summary profiles one-chunk launches (tools/kbench.py); this launch covers several chunks of the same tiles
             roofline["traffic"] *= per_launch_samples / chunk_samples

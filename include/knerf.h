@@ -130,9 +130,12 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *                            (empty space with a closed ReLU gate on sigma, rays whose pixel error is exactly 0): such samples add
  *                            exactly nothing to any of the 48 gradient tensors (utils.py:36-45, mlp.py:40), so the result is the
  *                            same; applies to the default MLP shape when n_coarse and n_coarse + n_fine are multiples of 32.
+ *   "grad_diagnostics"  0/1  (default 0) knerf_train_batch counts the non-zero entries of the last chunk's gradient of each net
+ *                            (knerf_grad_diagnostics; the reference does this when run_eagerly, nerf.py:430-451); one launch of the
+ *                            coarse weight-gradient kernel per chunk while it is on.
  *   "wgrad_group_max"   1..64, "wgrad_group_gb" >= 0: chunks per coarse weight-gradient launch of knerf_train_batch and the memory
  *                            budget of the workspaces that takes (defaults 4 and 40 GB; 1 or 0 = one launch per chunk).
- *   "wgrad_cost0".."wgrad_cost8": relative cost per sample tile of the nine weight-gradient jobs (workgroups are dealt out in that
+ *   "wgrad_cost0".."wgrad_cost<n_layers>": relative cost per sample tile of the n_layers + 1 weight-gradient jobs (nine for the default shape) (workgroups are dealt out in that
  *                            proportion; tuning sweeps).
  * knerf_get_option also answers "skip_dead_tiles_active", "wgrad_group" (of the current workspaces) and "general_shape_path". */
 int knerf_set_option(knerf_ctx* ctx, const char* name, double value);
@@ -140,6 +143,14 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value);
 /* running totals since the last reset: 32-sample tiles the dgrad launches found live / all tiles they covered (skip_dead_tiles
  * on; both 0 otherwise).  Synchronises `stream`. */
 int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset);
+/* the same per net: live[2], total[2] = {coarse passes, fine passes} */
+int knerf_tile_stats_net(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset);
+/* The reference's eager-mode check "is the gradient zero" (nerf.py:430-451: tf.math.count_nonzero summed over the 24 gradient
+ * tensors of each net, taken from the LAST chunk of the step).  With option "grad_diagnostics" on, knerf_train_batch keeps the sum of
+ * the earlier chunks aside while the last chunk runs, counts on the device and publishes to pinned memory; this call reads
+ * out[0] = coarse count, out[1] = fine count, out[2] = number of steps published so far (wait != 0: synchronises `stream` first,
+ * i.e. the counts of the step just enqueued; wait == 0: of the newest step that has completed).  out: 3 values. */
+int knerf_grad_diagnostics(knerf_ctx* ctx, void* stream, int wait, int64_t* out);
 int knerf_step_count(const knerf_ctx* ctx);
 int knerf_set_step_count(knerf_ctx* ctx, int step);
 

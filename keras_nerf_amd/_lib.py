@@ -47,6 +47,8 @@ SIGNATURES = {
     "knerf_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "knerf_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "knerf_tile_stats": (C.c_int, [_P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
+    "knerf_tile_stats_net": (C.c_int, [_P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
+    "knerf_grad_diagnostics": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64)]),
     "knerf_render_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "knerf_ray_points": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "knerf_image_metrics": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

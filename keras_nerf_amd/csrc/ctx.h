@@ -91,6 +91,10 @@ struct knerf_ctx {
     int wgrad_group_max = 4;            // chunks per coarse weight-gradient launch of knerf_train_batch (1 = one launch per chunk)
     double wgrad_group_gb = 40.0;       // memory budget of those grouped workspaces
     int wgrad_cost[17] = {};            // workgroups per job ~ cost (build_wgrad_plan); filled from the job kinds at creation
+    bool grad_diag = false;             // zero-gradient diagnostics of the last chunk (nerf.py:430-451; NeRF.compile(run_eagerly=True))
+    float* diag_tmp = nullptr;          // the earlier chunks' accumulated gradient while the last chunk runs alone
+    unsigned long long* d_diag = nullptr;
+    long long* h_diag = nullptr;        // pinned: [0] coarse, [1] fine non-zero count of the last chunk's gradient, [2] steps published
     bool plan_dirty = false;
     int group_cache_rays = 0, group_cache_chunks = 0, group_cache = 0;   // wgrad_group_for memo (hipMemGetInfo is a driver call)
     // workspaces (grow-only).  Inference buffers (raw, w_c, t_f, img_tmp) follow the largest chunk seen by any call; the training
@@ -101,15 +105,17 @@ struct knerf_ctx {
     int ws_group = 1;                   // training workspaces hold this many chunks (knerf_train_batch: one wgrad launch per group)
     float *raw = nullptr, *draw = nullptr, *w_c = nullptr, *t_f = nullptr, *img_tmp = nullptr, *loss_tmp = nullptr;
     char *act = nullptr, *mask = nullptr, *dz = nullptr;
-    size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0;
+    size_t act_bytes = 0, mask_bytes = 0, dz_bytes = 0, raw_bytes = 0, draw_bytes = 0;
     // dead-tile skipping: per-tile flags of the training workspaces (composite.hip), the compacted list and its length, running
     // totals (live, all) of the tiles seen by the dgrad launches
     int *tile_flags = nullptr, *tile_list = nullptr, *tile_list_g = nullptr, *tile_count = nullptr;   // tile_list_g: the list of a group of coarse passes
     // tile_count: a ring of counters, one per list; the whole ring is zeroed by ONE memset when a call takes its first counter (and
     // again should a call need more than the ring holds: its earlier consumers are already enqueued, the stream orders the memset)
-    static constexpr int kTileCounters = 4096;
+    // Sized per call (ensure_tile_counters: a train_batch of C chunks in groups of G needs 2 C + ceil(C / G)), grow-only, so that a
+    // call never wraps while a group's counter is still being appended to.
+    int tile_counters = 4096;
     int tile_counter_next = 0;
-    long long* tile_stats = nullptr;
+    long long* tile_stats = nullptr;    // [net][4]: live, total (dgrad launches of that net's passes), two guard counters
     size_t ws_tiles = 0;
     // deterministic mode: per-workgroup weight-gradient slabs, per-workgroup loss terms, plan offsets of the jobs
     float *partial = nullptr, *loss_partial = nullptr;

@@ -64,7 +64,7 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
         case 1: *dev = ctx->mask; *bytes = ctx->mask_bytes; break;
         case 2: *dev = ctx->dz; *bytes = ctx->dz_bytes; break;
         case 3: *dev = ctx->raw; *bytes = ctx->raw_bytes; break;
-        case 4: *dev = ctx->draw; *bytes = ctx->raw_bytes; break;
+        case 4: *dev = ctx->draw; *bytes = ctx->draw_bytes; break;      // sized by the largest TRAINING chunk (raw follows renders too)
         case 5: *dev = ctx->t_f; *bytes = (size_t)ctx->ws_rays * (ctx->cfg.n_coarse + ctx->cfg.n_fine) * sizeof(float); break;
         case 6: *dev = ctx->w_c; *bytes = (size_t)ctx->ws_rays * ctx->cfg.n_coarse * sizeof(float); break;
         case 7:

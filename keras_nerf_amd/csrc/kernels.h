@@ -75,7 +75,7 @@ struct WgradArgs {
     int n_jobs;             // Shape::kWgradJobs = n_layers + 1
     int aux_base;           // Shape::kAuxBase = the shape's parameter count: destination indices >= it address `aux`
     int job_off[18];        // offset of each job's table inside dst (n_jobs + 1 entries)
-    float* partial;         // deterministic mode: [n_plan][kWgradPartialStride] per-workgroup sums instead of atomics (zero-filled by the caller), or null
+    float* partial;         // deterministic mode: [n_plan][ShapeInfo::partial_stride] per-workgroup sums instead of atomics (zero-filled by the caller), or null
     const int* live;        // dead-tile skipping: ascending list of live tiles (relative to act / dz / mask) and its length (device), or null
     const int* n_live;
     long long* stats;       // -DKNERF_LIST_GUARD builds only: [3] += list entries outside [0, n_tiles) seen (and clamped) by this kernel
@@ -86,8 +86,9 @@ struct WgradArgs {
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream);
 template <class S> hipError_t launch_wgrad_t(const WgradArgs& a, hipStream_t stream);
 // deterministic mode, after launch_wgrad: grad[dst] += sum over the job's workgroups (ascending split) of their partial slabs
-hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0 /* device: kWgradJobs+1 plan offsets */, hipStream_t stream);
-size_t wgrad_partial_floats(int n_plan);
+// stride = layout.h ShapeInfo::partial_stride (floats per workgroup slab: the shape's largest job table)
+hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0 /* device: kWgradJobs+1 plan offsets */, int stride, hipStream_t stream);
+size_t wgrad_partial_floats(int n_plan, int stride);
 
 // dead-tile skipping: flags[i] (1 = some sample of tile i has a non-zero dL/d(rgb, sigma), written by the compositing kernel) ->
 // ascending list of the live tile indices among i in [0, n) with (i % period) < real, and their count; stats[0] += count,
@@ -142,6 +143,10 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t stream);
 hipError_t launch_pack(const float* w, const int* table, unsigned short* out, size_t n, hipStream_t stream);
 hipError_t launch_gather_f32(const float* w, const int* table, float* out, size_t n, hipStream_t stream);
 hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t stream);
+// zero-gradient diagnostics (nerf.py:430-451): non-zero counts of g = [coarse | fine] (n floats each) -> counts (device [2]) -> host
+// (pinned: [0], [1] the counts, [2] += 1); add_into: dst[i] += src[i]
+hipError_t launch_grad_diagnostics(const float* g, int n, unsigned long long* counts, long long* host, hipStream_t stream);
+hipError_t launch_add_into(float* dst, const float* src, size_t n, hipStream_t stream);
 hipError_t launch_step_status(const int* flag, int* host_status, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream);
 hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyper& h, hipStream_t stream);
 // collapsed head (layout.h): w = one net's extended weight buffer (kExtParamCount floats).  compose writes the head matrix

@@ -143,6 +143,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
             HIPCHK(hipMalloc(&g.dz, zb));
             HIPCHK(hipMemsetAsync(g.dz, 0, zb, s));
             HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
+            ctx->draw_bytes = ctx->raw_bytes;
             free_dev(ctx->loss_partial);
             HIPCHK(hipMalloc(&ctx->loss_partial, ((size_t)R + 3) / 4 * sizeof(float)));
         }
@@ -175,7 +176,8 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         const size_t tiles = group == 1 ? tiles_for((long long)ns) : (size_t)group * tiles_for((long long)R * ctx->cfg.n_coarse) + tiles_for((long long)ns);
         ctx->act_bytes = saved_region_bytes(tiles, ctx->si.act_blocks); ctx->mask_bytes = saved_region_bytes(tiles, ctx->si.mask_blocks);
         ctx->dz_bytes = saved_region_bytes(tiles, ctx->si.dz_blocks);
-        HIPCHK(hipMalloc(&ctx->draw, ns * 4 * sizeof(float)));
+        ctx->draw_bytes = ns * 4 * sizeof(float);
+        HIPCHK(hipMalloc(&ctx->draw, ctx->draw_bytes));
         HIPCHK(hipMalloc(&ctx->act, ctx->act_bytes));
         HIPCHK(hipMalloc(&ctx->mask, ctx->mask_bytes));
         HIPCHK(hipMalloc(&ctx->dz, ctx->dz_bytes));
@@ -221,9 +223,22 @@ bool skipping(const knerf_ctx* ctx) {
 // A fresh (zero) counter for one list of live tiles.  The ring is zeroed by one memset when a call takes its first counter, and again
 // if a call runs through the whole ring (the consumers of its earlier counters are enqueued by then; the stream orders the memset).
 int next_tile_counter(knerf_ctx* ctx, hipStream_t s, int** count) {
-    if (ctx->tile_counter_next >= knerf_ctx::kTileCounters) ctx->tile_counter_next = 0;
-    if (ctx->tile_counter_next == 0) HIPCHK(hipMemsetAsync(ctx->tile_count, 0, knerf_ctx::kTileCounters * sizeof(int), s));
+    if (ctx->tile_counter_next >= ctx->tile_counters) ctx->tile_counter_next = 0;     // not reached by the entry points: they size the ring first
+    if (ctx->tile_counter_next == 0) HIPCHK(hipMemsetAsync(ctx->tile_count, 0, (size_t)ctx->tile_counters * sizeof(int), s));
     *count = ctx->tile_count + ctx->tile_counter_next++;
+    return KNERF_OK;
+}
+
+// The ring holds every counter one call takes (grow-only): a wrap inside a call would zero a group's counter that later coarse
+// passes still append to, and the grouped weight-gradient launch would then see a short list.
+int ensure_tile_counters(knerf_ctx* ctx, hipStream_t s, long long need) {
+    if (need <= ctx->tile_counters) return KNERF_OK;
+    HIPCHK(hipStreamSynchronize(s));               // consumers of the old ring's counters have finished
+    free_dev(ctx->tile_count);
+    long long n = ctx->tile_counters;
+    while (n < need) n *= 2;
+    HIPCHK(hipMalloc(&ctx->tile_count, (size_t)n * sizeof(int)));
+    ctx->tile_counters = (int)n; ctx->tile_counter_next = 0;
     return KNERF_OK;
 }
 
@@ -247,21 +262,21 @@ int launch_wgrad_tiles(knerf_ctx* ctx, hipStream_t s, int net, size_t tile0, siz
     wa.plan = ctx->tab.d_plan; wa.n_plan = ctx->tab.n_plan; wa.net = net == KNERF_COARSE ? 0 : 1;
     for (int j = 0; j <= ctx->si.n_jobs; ++j) wa.job_off[j] = ctx->tab.wgrad_off[j];
     if (live) { wa.live = live; wa.n_live = live_count; wa.by_range = ctx->deterministic ? 1 : 0; }
-    wa.stats = ctx->tile_stats;
+    wa.stats = ctx->tile_stats + 4 * (net == KNERF_COARSE ? 0 : 1);
     if (ctx->deterministic) {
         // per-workgroup slabs (zeroed: a workgroup without tiles writes nothing) + the ordered second pass
         if (!ctx->partial || ctx->partial_plan != ctx->tab.n_plan) {
             HIPCHK(hipStreamSynchronize(s));
             free_dev(ctx->partial);
-            HIPCHK(hipMalloc(&ctx->partial, wgrad_partial_floats(ctx->tab.n_plan) * sizeof(float)));
+            HIPCHK(hipMalloc(&ctx->partial, wgrad_partial_floats(ctx->tab.n_plan, ctx->si.partial_stride) * sizeof(float)));
             ctx->partial_plan = ctx->tab.n_plan;
         }
-        HIPCHK(hipMemsetAsync(ctx->partial, 0, wgrad_partial_floats(ctx->tab.n_plan) * sizeof(float), s));
+        HIPCHK(hipMemsetAsync(ctx->partial, 0, wgrad_partial_floats(ctx->tab.n_plan, ctx->si.partial_stride) * sizeof(float), s));
         wa.partial = ctx->partial;
     }
     ProfScope ps(ctx, s, net == KNERF_COARSE ? P_WGRAD_C : P_WGRAD_F);
     HIPCHK(launch_wgrad(wa, s));
-    if (ctx->deterministic) HIPCHK(launch_wgrad_reduce(wa, ctx->d_job_wg0, s));
+    if (ctx->deterministic) HIPCHK(launch_wgrad_reduce(wa, ctx->d_job_wg0, ctx->si.partial_stride, s));
     return KNERF_OK;
 }
 
@@ -317,7 +332,7 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + saved_tile_off(tile0, ctx->si.dz_blocks);
         ba.n_samples = fa.n_samples; ba.net = fa.net; ba.shape = ctx->shape;
-        if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; ba.stats = ctx->tile_stats; }
+        if (skip) { ba.live = ctx->tile_list; ba.n_live = live_count; ba.stats = ctx->tile_stats + 4 * fa.net; }
         { ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F); HIPCHK(launch_mlp_bwd(ba, s)); }
         if (wgrad_now) { if (int r = launch_wgrad_tiles(ctx, s, net, tile0, n_tiles, skip ? ctx->tile_list : nullptr, live_count)) return r; }
     }
@@ -448,10 +463,13 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     CREATECHK(up(ctx->tab.d_wgrad, ctx->tab.wgrad));
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (int r = upload_plan(ctx)) { std::string m_ = ctx->err; knerf_destroy(ctx); return fail(nullptr, r, m_); }
-    CREATECHK(hipMalloc(&ctx->tile_count, knerf_ctx::kTileCounters * sizeof(int)));
-    CREATECHK(hipMemset(ctx->tile_count, 0, knerf_ctx::kTileCounters * sizeof(int)));
-    CREATECHK(hipMalloc(&ctx->tile_stats, 4 * sizeof(long long)));       // [2], [3]: out-of-range list entries (diagnostic builds)
-    CREATECHK(hipMemset(ctx->tile_stats, 0, 4 * sizeof(long long)));
+    CREATECHK(hipMalloc(&ctx->tile_count, (size_t)ctx->tile_counters * sizeof(int)));
+    CREATECHK(hipMemset(ctx->tile_count, 0, (size_t)ctx->tile_counters * sizeof(int)));
+    CREATECHK(hipMalloc(&ctx->tile_stats, 8 * sizeof(long long)));       // per net: live, total, [2], [3]: out-of-range list entries (diagnostic builds)
+    CREATECHK(hipMemset(ctx->tile_stats, 0, 8 * sizeof(long long)));
+    CREATECHK(hipMalloc(&ctx->d_diag, 2 * sizeof(unsigned long long)));
+    CREATECHK(hipHostMalloc(&ctx->h_diag, 4 * sizeof(long long), hipHostMallocDefault));
+    ctx->h_diag[0] = ctx->h_diag[1] = ctx->h_diag[2] = ctx->h_diag[3] = 0;
     CREATECHK(hipMalloc(&ctx->grads, 2 * NP * sizeof(float)));
     CREATECHK(hipMemset(ctx->grads, 0, 2 * NP * sizeof(float)));
     CREATECHK(hipMalloc(&ctx->aux, 2 * (size_t)kAuxCount * sizeof(float)));
@@ -503,6 +521,8 @@ int knerf_destroy(knerf_ctx* ctx) {
     }
     free_dev(ctx->grads); free_dev(ctx->aux); free_dev(ctx->d_flag); free_dev(ctx->loss_tmp); free_dev(ctx->d_step); free_dev(ctx->d_lr_t);
     if (ctx->h_status) { (void)hipHostFree(ctx->h_status); ctx->h_status = nullptr; }
+    if (ctx->h_diag) { (void)hipHostFree(ctx->h_diag); ctx->h_diag = nullptr; }
+    free_dev(ctx->d_diag); free_dev(ctx->diag_tmp);
     free_dev(ctx->tab.d_fwd); free_dev(ctx->tab.d_bias); free_dev(ctx->tab.d_bwd); free_dev(ctx->tab.d_wgrad); free_dev(ctx->tab.d_plan);
     free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
@@ -661,7 +681,8 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
     ctx->tile_counter_next = 0;
-    int G = wgrad_group_for(ctx, ray_chunks, C);
+    // zero-gradient diagnostics count the LAST chunk's gradient (nerf.py:430-451): that chunk's weight-gradient launches must be its own
+    int G = ctx->grad_diag ? 1 : wgrad_group_for(ctx, ray_chunks, C);
     if (int r = ensure_ws(ctx, ray_chunks, true, s, G)) {
         if (G == 1) return r;
         G = 1;                                                      // the group did not fit: one chunk per wgrad launch
@@ -670,11 +691,21 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     }
     const size_t tc = tiles_for((long long)ray_chunks * Nc);
     const bool skip = skipping(ctx);
+    if (skip) { if (int r = ensure_tile_counters(ctx, s, 2LL * C + (C + G - 1) / G + 8)) return r; }   // two passes per chunk + one per group
     int* group_count = nullptr;
     for (int i = 0; i < C; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
         const int slot = i % G;
         const bool last = slot == G - 1 || i == C - 1;
+        if (ctx->grad_diag && i == C - 1 && C > 1) {
+            // set the sum of the earlier chunks aside (head sums expanded first: the expansion is linear), so that the accumulator
+            // holds the last chunk's gradient alone when it is counted
+            if (int r = expand_head_grads(ctx, s)) return r;
+            const size_t nb = 2 * (size_t)ctx->n_params * sizeof(float);
+            if (!ctx->diag_tmp) HIPCHK(hipMalloc(&ctx->diag_tmp, nb));
+            HIPCHK(hipMemcpyAsync(ctx->diag_tmp, ctx->grads, nb, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemsetAsync(ctx->grads, 0, nb, s));
+        }
         // default-mode skipping: the coarse passes of a group append their live tiles to the group's list under one counter
         if (G > 1 && skip && !ctx->deterministic && slot == 0) { if (int r = next_tile_counter(ctx, s, &group_count)) return r; }
         if (int r = train_chunk_impl(ctx, s, o + r0 * 3, d + r0 * 3, t + r0 * Nc, target + r0 * 3, u ? u + r0 * Nf : nullptr, seed,
@@ -692,7 +723,12 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
             if (int r = launch_wgrad_tiles(ctx, s, KNERF_COARSE, 0, (size_t)(slot + 1) * tc, live, live_count)) return r;
         }
     }
-    return expand_head_grads(ctx, s);
+    if (int r = expand_head_grads(ctx, s)) return r;
+    if (ctx->grad_diag) {
+        HIPCHK(launch_grad_diagnostics(ctx->grads, ctx->n_params, ctx->d_diag, ctx->h_diag, s));
+        if (C > 1) HIPCHK(launch_add_into(ctx->grads, ctx->diag_tmp, 2 * (size_t)ctx->n_params, s));
+    }
+    return KNERF_OK;
 }
 
 int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
@@ -745,6 +781,8 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
     if (n == "deterministic") {
         if (ctx->generic && value != 0) return fail(ctx, KNERF_ERR_INVALID, "deterministic: implemented for the fused (default-shape) kernels only");
         ctx->deterministic = value != 0;
+    } else if (n == "grad_diagnostics") {
+        ctx->grad_diag = value != 0;
     } else if (n == "skip_dead_tiles") {
         ctx->skip_dead = value != 0;               // ignored where it does not apply (general-shape path, sample counts not multiples of 32)
     } else if (n == "wgrad_group_max") {
@@ -767,6 +805,7 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     const std::string n(name);
     if (n == "deterministic") *value = ctx->deterministic;
     else if (n == "skip_dead_tiles") *value = ctx->skip_dead;
+    else if (n == "grad_diagnostics") *value = ctx->grad_diag;
     else if (n == "skip_dead_tiles_active") *value = skipping(ctx);
     else if (n == "wgrad_group_max") *value = ctx->wgrad_group_max;
     else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
@@ -778,15 +817,31 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     return KNERF_OK;
 }
 
-int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset) {
+int knerf_tile_stats_net(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset) {
     if (!ctx || !live || !total) return KNERF_ERR_INVALID;
-    long long h[4] = {0, 0, 0, 0};
+    long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(h, ctx->tile_stats, sizeof(h), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(ctx->tile_stats, 0, sizeof(h)));
-    *live = h[0]; *total = h[1];
-    if (h[2] || h[3])      // only a -DKNERF_LIST_GUARD build counts these
-        return fail(ctx, KNERF_ERR_HIP, "tile list held " + std::to_string(h[2]) + " (dgrad) / " + std::to_string(h[3]) + " (wgrad) entries outside their pass");
+    for (int n = 0; n < 2; ++n) { live[n] = h[4 * n]; total[n] = h[4 * n + 1]; }
+    if (h[2] || h[3] || h[6] || h[7])      // only a -DKNERF_LIST_GUARD build counts these
+        return fail(ctx, KNERF_ERR_HIP, "tile list held " + std::to_string(h[2] + h[6]) + " (dgrad) / " + std::to_string(h[3] + h[7]) + " (wgrad) entries outside their pass");
+    return KNERF_OK;
+}
+
+int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total, int reset) {
+    if (!ctx || !live || !total) return KNERF_ERR_INVALID;
+    int64_t l[2], t[2];
+    const int r = knerf_tile_stats_net(ctx, stream, l, t, reset);
+    *live = l[0] + l[1]; *total = t[0] + t[1];
+    return r;
+}
+
+int knerf_grad_diagnostics(knerf_ctx* ctx, void* stream, int wait, int64_t* out) {
+    if (!ctx || !out) return KNERF_ERR_INVALID;
+    if (wait) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    volatile long long* h = ctx->h_diag;
+    out[2] = h[2]; out[0] = h[0]; out[1] = h[1];
     return KNERF_OK;
 }
 

@@ -448,6 +448,20 @@ constexpr WgradJob wgrad_job(int j) {
     if (j == S::NL - 1 && !S::kSaveLastDz) return {4, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
     return {2, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
 }
+// floats of the largest job table of a shape ((32 n_it + 1) rows x 32 n_ot columns): the per-workgroup slab of the deterministic
+// mode (wgrad_body.h flush_acc, wgrad.hip wgrad_reduce_kernel).  82,176 = layer_5's (320 + 1) x 256 for the default shape; a width-256
+// shape with pos_emb_xyz >= 11 has 11 or 12 input tiles in its concat job (a fixed stride overflowed there).
+template <class S>
+constexpr int wgrad_partial_stride() {
+    int m = 0;
+    for (int j = 0; j < S::kWgradJobs; ++j) {
+        const WgradJob J = wgrad_job<S>(j);
+        const int e = (J.n_it * 32 + 1) * J.n_ot * 32;
+        if (e > m) m = e;
+    }
+    return m;
+}
+static_assert(wgrad_partial_stride<DefaultShape>() == (10 * 32 + 1) * 256, "the default shape's largest job table is layer_5's");
 // in_row of job jb for tile-row index tr (0..32*n_it-1) in *natural tr-read order*: the transposed read un-permutes
 // hidden tensors (row = feature), and presents enc/dir blocks in slot order (q = tr>>4, c16 = tr&15 ->
 // h = (c16>>2)&1, j = 4*(c16>>3) + (c16&3)).
@@ -487,6 +501,7 @@ struct ShapeInfo {
     int act_blocks, dz_blocks, mask_blocks;
     int n_jobs;
     int job_kind[17];
+    int partial_stride;             // wgrad_partial_stride<S>(): floats per workgroup slab of the deterministic mode
 };
 template <class S>
 inline ShapeInfo make_shape_info(int id) {
@@ -498,6 +513,7 @@ inline ShapeInfo make_shape_info(int id) {
     i.act_blocks = S::kActBlocks; i.dz_blocks = S::kDzBlocks; i.mask_blocks = S::kMaskBlocks;
     i.n_jobs = S::kWgradJobs;
     for (int j = 0; j < S::kWgradJobs; ++j) i.job_kind[j] = wgrad_job<S>(j).kind;
+    i.partial_stride = wgrad_partial_stride<S>();
     return i;
 }
 inline const ShapeInfo& shape_info(int id) {

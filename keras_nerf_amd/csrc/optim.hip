@@ -64,6 +64,40 @@ hipError_t launch_check_finite(const float* g, int n, int* flag, hipStream_t str
     return hipGetLastError();
 }
 
+// ---- zero-gradient diagnostics (reference nerf.py:430-451, eager mode): tf.math.count_nonzero summed over the 24 gradient tensors
+// of each net -- of the LAST chunk, as there (knerf_train_batch keeps the earlier chunks' sum aside while the last chunk runs).
+// g = [coarse | fine], n floats per net; counts: device [2], zeroed by the caller.
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const float* g, int n, unsigned long long* counts) {
+    const int net = blockIdx.y;
+    unsigned c = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += g[(size_t)net * n + i] != 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(counts + net, (unsigned long long)c);
+}
+// host (pinned): [0] coarse count, [1] fine count, [2] number of steps published so far
+__global__ void diag_publish_kernel(const unsigned long long* counts, long long* host) {
+    host[0] = (long long)counts[0]; host[1] = (long long)counts[1];
+    __threadfence_system();
+    host[2] = host[2] + 1;
+    __threadfence_system();
+}
+hipError_t launch_grad_diagnostics(const float* g, int n, unsigned long long* counts, long long* host, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(64, 2), dim3(256), 0, stream, g, n, counts);
+    hipLaunchKernelGGL(diag_publish_kernel, dim3(1), dim3(1), 0, stream, counts, host);
+    return hipGetLastError();
+}
+__global__ void add_into_kernel(float* dst, const float* src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+hipError_t launch_add_into(float* dst, const float* src, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+    return hipGetLastError();
+}
+
 // End of a step (one thread).  host_status (pinned, device-visible): [0] += 1 when this step's finite check failed, [1] = steps
 // processed.  step_state (device): [0] = optimizer steps APPLIED so far; lr_t = the bias-corrected learning rate of the NEXT
 // step, t = applied + 1 (Keras form, see the header) -- a skipped step leaves both as they were.

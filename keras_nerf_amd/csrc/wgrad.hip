@@ -92,12 +92,12 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t stream) {
 }
 
 // ---- deterministic mode: ordered second pass over the per-workgroup slabs (wgrad_body.h flush_acc / flush_bias) ------------------
-size_t wgrad_partial_floats(int n_plan) { return (size_t)n_plan * kWgradPartialStride; }
+size_t wgrad_partial_floats(int n_plan, int stride) { return (size_t)n_plan * (size_t)stride; }
 
 // one thread per element of a job's destination table; the job's workgroups are the plan entries [job_wg0[j], job_wg0[j+1])
 // in ascending split order.  Every destination index occurs once per launch (a weight belongs to one job), so the plain
 // read-modify-write of grad races with nothing.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, const int* job_wg0) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, const int* job_wg0, int stride) {
     const int job = blockIdx.y;
     const int n_elem = a.job_off[job + 1] - a.job_off[job];
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, const in
     const int d = a.dst[a.job_off[job] + e];
     if (d < 0) return;
     float s = 0.f;
-    for (int wg = job_wg0[job]; wg < job_wg0[job + 1]; ++wg) s += a.partial[(size_t)wg * kWgradPartialStride + e];
+    for (int wg = job_wg0[job]; wg < job_wg0[job + 1]; ++wg) s += a.partial[(size_t)wg * stride + e];
     float* p = d < a.aux_base ? a.grad + d : a.aux + (d - a.aux_base);
     *p += s;
 }
-hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0, hipStream_t stream) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kWgradPartialStride + 255) / 256, a.n_jobs), dim3(256), 0, stream, a, job_wg0);
+hipError_t launch_wgrad_reduce(const WgradArgs& a, const int* job_wg0, int stride, hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((stride + 255) / 256, a.n_jobs), dim3(256), 0, stream, a, job_wg0, stride);
     return hipGetLastError();
 }
 #endif

@@ -73,10 +73,10 @@ struct WgradPlan {          // one entry per workgroup, built on the host (knerf
 // Deterministic mode (a.partial != null, knerf_set_option "deterministic"): no atomics -- the workgroup's sums go to its own slab of
 // `partial` with plain stores (element index = the one the destination table is read at) and wgrad_reduce_kernel (wgrad.hip) adds
 // the slabs of a job in split order, so the gradient is bit-reproducible from run to run.
-constexpr int kWgradPartialStride = (10 * 32 + 1) * 256;     // floats per workgroup: the largest job table (layer_5)
-__device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, int row0, int ncols, int col, const f32x16& acc) {
+// `stride` = layout.h wgrad_partial_stride<S>(): floats per workgroup slab = the shape's largest job table (82,176 for the default shape)
+__device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, int row0, int ncols, int col, const f32x16& acc, int stride) {
     if (a.partial) {
-        float* p = a.partial + (size_t)blockIdx.x * kWgradPartialStride;
+        float* p = a.partial + (size_t)blockIdx.x * stride;
 #pragma unroll
         for (int i = 0; i < 16; ++i) p[(row0 + (i & 3) + 8 * (i >> 2)) * ncols + col] = acc[i];
         return;
@@ -95,9 +95,9 @@ __device__ __forceinline__ void flush_acc(const WgradArgs& a, const int* dst, in
 }
 
 // bias row (column sums of dz): element `idx` of the job's table, held by the half-0 lanes
-__device__ __forceinline__ void flush_bias(const WgradArgs& a, const int* dst, int idx, int hh, float v) {
+__device__ __forceinline__ void flush_bias(const WgradArgs& a, const int* dst, int idx, int hh, float v, int stride) {
     if (a.partial) {
-        if (hh == 0) a.partial[(size_t)blockIdx.x * kWgradPartialStride + idx] = v;
+        if (hh == 0) a.partial[(size_t)blockIdx.x * stride + idx] = v;
         return;
     }
     const int d = dst[idx];
@@ -332,9 +332,9 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
     for (int n = 0; n < NACC; ++n) {
         const int it = wi + n * WI;
         if (it < NI) {
-            flush_acc(a, dst, 32 * it + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
+            flush_acc(a, dst, 32 * it + 4 * hh, NCOLS, 32 * wo + c, acc[n], wgrad_partial_stride<S>());
         } else if (it == NI) {
-            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);   // bias row: every row of the ones-tile holds the column sums
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0], wgrad_partial_stride<S>());   // bias row: every row of the ones-tile holds the column sums
         }
     }
 }
@@ -465,9 +465,9 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (n < NI) {
-            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
+            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n], wgrad_partial_stride<S>());
         } else {
-            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0], wgrad_partial_stride<S>());
         }
     }
 }
@@ -598,9 +598,9 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (n < NI) {
-            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n]);
+            flush_acc(a, dst, 32 * n + 4 * hh, NCOLS, 32 * wo + c, acc[n], wgrad_partial_stride<S>());
         } else {
-            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0]);
+            flush_bias(a, dst, NI * 32 * NCOLS + 32 * wo + c, hh, acc[n][0], wgrad_partial_stride<S>());
         }
     }
 }

@@ -86,7 +86,7 @@ class NeRFTrainMonitor:
         self.coarse_log_list_batch.append(logs["coarse_loss"]); self.fine_log_list_batch.append(logs["fine_loss"])
         if not parallel.is_main():
             return
-        coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
+        coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points), outputs=("image", "depth"))
         curves = [(self.coarse_log_list_batch, "blue", "solid", "Coarse Train Loss"), (self.fine_log_list_batch, "orange", "solid", "Fine Train Loss")]
         for i in range(self.batch_size):
             self._panel(os.path.join(self.log_dir, f"debug_{i}_{batch}.png"), coarse, fine, self.images, i, curves, f"Loss Batch Plot: {batch}")
@@ -105,7 +105,7 @@ class NeRFTrainMonitor:
             self.coarse_log_list_batch, self.fine_log_list_batch = [], []
 
     def _write_epoch(self, epoch, logs):
-        coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points))
+        coarse, fine = self.model.predict_and_render_images((self.ray_origin, self.ray_direction, self.coarse_points), outputs=("image", "depth"))
         curves = [(self.coarse_log_list, "blue", "solid", "Coarse Train Loss"), (self.val_coarse_log_list, "blue", "dashed", "Coarse Val Loss"),
                   (self.fine_log_list, "orange", "solid", "Fine Train Loss"), (self.val_fine_log_list, "orange", "dashed", "Fine Val Loss")]
         for i in range(self.batch_size):
@@ -116,7 +116,7 @@ class NeRFTrainMonitor:
             self.dataset_iterator = iter(self._sample_view)
             images, rays = self.dataset_iterator.get_next()
         o, d, t = [r[:self.batch_size] for r in rays]
-        coarse, fine = self.model.predict_and_render_images((o, d, t))
+        coarse, fine = self.model.predict_and_render_images((o, d, t), outputs=("image", "depth"))     # the panels show images and depths only
         for i in range(self.batch_size):
             self._panel(os.path.join(self.log_dir, f"test_sample_{i}_{epoch}.png"), coarse, fine, images, i)
         with open(self.log_csv, "a") as f:                     # callback.py:211-218

@@ -131,11 +131,11 @@ class NeRF:
 
     # ------------------------------------------------------------------ compile (nerf.py:78-173)
     def compile(self, optimizer="adam", loss="mse", batch_size=1, image_height=128, image_width=128, ray_chunks=2048,
-                white_background=False, is_training=True, all_reduce="sum", deterministic=False, skip_dead_tiles=True, **kwargs):
+                white_background=False, is_training=True, all_reduce="sum", deterministic=False, skip_dead_tiles=None, **kwargs):
         """nerf.py:78-173.  Extensions (keyword-only in spirit; the reference's callers never pass them):
         all_reduce 'sum' | 'mean' (data parallel), deterministic (bit-reproducible gradient sums, slower),
-        skip_dead_tiles (default on: the backward skips 32-sample tiles whose dL/d(rgb, sigma) is exactly zero -- same gradients,
-        less work once the scene has empty space)."""
+        skip_dead_tiles (None = the library default, on, unless KNERF_SKIP_DEAD_TILES says otherwise: the backward skips 32-sample
+        tiles whose dL/d(rgb, sigma) is exactly zero -- same gradients, less work once the scene has empty space)."""
         logging.info("Compiling NeRF model")
         if not _is_mse(loss):
             raise ValueError("the fused HIP path implements the reference's mean-squared-error loss only")
@@ -162,7 +162,10 @@ class NeRF:
         opts = {}
         if deterministic:
             opts["deterministic"] = 1
-        opts["skip_dead_tiles"] = int(bool(skip_dead_tiles))
+        if self.run_eagerly:                             # nerf.py:430-451: the zero-gradient check exists in eager mode only
+            opts["grad_diagnostics"] = 1
+        if skip_dead_tiles is not None:                  # only an explicit argument overrides KNERF_SKIP_DEAD_TILES (runtime.py)
+            opts["skip_dead_tiles"] = int(bool(skip_dead_tiles))
         self._ctx = KnerfContext(self.n_coarse, self.n_fine, self.pos_emb_xyz, self.pos_emb_dir, self.n_layers, self.dense_units,
                                  self.skip_layer, white_background, self.oob, h["lr"], h["beta1"], h["beta2"], h["epsilon"],
                                  options=opts)
@@ -177,7 +180,31 @@ class NeRF:
             self._ctx.refresh_weights()
         self._loss_acc = torch.zeros(2, device=self.device)
         self._initialize_metrics()
+        self._diag_seen = 0
         self._compiled = True
+
+    def _zero_gradient_diagnostics(self, wait: bool):
+        """nerf.py:430-451 (eager mode only): the non-zero counts of the LAST chunk's coarse and fine gradients, counted on the
+        device (knerf_grad_diagnostics), with the reference's three messages.  wait=False (the asynchronous `fit` path) reports the
+        newest step that has completed, once.  One further message the reference cannot give: every 32-sample tile of a net's
+        passes was exactly dead in the backward (knerf_tile_stats_net) -- the sigma == 0 collapse in which the ReLU on sigma is
+        closed everywhere and no gradient can ever re-open it."""
+        c, f, seq = self._ctx.grad_diagnostics(wait=wait)
+        if seq == self._diag_seen:
+            return None
+        self._diag_seen = seq
+        if c == 0 and f == 0:
+            logging.error('Both Coarse and Fine Gradient are zero')
+        elif c == 0:
+            logging.warning('Coarse Gradient is zero')
+        elif f == 0:
+            logging.warning('Fine Gradient is zero')
+        if wait and self._ctx.get_option("skip_dead_tiles_active"):
+            for name, (live, total) in zip(("coarse", "fine"), self._ctx.tile_stats_net(reset=True)):
+                if total > 0 and live == 0:
+                    logging.warning(f'Every sample tile of the {name} passes is dead (no sample passes a gradient): sigma has collapsed to zero '
+                                    f'or the pixel error is exactly zero everywhere')
+        return c, f
 
     def _build_model(self):                              # nerf.py:116-136
         self.coarse._bind(self._ctx, COARSE)
@@ -230,21 +257,30 @@ class NeRF:
         return ({"image": out["c_image"], "depth": out["c_depth"], "weights": out["c_weights"]},
                 {"image": out["f_image"], "depth": out["f_depth"], "weights": out["f_weights"]})
 
-    def predict_and_render_images(self, rays, u=None):
-        """nerf.py:229-304: returns (coarse_results, fine_results), each {image [B,H,W,3], depth [B,H,W], weights [B,H,W,S]}"""
+    def predict_and_render_images(self, rays, u=None, outputs=None):
+        """nerf.py:229-304: returns (coarse_results, fine_results), each {image [B,H,W,3], depth [B,H,W], weights [B,H,W,S]}.
+        outputs (extension): the keys wanted, e.g. ("image", "depth") -- what inference.py:108-114 reads -- or ("image",) (test_step);
+        the others are neither allocated nor written (knerf_render_batch takes NULL for them: at 256 x 256 the two `weights` arrays
+        are 67 MB per frame).  Default: the reference's full dictionaries."""
+        keys = ("image", "depth", "weights") if outputs is None else tuple(outputs)
+        if "image" not in keys or any(k not in ("image", "depth", "weights") for k in keys):
+            raise ValueError("outputs must contain 'image' and may contain 'depth' and 'weights'")
         o, d, t = self._flat_rays(rays)
         N, R, Nc, Na = self.num_rays, self.ray_chunks, self.n_coarse, self.n_coarse + self.n_fine
         e = lambda *s: torch.empty(s, device=self.device)
-        buf = dict(c_image=e(N, 3), c_depth=e(N), c_weights=e(N, Nc), f_image=e(N, 3), f_depth=e(N), f_weights=e(N, Na))
+        buf = dict(c_image=e(N, 3), f_image=e(N, 3))
+        if "depth" in keys:
+            buf.update(c_depth=e(N), f_depth=e(N))
+        if "weights" in keys:
+            buf.update(c_weights=e(N, Nc), f_weights=e(N, Na))
         uf = None if u is None else self._ctx.f32(u).reshape(N, self.n_fine)
         seed = self._next_seed()
         # the chunk loop of nerf.py:236-288 runs inside the library: one host call per batch of images
         self._ctx.render_batch(o, d, t, uf, seed, R, out=buf)
         B, H, W = self.batch_size, self.image_height, self.image_width
-        coarse = {"image": buf["c_image"].reshape(B, H, W, 3), "depth": buf["c_depth"].reshape(B, H, W),
-                  "weights": buf["c_weights"].reshape(B, H, W, Nc)}
-        fine = {"image": buf["f_image"].reshape(B, H, W, 3), "depth": buf["f_depth"].reshape(B, H, W),
-                "weights": buf["f_weights"].reshape(B, H, W, Na)}
+        shape = {"image": (B, H, W, 3), "depth": (B, H, W)}
+        coarse = {k: buf["c_" + k].reshape(shape.get(k, (B, H, W, Nc))) for k in keys}
+        fine = {k: buf["f_" + k].reshape(shape.get(k, (B, H, W, Na))) for k in keys}
         return coarse, fine
 
     call = predict_and_render_images          # the reference defines no call(); Keras users expect one
@@ -287,6 +323,8 @@ class NeRF:
                 e1.record(); timing.append((e0, e1))
         # finite check (nerf.py:381-382), 2x Adam, accumulators zeroed (nerf.py:464-471): enqueued, nothing waits for the GPU
         self._ctx.apply_adam(check=False)
+        if self.run_eagerly:
+            self._zero_gradient_diagnostics(wait=bool(sync))
         if not with_metrics:
             # fast path (no host synchronisation per step): a step skipped for a non-finite gradient is reported by the
             # first later call that finds it completed
@@ -302,7 +340,7 @@ class NeRF:
         """nerf.py:475-497"""
         images, rays = inputs
         images = self._ctx.f32(images)[..., :3].contiguous()
-        coarse, fine = self.predict_and_render_images(rays, u)
+        coarse, fine = self.predict_and_render_images(rays, u, outputs=("image",))     # nerf.py:489-497 reads the two images only
         # whole-image MSE (nerf.py:484-487) from the metrics kernel's squared-difference sums (losses=None)
         self._metric_state.update(images, coarse["image"], fine["image"], None)
         return self._metric_state.snapshot()

@@ -38,7 +38,7 @@ class KnerfContext:
                  force_generic=None, options=None):
         """force_generic: run the default MLP shape through the general-shape kernels as well (tests).  options: {name: value}
         for knerf_set_option.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
-        KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c8"), KNERF_DETERMINISTIC and
+        KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
         KNERF_SKIP_DEAD_TILES into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
         if not torch.cuda.is_available():
@@ -67,12 +67,19 @@ class KnerfContext:
                           ("KNERF_DETERMINISTIC", "deterministic"), ("KNERF_SKIP_DEAD_TILES", "skip_dead_tiles")):
             if env.get(key):
                 opts[name] = float(env[key])
-        if env.get("KNERF_WGRAD_COSTS"):
-            for j, v in enumerate(env["KNERF_WGRAD_COSTS"].split(",")[:17]):
-                opts[f"wgrad_cost{j}"] = float(v)
+        env_costs = {}
+        if env.get("KNERF_WGRAD_COSTS"):          # one entry per weight-gradient job (n_layers + 1 of them); surplus entries are ignored
+            for j, v in enumerate(env["KNERF_WGRAD_COSTS"].split(",")[:n_layers + 1]):
+                env_costs[f"wgrad_cost{j}"] = float(v)
         opts.update(options or {})
         for k, v in opts.items():
             self.set_option(k, v)
+        for k, v in env_costs.items():
+            if k not in opts:
+                try:
+                    self.set_option(k, v)
+                except ValueError:           # the context has fewer jobs than n_layers + 1 (general-shape path)
+                    break
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -99,6 +106,19 @@ class KnerfContext:
         a, b = C.c_int64(), C.c_int64()
         self._check(self.lib.knerf_tile_stats(self._ctx, self._stream(), C.byref(a), C.byref(b), int(reset)))
         return a.value, b.value
+
+    def tile_stats_net(self, reset: bool = True):
+        """((live, total) of the coarse passes, (live, total) of the fine passes) since the last reset"""
+        a, b = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        self._check(self.lib.knerf_tile_stats_net(self._ctx, self._stream(), a, b, int(reset)))
+        return (a[0], b[0]), (a[1], b[1])
+
+    def grad_diagnostics(self, wait: bool = True):
+        """(non-zero entries of the last chunk's coarse gradient, of its fine gradient, steps published so far): the reference's
+        tf.math.count_nonzero check (nerf.py:430-451); needs the option grad_diagnostics"""
+        out = (C.c_int64 * 3)()
+        self._check(self.lib.knerf_grad_diagnostics(self._ctx, self._stream(), int(wait), out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     # ---- helpers
     def _check(self, rc: int):

@@ -42,11 +42,23 @@ def main():
         S = cfg.n_coarse + cfg.n_fine
         t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:P["N"] * S].reshape(P["N"], S).copy()
         g = ctx.grads_view().cpu().numpy(); n = g.size // 2
+        # deterministic mode on the same chunk (per-workgroup slabs of ShapeInfo::partial_stride floats + ordered second pass): the
+        # slab must hold the shape's LARGEST job table -- 11 or 12 input tiles in the concat job at pos_emb_xyz >= 11
+        ctx.zero_grads(); ctx.set_option("deterministic", 1)
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0)
+        gd = ctx.grads_view().cpu().numpy()
+        ctx.zero_grads(); ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0)
+        gd2 = ctx.grads_view().cpu().numpy()
+        ctx.set_option("deterministic", 0)
+        det_err = float(np.abs(gd - g).max() / np.abs(g).max())
         rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
         rf, lf, gf = O.chunk_loss_and_grads(P["fp"], o, d, t_fine, img, cfg, True, emulate_bf16=O.FUSED)
         print(json.dumps({"shape": [nl, sk, units, lx, ld], "info": info, "general_shape_path": ctx.get_option("general_shape_path"),
                           "coarse_worst": float(per_tensor_err(g[:n], O.flatten_params(gc), cfg)[0]),
                           "fine_worst": float(per_tensor_err(g[n:], O.flatten_params(gf), cfg)[0]),
+                          "det_vs_atomic": det_err, "det_repeatable": bool(np.array_equal(gd, gd2)),
+                          "det_coarse_worst": float(per_tensor_err(gd[:n], O.flatten_params(gc), cfg)[0]),
+                          "det_fine_worst": float(per_tensor_err(gd[n:], O.flatten_params(gf), cfg)[0]),
                           "loss_err": max(abs(float(loss[0]) - float(lc)), abs(float(loss[1]) - float(lf))),
                           "img_err": float(max(np.abs(ci.cpu().numpy() - rc["image"]).max(), np.abs(fi.cpu().numpy() - rf["image"]).max()))}), flush=True)
         ctx.close()

@@ -94,3 +94,46 @@ def test_shard_batch_divisibility():
     with pytest.raises(ValueError):
         parallel.shard_batch(torch.zeros(3, 2), 0, 2)
     assert parallel.shard_batch(torch.arange(8).reshape(4, 2), 1, 2).tolist() == [[4, 5], [6, 7]]
+
+
+def _worker8(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from keras_nerf_amd import parallel
+    from keras_nerf_amd.data.loader import replica_batches, shuffled_order
+    w = [torch.full((1000,), float(rank + 1)), torch.full((7,), -float(rank))]          # every rank starts with its own "weights"
+    parallel.broadcast_weights(w)
+    g = torch.arange(2 * 595844, dtype=torch.float32) % 17 * (rank + 1)                  # the real operand size: 4,766,752 bytes
+    parallel.all_reduce_gradients(g, "sum")
+    logs = parallel.reduce_logs({"fine_loss": float(rank), "coarse_loss": 2.0})
+    # the shared-seed batch plan (data/loader.py): all ranks draw the same order, each keeps its slice of every global batch
+    order = shuffled_order(100, 1 * world, np.random.default_rng(7))
+    mine = replica_batches(order, 1, rank, world)
+    # the bench's replica-drift check on CPU tensors: exact integer checksum, MAX - MIN over the ranks
+    chk = (w[0].view(torch.int32).to(torch.int64)).sum().reshape(1)
+    hi, lo = chk.clone(), chk.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    np.savez(out.format(rank=rank), w0=w[0].numpy(), w1=w[1].numpy(), g=g[:64].numpy(), gsum=float(g.double().sum()), drift=int(hi[0]) - int(lo[0]),
+             mine=np.asarray(mine).reshape(-1), **logs)
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_cfg4_shape_of_the_glue():
+    """cfg4 is 8 GPUs; the largest job a one-GPU box can host on its card is 4-5 ranks (tests/test_gpu_api.py), so the EIGHT-rank
+    case of the glue runs here on the CPU: mirrored start from rank 0, one SUM all-reduce of the real 4.77 MB operand, replica
+    means of the logs, zero drift of the weight checksum, and the loader's batch plan (train.py:84-93: global batch = batch_size x
+    replicas, replica r takes elements [r b, (r+1) b) of each): 12 global batches of 8 out of 100 views, slices disjoint."""
+    port = _free_port()
+    import tempfile
+    d = tempfile.mkdtemp()
+    out = os.path.join(d, "rank{rank}.npz")
+    mp.spawn(_worker8, args=(8, port, out), nprocs=8, join=True)
+    rs = [np.load(out.format(rank=r)) for r in range(8)]
+    seen = []
+    for r, z in enumerate(rs):
+        assert (z["w0"] == 1.0).all() and (z["w1"] == 0.0).all() and int(z["drift"]) == 0
+        np.testing.assert_array_equal(z["g"], (np.arange(64) % 17 * 36).astype(np.float32))                  # 1 + 2 + ... + 8 = 36
+        assert float(z["fine_loss"]) == pytest.approx(3.5) and float(z["coarse_loss"]) == pytest.approx(2.0)
+        assert z["mine"].size == 12
+        seen += z["mine"].tolist()
+    assert len(set(seen)) == 96 and rs[0]["gsum"] == rs[7]["gsum"]

@@ -333,6 +333,143 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal():
         assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr
 
 
+def test_zero_gradient_diagnostics_eager_mode(caplog):
+    """nerf.py:430-451: with run_eagerly the reference counts the non-zero entries of the LAST chunk's coarse and fine gradients and
+    logs 'Both Coarse and Fine Gradient are zero' (error) / 'Coarse Gradient is zero' / 'Fine Gradient is zero' (warnings).  Here the
+    counts are taken on the device (knerf_grad_diagnostics).  White on white: sigma's bias far below zero closes the ReLU on sigma
+    everywhere, the image is the exact white background, the target is exact white, so every gradient of that net is exactly
+    zero -- and every 32-sample tile of its passes is dead, which is reported too."""
+    import logging
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    P = make_problem(n_images=1, wh=16, weight_scale=1.0, bias_std=0.0)
+    cfg = P["cfg"]
+    white = np.ones((1, 16, 16, 3), np.float32)
+
+    def closed(params):              # the same weights with sigma's bias at -100: sigma == 0 for every sample
+        q = [p.copy() for p in params]
+        names = [n for n, _, _ in O.layer_shapes(cfg)]
+        q[2 * names.index("sigma") + 1][:] = -100.0
+        return q
+    cases = [(closed(P["cp"]), closed(P["fp"]), "Both Coarse and Fine Gradient are zero", logging.ERROR, (0, 0)),
+             (closed(P["cp"]), P["fp"], "Coarse Gradient is zero", logging.WARNING, (0, 1)),
+             (P["cp"], closed(P["fp"]), "Fine Gradient is zero", logging.WARNING, (1, 0)),
+             (P["cp"], P["fp"], None, None, (1, 1))]
+    for cp, fp, msg, level, nz in cases:
+        nerf = NeRF()
+        nerf.compile("adam", "mse", batch_size=1, image_height=16, image_width=16, ray_chunks=64, white_background=True, run_eagerly=True)
+        assert nerf._ctx.get_option("grad_diagnostics") == 1.0
+        nerf.coarse.set_flat_weights(O.flatten_params(cp)); nerf.fine.set_flat_weights(O.flatten_params(fp))
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            nerf.train_step((white, (P["o"], P["d"], P["t"])), u=P["u"])
+        c, f, seq = nerf._ctx.grad_diagnostics(wait=True)
+        assert seq == 1 and (c > 0) == bool(nz[0]) and (f > 0) == bool(nz[1]), (c, f, seq)
+        texts = [(r.levelno, r.getMessage()) for r in caplog.records]
+        if msg:
+            assert (level, msg) in texts, texts
+        else:
+            assert not [t for t in texts if "Gradient" in t[1]], texts
+        for k, name in enumerate(("coarse", "fine")):
+            dead = any(f"Every sample tile of the {name} passes is dead" in t[1] for t in texts)
+            assert dead == (nz[k] == 0), (name, texts)
+        # the count is of the LAST chunk only (4 chunks of 64 rays), and the accumulated gradient is still the sum of all four: a
+        # second context without the diagnostics gives the same step
+        if msg is None:
+            ref = NeRF()
+            ref.compile("adam", "mse", batch_size=1, image_height=16, image_width=16, ray_chunks=64, white_background=True)
+            ref.coarse.set_flat_weights(O.flatten_params(cp)); ref.fine.set_flat_weights(O.flatten_params(fp))
+            ref.train_step((white, (P["o"], P["d"], P["t"])), u=P["u"])
+            for a, b in ((nerf.coarse, ref.coarse), (nerf.fine, ref.fine)):
+                np.testing.assert_allclose(a.get_flat_weights(), b.get_flat_weights(), atol=2e-6)
+            assert 0 < c <= 595844 and 0 < f <= 595844
+    # graph mode (the default): no diagnostics, no messages, no extra launches
+    nerf = NeRF()
+    nerf.compile("adam", "mse", batch_size=1, image_height=16, image_width=16, ray_chunks=64, white_background=True)
+    assert nerf._ctx.get_option("grad_diagnostics") == 0.0
+
+
+def test_render_outputs_selection_gives_the_same_pixels():
+    """predict_and_render_images(outputs=("image", "depth")) -- what inference.py:108-114, test_step and the monitor read -- leaves the
+    four weight arrays unallocated and unwritten and returns the same images and depths, bit for bit, as the reference's full
+    dictionaries; a frame read back through pinned memory on a side stream equals the blocking `.cpu()` of the same frame."""
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+    nerf = NeRF()
+    nerf.compile("adam", "mse", batch_size=1, image_height=16, image_width=16, ray_chunks=64, white_background=True, is_training=False)
+    nerf.coarse.set_flat_weights(O.flatten_params(P["cp"])); nerf.fine.set_flat_weights(O.flatten_params(P["fp"]))
+    rays = (P["o"], P["d"], P["t"])
+    cf, ff = nerf.predict_and_render_images(rays, u=P["u"])
+    assert sorted(cf) == sorted(ff) == ["depth", "image", "weights"] and ff["weights"].shape == (1, 16, 16, 192)
+    c2, f2 = nerf.predict_and_render_images(rays, u=P["u"], outputs=("image", "depth"))
+    assert sorted(c2) == sorted(f2) == ["depth", "image"]
+    c1, f1 = nerf.predict_and_render_images(rays, u=P["u"], outputs=("image",))
+    assert list(c1) == list(f1) == ["image"]
+    for k in ("image", "depth"):
+        assert torch.equal(cf[k], c2[k]) and torch.equal(ff[k], f2[k])
+    assert torch.equal(ff["image"], f1["image"]) and torch.equal(cf["image"], c1["image"])
+    with pytest.raises(ValueError):
+        nerf.predict_and_render_images(rays, outputs=("depth",))
+    # pipelined read-back (bench.py bench_render): pinned buffer, side stream, event
+    side = torch.cuda.Stream(); done = torch.cuda.Event(); ready = torch.cuda.Event()
+    host = torch.empty((1, 16, 16, 3), pin_memory=True)
+    ready.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        host.copy_(f2["image"], non_blocking=True); done.record(side)
+    done.synchronize()
+    assert torch.equal(host, ff["image"].cpu())
+
+
+def _bench(args, env_extra, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNERF_DIST_BACKEND", "MASTER_ADDR", "MASTER_PORT",
+                                                             "HSA_ENABLE_IPC_MODE_LEGACY")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                          env=dict(base, **env_extra))
+
+
+def test_cfg4_rehearsal_four_ranks_on_one_gpu_replicas_stay_identical():
+    """cfg4 (BASELINE configs[3]: one 128 x 128 image per GPU, 8 GPUs) as far as a one-GPU box allows: FOUR ranks share this device
+    over gloo (the pool admits at most six GPU processes of one user at a time, and this test process is one of them; eight ranks
+    are rehearsed on the CPU by tests/test_dp_gloo.py).  Every rank draws its OWN initial weights (seed 100 + rank), so the line's
+    `replica_drift` == 0 proves the broadcast of NeRF.compile, the SUM all-reduce of every step and identical Adam updates on all
+    ranks (train.py:75-93, 130-157); rank 0's line carries the collective's time and size; every rank says which device it sits on
+    and how much of it is free; the launch environment (MASTER_ADDR, HSA_ENABLE_IPC_MODE_LEGACY) is NOT provided by the caller."""
+    import json
+    r = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline"], {"KNERF_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["dist_backend"] == "gloo" and line["config"]["parallelism"] == "dp4" and line["config"]["global_batch_images"] == 4
+    assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
+    assert line["grad_bytes"] == 2 * 595844 * 4 and line["allreduce_ms_per_step"] > 0
+    assert line["value"] > 0 and line["scaling"] == "weak"
+    for k in range(4):
+        assert f"[bench rank {k}/4] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
+        assert f"[bench rank {k}/4] device memory free" in r.stderr
+    # the same through NeRF.fit (loader slices of the global batch, metrics, monitor on rank 0, barrier at epoch end)
+    r = _bench(["--gpus", "4", "--mode", "fit", "--config", "cfg4", "--epochs", "1"], {"KNERF_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["replica_drift"] == 0.0 and line["steps"] == 25 and line["value"] > 0      # 100 views / 4 ranks
+
+
+def test_a_failing_rank_ends_the_run_at_once_with_its_name():
+    """The first RCCL run with N > 1 happens on the driver's box with nobody to debug it: a rank that cannot join (or whose first
+    collective fails) must say which rank / device / stage and end the whole job with a non-zero code within seconds, not leave
+    the others in a collective until its time-out.  Failure injected at each guarded stage of rank 1 of 2 (gloo)."""
+    import time
+    for stage in ("init", "warmup"):               # the first and the last guarded stage (bench.py also guards first_all_reduce and compile)
+        t0 = time.time()
+        r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline", "--no-profile"],
+                   {"KNERF_DIST_BACKEND": "gloo", "KNERF_BENCH_INJECT_FAILURE": f"1:{stage}"}, timeout=400)
+        assert r.returncode != 0, stage
+        assert "[bench rank 1/2] FAILED in" in r.stderr and "injected failure" in r.stderr, (stage, r.stderr[-2000:])
+        assert not [x for x in r.stdout.splitlines() if x.startswith("{")], stage          # no JSON line from a broken job
+        assert time.time() - t0 < 240, (stage, time.time() - t0)
+
+
 def test_loader_resident_and_staged_paths_yield_the_same_batches(tmp_path):
     """DatasetLoader feeds the GPU from a device-resident copy of the dataset, or -- when it exceeds `device_cache_gb` -- through two
     pinned staging buffers on a side stream (data/loader.py).  Both must deliver the batches of the reference's pipeline

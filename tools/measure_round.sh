@@ -14,7 +14,8 @@ for st in $STAGES; do
     bench) timeout -k 10 300 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err || fault bench; python -c "import json; l=json.load(open('$OUT/bench_cfg2.json')); print('cfg2', l['ms_per_step'], l['value'], l['roofline']['frac'], l['metrics_ms_per_step'], l['dead_tile_frac'])" ;;
     prof)  rm -rf $OUT/prof; (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -- python3 $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OLDPWD/$OUT/bench_under_rocprofv3.json 2> $OLDPWD/$OUT/prof.err) || fault prof
            f=$(find $OUT/prof -name "*kernel_stats.csv" | head -n 1); cp "$f" $OUT/kernel_stats.csv; head -n 12 $OUT/kernel_stats.csv | cut -c1-150; rm -rf $OUT/prof ;;
-    pmc)   bash tools/pmc.sh $OUT/pmc > $OUT/pmc.log 2>&1 || fault pmc; python tools/pmc_report.py $OUT/pmc act118_dz114 > $OUT/pmc_traffic.json; rm -rf $OUT/pmc; python -c "import json; r=json.load(open('$OUT/pmc_traffic.json')); print({k: v.get('hbm_bytes_per_launch') for k, v in r.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v})" ;;
+    pmc)   # the instantiations bench.py runs by default: list mode (skip_dead_tiles = 1)
+           bash tools/pmc.sh $OUT/pmc --skip-dead-tiles 1 > $OUT/pmc.log 2>&1 || fault pmc; python tools/pmc_report.py $OUT/pmc act118_dz114 1 > $OUT/pmc_traffic.json; rm -rf $OUT/pmc; python -c "import json; r=json.load(open('$OUT/pmc_traffic.json')); print({k: v.get('hbm_bytes_per_launch') for k, v in r.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v})" ;;
     cfgs)  for c in cfg3 cfg4 cfg5; do timeout -k 10 200 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err || fault $c; python -c "import json; l=json.load(open('$OUT/bench_$c.json')); print('$c', l['ms_per_step'], l['value'])"; done ;;
     fit)   for c in cfg2 cfg4; do timeout -k 10 200 python bench.py --mode fit --config $c > $OUT/fit_$c.json 2> $OUT/fit_$c.err || fault fit_$c; python -c "import json; l=json.load(open('$OUT/fit_$c.json')); print('fit $c', l['ms_per_step'], l['train_step_ms'], l['fit_vs_train_step'], l['metrics_ms_per_step'])"; done ;;
     opts)  for o in "--skip-dead-tiles 0" "--skip-dead-tiles 1" "--deterministic 1" "--skip-dead-tiles 0"; do n=$(echo $o | tr -d ' -'); timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $o > $OUT/opt_$n.json 2> $OUT/opt_$n.err || fault "$o"; python -c "import json; l=json.load(open('$OUT/opt_$n.json')); print('$o', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"; done ;;

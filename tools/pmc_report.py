@@ -3,6 +3,7 @@
 import csv, glob, json, sys, collections
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 layout = sys.argv[2] if len(sys.argv) > 2 else None      # bench.py LAYOUT_TAG of the build that was profiled
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else None   # kbench --skip-dead-tiles of the profiled run (list-mode or contiguous backward kernels)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -14,6 +15,8 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
 rep = {}
 if layout:
     rep["_layout"] = layout
+if skip is not None:
+    rep["_options"] = {"skip_dead_tiles": skip}
 for (k, grid), cs in sorted(agg.items()):
     rep[f"{k} grid={grid}"] = {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())}
     row = rep[f"{k} grid={grid}"]
