@@ -27,7 +27,7 @@ SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.
 # the run-time dispatchers), so the shapes build in parallel and the default shape's object is what it was before the others existed.
 SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
 N_BUILTIN_SHAPES = 12   # = kNumBuiltinShapes (csrc/layout.h static_asserts it); knerf_api.hip checks the total against KNERF_N_SHAPE_SLICES
-MAX_EXTRA_SHAPES = 12
+MAX_EXTRA_SHAPES = 36   # a build-time budget, not a limit of csrc/layout.h (one more instantiation of the three big kernels each)
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]
@@ -91,7 +91,8 @@ def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
     jobs = []
     for src in sources:
         if src in SLICED:
-            jobs += [(src, src.replace(".hip", f"_s{k}.o"), [f"-DKNERF_SHAPE_SLICE={k}", f"-DKNERF_N_SHAPE_SLICES={n_slices}"]) for k in range(n_slices)]
+            # -DKNERF_OWN_<k>=, : the lone comma csrc/layout.h KNERF_PICK looks for (which shape this translation unit instantiates)
+            jobs += [(src, src.replace(".hip", f"_s{k}.o"), [f"-DKNERF_SHAPE_SLICE={k}", f"-DKNERF_OWN_{k}=,", f"-DKNERF_N_SHAPE_SLICES={n_slices}"]) for k in range(n_slices)]
         else:
             jobs.append((src, src.replace(".hip", ".o"), [f"-DKNERF_N_SHAPE_SLICES={n_slices}"]))
     todo = []

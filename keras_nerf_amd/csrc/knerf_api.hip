@@ -417,8 +417,9 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     if (cfg->n_layers < 1 || cfg->n_layers > 64 || cfg->dense_units < 2 || cfg->dense_units > 4096 || cfg->skip_layer < 1 ||
         cfg->pos_emb_xyz < 0 || cfg->pos_emb_xyz > 32 || cfg->pos_emb_dir < 0 || cfg->pos_emb_dir > 32)
         return fail(nullptr, KNERF_ERR_INVALID, "need 1 <= n_layers <= 64, 2 <= dense_units <= 4096, skip_layer >= 1, 0 <= pos_emb_* <= 32");
-    if (cfg->n_coarse < 2 || cfg->n_coarse > 256 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 512)
-        return fail(nullptr, KNERF_ERR_INVALID, "need 2 <= n_coarse <= 256 and n_coarse + n_fine <= 512");
+    // one wavefront walks a ray in compositing (a lane's run of up to 16 samples in registers) and in the sampler (tables in LDS)
+    if (cfg->n_coarse < 2 || cfg->n_coarse > 512 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 1024)
+        return fail(nullptr, KNERF_ERR_INVALID, "need 2 <= n_coarse <= 512 and n_coarse + n_fine <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KNERF_ERR_NODEVICE, "no HIP device visible");
     hipDeviceProp_t prop;

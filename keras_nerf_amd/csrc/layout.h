@@ -105,7 +105,7 @@ using DefaultShape = Shape<8, 4>;
 #define KNERF_BUILTIN_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
     X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128)
 // Further entries chosen at BUILD time: `python keras_nerf_amd/build.py --add-shape=NL,SK,U[,LX,LD] ...` defines KNERF_EXTRA_SHAPES(X) as
-// X(12, NL, SK, U) X(13, NL, SK, U, LX, LD) ... (indices continue the built-in list, at most 12 of them: KNERF_SLICE_12 .. 23 below).  A triple the
+// X(12, NL, SK, U) X(13, NL, SK, U, LX, LD) ... (indices continue the built-in list).  A triple the
 // kernels do not cover fails to compile on Shape's static_assert; one that repeats an earlier entry is never selected.
 #ifndef KNERF_EXTRA_SHAPES
 #define KNERF_EXTRA_SHAPES(X)
@@ -115,7 +115,7 @@ using DefaultShape = Shape<8, 4>;
 constexpr int kNumBuiltinShapes = 0 KNERF_BUILTIN_SHAPES(KNERF_X);
 constexpr int kNumFusedShapes = 0 KNERF_FUSED_SHAPES(KNERF_X);
 #undef KNERF_X
-static_assert(kNumBuiltinShapes == 12 && kNumFusedShapes <= 24, "the slice macros below cover indices 0 .. 23");
+static_assert(kNumBuiltinShapes == 12, "keras_nerf_amd/build.py N_BUILTIN_SHAPES");
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
 template <class S> constexpr bool shape_is(int n_layers, int skip_layer, int dense_units, int lx, int ld) {
     return n_layers == S::NL && skip_layer == S::SK && dense_units == S::U && lx == S::LX && ld == S::LD;
@@ -126,130 +126,23 @@ constexpr int fused_shape_id(int n_layers, int skip_layer, int dense_units = 256
 #undef KNERF_X
     return -1;
 }
-// KNERF_PICK(I, DEF, EXT) -> DEF when this translation unit owns shape I (no slicing: every shape), EXT otherwise
-#define KNERF_SLICE_OWNS(I) (!defined(KNERF_SHAPE_SLICE) || KNERF_SHAPE_SLICE == I)
-#if KNERF_SLICE_OWNS(0)
-#define KNERF_SLICE_0(DEF, EXT) DEF
+// KNERF_PICK(I, DEF, EXT) -> DEF when this translation unit owns shape I (no slicing: every shape), EXT otherwise.  build.py compiles
+// a sliced source with -DKNERF_SHAPE_SLICE=<k> AND -DKNERF_OWN_<k>=, (a lone comma): `KNERF_OWN_##I 1, 0` then starts with a comma for the
+// owned index only, which shifts the argument that KNERF_PICK_2ND returns from 0 to 1 -- any number of shapes, no per-index macro
+// (rounds 2-3 carried 24 hand-expanded KNERF_SLICE_n blocks here).
+#ifndef KNERF_SHAPE_SLICE
+#define KNERF_PICK(I, DEF, EXT) DEF
+#define KNERF_HAS_DISPATCH 1
 #else
-#define KNERF_SLICE_0(DEF, EXT) EXT
+#define KNERF_PICK_2ND(a, b, ...) b
+#define KNERF_PICK_SEL(...) KNERF_PICK_2ND(__VA_ARGS__)
+#define KNERF_PICK_1(DEF, EXT) DEF
+#define KNERF_PICK_0(DEF, EXT) EXT
+#define KNERF_PICK_CAT(a, b) a##b
+#define KNERF_PICK_GO(bit) KNERF_PICK_CAT(KNERF_PICK_, bit)
+#define KNERF_PICK(I, DEF, EXT) KNERF_PICK_GO(KNERF_PICK_SEL(KNERF_OWN_##I 1, 0))(DEF, EXT)
+#define KNERF_HAS_DISPATCH (KNERF_SHAPE_SLICE == 0)
 #endif
-#if KNERF_SLICE_OWNS(1)
-#define KNERF_SLICE_1(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_1(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(2)
-#define KNERF_SLICE_2(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_2(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(3)
-#define KNERF_SLICE_3(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_3(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(4)
-#define KNERF_SLICE_4(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_4(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(5)
-#define KNERF_SLICE_5(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_5(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(6)
-#define KNERF_SLICE_6(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_6(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(7)
-#define KNERF_SLICE_7(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_7(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(8)
-#define KNERF_SLICE_8(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_8(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(9)
-#define KNERF_SLICE_9(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_9(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(10)
-#define KNERF_SLICE_10(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_10(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(11)
-#define KNERF_SLICE_11(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_11(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(12)
-#define KNERF_SLICE_12(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_12(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(13)
-#define KNERF_SLICE_13(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_13(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(14)
-#define KNERF_SLICE_14(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_14(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(15)
-#define KNERF_SLICE_15(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_15(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(16)
-#define KNERF_SLICE_16(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_16(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(17)
-#define KNERF_SLICE_17(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_17(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(18)
-#define KNERF_SLICE_18(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_18(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(19)
-#define KNERF_SLICE_19(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_19(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(20)
-#define KNERF_SLICE_20(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_20(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(21)
-#define KNERF_SLICE_21(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_21(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(22)
-#define KNERF_SLICE_22(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_22(DEF, EXT) EXT
-#endif
-#if KNERF_SLICE_OWNS(23)
-#define KNERF_SLICE_23(DEF, EXT) DEF
-#else
-#define KNERF_SLICE_23(DEF, EXT) EXT
-#endif
-#define KNERF_PICK(I, DEF, EXT) KNERF_SLICE_##I(DEF, EXT)
-#define KNERF_HAS_DISPATCH KNERF_SLICE_OWNS(0)
 constexpr int kParamCount = DefaultShape::kParamCount;      // 595,844: knerf_param_count()
 static_assert(kParamCount == 595844 && DefaultShape::kFwdBlocks == 978 && DefaultShape::kBwdBlocks == 904 && DefaultShape::kActBlocks == 118 &&
               DefaultShape::kActEnc == 64 && DefaultShape::act_h(5) == 68 && DefaultShape::kDzBlocks == 130, "the default shape's layout");

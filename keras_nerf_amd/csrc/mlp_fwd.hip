@@ -6,6 +6,10 @@
 // sigmoid / relu.  SAVE additionally writes every trunk layer's bf16 activations (B-operand blocks, layout.h) and the
 // ReLU masks for the backward kernels.  The three linear layers behind the trunk (features, rgb_features, rgb; mlp.py:44-48)
 // and the sigma head are evaluated as ONE 4-row stage on the composed matrix (layout.h "collapsed head").
+#ifdef KNERF_ABLATE_FWD_STORES     // timing experiment only (r04): the training forward WITHOUT its saved-tensor stores -- the
+#define KNERF_ABLATE_STORES         // upper bound of a forward that does not save what the backward will skip.  Waits as if no store
+#define KNERF_CONSERVATIVE_WAIT     // had been issued; results of the backward are garbage, its timing is what it is.
+#endif
 #include "chain.h"
 #include "kernels.h"
 #include "layout.h"

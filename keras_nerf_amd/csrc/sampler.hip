@@ -32,17 +32,20 @@ __device__ __forceinline__ float philox_u(unsigned long long seed, unsigned stre
     return (float)(x >> 8) * 5.9604644775390625e-08f;
 }
 
-constexpr int kMaxCoarse = 256, kMaxAll = 768;   // kMaxAll >= 2*kMaxCoarse: the fine half doubles as scratch
+// Any sample count the reference's CLI can ask for (train_single.py:28-29: --num_coarse_samples / --num_fine_samples are free
+// integers) up to kMaxCoarse coarse and kMaxAll samples per ray: the per-wave tables live in DYNAMIC LDS sized by the launch
+// (t: Nc, cdf: Nc + 1, all: max(Nc + Nf, 2 Nc) floats -- the fine half of `all` doubles as scratch for the pdf), 20 KB per
+// workgroup at 64 + 128, 131 KB at the limits.
+constexpr int kMaxCoarse = 1024, kMaxAll = 4096;
+__host__ __device__ inline int sampler_wave_floats(int Nc, int Nf) { const int na = Nc + Nf > 2 * Nc ? Nc + Nf : 2 * Nc; return Nc + (Nc + 1) + na + 3; }
 
 __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
-    __shared__ float s_t[4][kMaxCoarse];
-    __shared__ float s_cdf[4][kMaxCoarse + 1];
-    __shared__ float s_all[4][kMaxAll];
+    extern __shared__ float s_dyn[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     if (ray >= a.R) return;
     const int Nc = a.Nc, Nf = a.Nf, Na = Nc + Nf;
-    float* tt = s_t[wv]; float* cdf = s_cdf[wv]; float* all = s_all[wv];
+    float* tt = s_dyn + (size_t)wv * sampler_wave_floats(Nc, Nf); float* cdf = tt + Nc; float* all = cdf + Nc + 1;
     const float* tc = a.t_coarse + (size_t)ray * Nc;
     const float* wc = a.w_coarse + (size_t)ray * Nc;
 
@@ -129,7 +132,14 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
 
 hipError_t launch_sample_fine(const SampleArgs& a, hipStream_t stream) {
     if (a.Nc > kMaxCoarse || a.Nc + a.Nf > kMaxAll || a.Nc < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sample_fine_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+    const size_t lds = 4 * (size_t)sampler_wave_floats(a.Nc, a.Nf) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        static AttrOnce once;
+        hipError_t ae = once([&]() -> hipError_t { return hipFuncSetAttribute(reinterpret_cast<const void*>(sample_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (ae != hipSuccess) return ae;
+    }
+    hipLaunchKernelGGL(sample_fine_kernel, dim3((a.R + 3) / 4), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

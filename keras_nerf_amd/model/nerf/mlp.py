@@ -28,11 +28,56 @@ def layer_shapes(n_layers: int, dense_units: int, skip_layer: int, xyz_dim: int,
     return shapes
 
 
+def _truncated_normal(rng, n, stddev):
+    """Keras' truncated normal: N(0, stddev) with draws beyond two standard deviations redrawn"""
+    x = rng.standard_normal(n)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return x * stddev
+
+
+# tf.keras.initializers by name: the VarianceScaling family (scale, mode, distribution) as Keras defines it -- the `initializer`
+# argument of the reference's NeRFMLP goes to every Dense layer's kernel_initializer (mlp.py:5, 13-27); biases stay zero.
+# "normal" variants are TRUNCATED normals whose stddev is divided by 0.87962566103423978 (the std of a unit normal cut at +-2).
+_VARIANCE_SCALING = {"glorot_uniform": (1.0, "avg", "uniform"), "glorot_normal": (1.0, "avg", "normal"),
+                     "he_uniform": (2.0, "in", "uniform"), "he_normal": (2.0, "in", "normal"),
+                     "lecun_uniform": (1.0, "in", "uniform"), "lecun_normal": (1.0, "in", "normal")}
+
+
+def init_kernel(initializer, rng, fan_in: int, fan_out: int) -> np.ndarray:
+    """one Dense kernel [fan_in, fan_out] flattened, drawn as tf.keras.initializers.get(initializer) would; a callable
+    (shape) -> array is accepted as well"""
+    n = fan_in * fan_out
+    if callable(initializer):
+        return np.asarray(initializer((fan_in, fan_out)), np.float32).reshape(-1)
+    name = str(initializer).lower()
+    if name in _VARIANCE_SCALING:
+        scale, mode, dist = _VARIANCE_SCALING[name]
+        k, den = (1.0, fan_in) if mode == "in" else (2.0, fan_in + fan_out)          # scale / fan, fan = fan_in or (fan_in + fan_out) / 2
+        if dist == "uniform":
+            lim = np.sqrt(3.0 * scale * k / den)                                     # glorot_uniform: sqrt(6 / (fan_in + fan_out))
+            return rng.uniform(-lim, lim, size=n).astype(np.float32)
+        return _truncated_normal(rng, n, np.sqrt(scale * k / den) / 0.87962566103423978).astype(np.float32)
+    if name in ("zeros", "ones"):
+        return np.full(n, float(name == "ones"), np.float32)
+    if name in ("random_normal", "randomnormal"):
+        return (rng.standard_normal(n) * 0.05).astype(np.float32)
+    if name in ("truncated_normal", "truncatednormal"):
+        return _truncated_normal(rng, n, 0.05).astype(np.float32)
+    if name in ("random_uniform", "randomuniform"):
+        return rng.uniform(-0.05, 0.05, size=n).astype(np.float32)
+    raise ValueError(f"initializer {initializer!r}: known names are {sorted(_VARIANCE_SCALING)} + zeros, ones, random_normal, "
+                     f"truncated_normal, random_uniform; or pass a callable (shape) -> array")
+
+
 class NeRFMLP:
     def __init__(self, n_layers: int = 8, dense_units: int = 256, skip_layer=4, initializer="glorot_uniform", name=None,
                  xyz_dim: int = 63, dir_dim: int = 27, seed=None, **kwargs):
-        if initializer != "glorot_uniform":
-            raise ValueError("only the reference's initializer 'glorot_uniform' is implemented")
+        if not callable(initializer):
+            init_kernel(initializer, np.random.default_rng(0), 1, 1)          # an unknown name fails here, as in Keras
+        self.initializer = initializer
         self.n_layers, self.dense_units, self.skip_layer = n_layers, dense_units, skip_layer
         self.name = name or "nerf_mlp"
         self.xyz_dim, self.dir_dim = xyz_dim, dir_dim
@@ -51,14 +96,13 @@ class NeRFMLP:
         return sum(i * o + o for _, i, o in self._shapes)
 
     def build(self):
-        """glorot_uniform kernels U(+-sqrt(6/(fan_in+fan_out))), zero biases (Keras Dense defaults)."""
+        """kernels from `initializer` (default glorot_uniform: U(+-sqrt(6/(fan_in+fan_out)))), zero biases (Keras Dense defaults)."""
         if self.built:
             return
         rng = np.random.default_rng(self._seed)
         parts = []
         for _, fi, fo in self._shapes:
-            lim = np.sqrt(6.0 / (fi + fo))
-            parts.append(rng.uniform(-lim, lim, size=fi * fo).astype(np.float32))
+            parts.append(init_kernel(self.initializer, rng, fi, fo))
             parts.append(np.zeros(fo, np.float32))
         self._host = np.concatenate(parts)
 

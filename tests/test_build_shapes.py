@@ -40,7 +40,8 @@ def test_parse_shapes_accepts_covered_triples_and_names_the_others():
         with pytest.raises(ValueError):
             B.parse_shapes([bad])
     with pytest.raises(ValueError):
-        B.parse_shapes([f"{nl},{nl},128" for nl in range(4, 17)])       # 13 valid triples: more than the slice macros cover
+        B.parse_shapes([f"{nl},{sk},{u}" for nl in range(4, 17) for sk in (nl, nl + 1) for u in (128, 256)])       # 52 valid triples: over the build-time budget (MAX_EXTRA_SHAPES)
+    assert len(B.parse_shapes([f"{nl},{nl},128" for nl in range(4, 17)])) == 13      # round 4: no cap at 12 any more (csrc/layout.h KNERF_PICK needs no per-index macro)
 
 
 def test_layout_header_with_extra_shapes(tmp_path):

@@ -298,3 +298,42 @@ def test_lego_camera_of_the_reference_ray_test():
     np.testing.assert_array_equal(o, eo); np.testing.assert_allclose(d, ed, atol=2e-7); np.testing.assert_allclose(t, et, atol=1e-6)
     np.testing.assert_allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)            # rays.py:108-109
     np.testing.assert_array_equal(o, np.broadcast_to(c2w[:3, 3], o.shape))            # rays.py:111-113
+
+
+@pytest.mark.parametrize("nc,nf", [(512, 256), (320, 704), (96, 32)])
+def test_sample_counts_beyond_the_defaults(nc, nf):
+    """train_single.py:28-29: --num_coarse_samples / --num_fine_samples are free integers.  Rounds 1-3 stopped at 256 coarse and 512 total
+    (a lane's run in compositing, static LDS tables in the sampler); now 512 / 1024: compositing templates of 12 and 16 samples per
+    lane, sampler tables in dynamic LDS.  16 rays through coarse pass, sampler (merged t bit for bit), fine pass and one train chunk
+    against the oracle; the limits themselves are checked at creation."""
+    from keras_nerf_amd.runtime import KnerfContext
+    from tests.problem import make_problem
+    cfg = O.NerfConfig(n_coarse=nc, n_fine=nf)
+    P = make_problem(n_images=1, wh=4, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    N = P["N"]
+    o, d, t, u, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, nc), P["u"].reshape(N, nf), P["img"].reshape(N, 3)
+    ctx = KnerfContext(n_coarse=nc, n_fine=nf, white_background=True)
+    ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+    out = {k: v.cpu().numpy() for k, v in ctx.render_chunk(o, d, t, u).items()}
+    c = O.predict_and_render_chunk_single(P["cp"], o, d, t, cfg, True, emulate_bf16=O.FUSED)
+    np.testing.assert_allclose(out["c_image"], c["image"], atol=1e-2); np.testing.assert_allclose(out["c_weights"], c["weights"], atol=1e-2)
+    assert out["t_fine"].shape == (N, nc + nf)
+    np.testing.assert_array_equal(out["t_fine"], O.fine_points(t, out["c_weights"], u, "zero"))          # sampler + merge: bit-exact on the GPU's own weights
+    f = O.predict_and_render_chunk_single(P["fp"], o, d, out["t_fine"], cfg, True, emulate_bf16=O.FUSED)
+    np.testing.assert_allclose(out["f_image"], f["image"], atol=1e-2); np.testing.assert_allclose(out["f_weights"], f["weights"], atol=1e-2)
+    np.testing.assert_allclose(out["f_depth"], f["depth"], atol=5e-2)
+    loss = torch.zeros(2, device="cuda")
+    ctx.train_chunk(o, d, t, img, u, loss=loss)
+    g = ctx.grads_view().cpu().numpy(); n = ctx.param_count
+    t_fine = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * (nc + nf)].reshape(N, nc + nf)
+    for net, (params, tt) in enumerate(((P["cp"], t), (P["fp"], t_fine))):
+        _, l, gr = O.chunk_loss_and_grads(params, o, d, tt, img, cfg, True, emulate_bf16=O.FUSED)
+        e = per_tensor_err(g[net * n:(net + 1) * n], O.flatten_params(gr), cfg)
+        log_stats(f"sample_counts_{nc}_{nf}_net{net}", worst=e[0], loss=abs(float(loss[net]) - float(l)))
+        assert e[0] < GRAD_TOL_EMU, (net, e)
+        assert abs(float(loss[net]) - float(l)) < 2e-3
+    assert bool(ctx.get_option("skip_dead_tiles_active")) == (nc % 32 == 0 and (nc + nf) % 32 == 0)
+    ctx.close()
+    for bad in (dict(n_coarse=513, n_fine=0), dict(n_coarse=512, n_fine=513), dict(n_coarse=1, n_fine=8)):
+        with pytest.raises(ValueError):
+            KnerfContext(**bad)

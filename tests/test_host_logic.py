@@ -194,3 +194,27 @@ def test_reference_import_names_resolve_to_this_implementation():
         b = importlib.import_module(mod.replace("keras_nerf.", "keras_nerf_amd.", 1))
         for n in names:
             assert getattr(a, n) is getattr(b, n), (mod, n)
+
+
+def test_nerfmlp_initializer_names_follow_keras():
+    """mlp.py:5, 13-27: `initializer` goes to every Dense kernel_initializer.  The VarianceScaling family by name: limits of the
+    uniform variants, standard deviations (and the +-2 sigma truncation) of the normal ones, zero biases; unknown names raise."""
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    fi, fo = 256, 256
+    want = {"glorot_uniform": ("u", np.sqrt(6 / (fi + fo))), "he_uniform": ("u", np.sqrt(6 / fi)), "lecun_uniform": ("u", np.sqrt(3 / fi)),
+            "glorot_normal": ("n", np.sqrt(2 / (fi + fo))), "he_normal": ("n", np.sqrt(2 / fi)), "lecun_normal": ("n", np.sqrt(1 / fi))}
+    for name, (kind, v) in want.items():
+        m = NeRFMLP(initializer=name, seed=3); m.build()
+        ws = m.get_weights()
+        k = ws[2]                                    # layer_1: 256 x 256
+        assert k.shape == (fi, fo) and not ws[3].any()
+        if kind == "u":
+            assert np.abs(k).max() <= v and np.abs(k).max() > 0.99 * v and abs(k.std() - v / np.sqrt(3)) < 0.02 * v
+        else:
+            assert abs(k.std() - v) < 0.02 * v and np.abs(k).max() <= 2.0 * v / 0.87962566103423978 + 1e-6
+    a = NeRFMLP(seed=3); a.build(); b = NeRFMLP(initializer="glorot_uniform", seed=3); b.build()
+    np.testing.assert_array_equal(a.get_flat_weights(), b.get_flat_weights())
+    c = NeRFMLP(initializer=lambda shape: np.full(shape, 0.25, np.float32)); c.build()
+    assert float(c.get_weights()[0][0, 0]) == 0.25
+    with pytest.raises(ValueError):
+        NeRFMLP(initializer="orthogonal")

@@ -38,6 +38,9 @@ def _flags():
     return b.FLAGS          # exactly what the library is built with
 
 
+SLICE0 = ["-DKNERF_SHAPE_SLICE=0", "-DKNERF_OWN_0=,"]      # what build.py passes for slice 0 (csrc/layout.h KNERF_PICK)
+
+
 def _asm(name):
     """gfx950 assembly of csrc/<name>.hip, cached under the temp dir by the hash of every source and header it may include"""
     h = hashlib.sha1()
@@ -45,12 +48,12 @@ def _asm(name):
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode()); h.update(open(p, "rb").read())
-    h.update(" ".join(_flags()).encode())
+    h.update(" ".join(_flags() + SLICE0).encode())
     out = os.path.join(tempfile.gettempdir(), f"knerf_isa_{name}_{h.hexdigest()[:16]}.s")
     if not os.path.exists(out):
         tmp = out + f".{os.getpid()}"
         # slice 0 = the reference's default trunk shape (layout.h KNERF_FUSED_SHAPES): the object build.py links for it
-        subprocess.run([HIPCC, *_flags(), "-DKNERF_SHAPE_SLICE=0", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", tmp,
+        subprocess.run([HIPCC, *_flags(), *SLICE0, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", tmp,
                         os.path.join(CSRC, name + ".hip")], check=True, capture_output=True)
         os.replace(tmp, out)
     return open(out).read()

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Mean +- standard error of (fp32 leg - HIP leg) validation PSNR from tools/convergence128.py logs.
 
-    python tools/convergence_stats.py --hip profiles/r02_convergence128_lr5e-4_{hip*,final*}.json profiles/r03_conv128_hip*.json \\
-                                      --fp32 profiles/r02_convergence128_lr5e-4_fp32.json profiles/r03_conv128_fp32_p*.json \\
+    python tools/convergence_stats.py --hip profiles/archive/r02_convergence128_lr5e-4_{hip*,final*}.json profiles/archive/r03_conv128/r03_conv128_lr5e-4_hip*.json \\
+                                      --fp32 profiles/archive/r02_convergence128_lr5e-4_fp32.json profiles/archive/r03_conv128/r03_conv128_lr5e-4_fp32_p*.json \\
                                       --out profiles/r03_convergence_stats.json
 
 Per checkpoint s: D(s) = mean_j F_j(s) - mean_i H_i(s), SE(s) = sqrt(var F / n_F + var H / n_H) (sample variances over the runs of each
