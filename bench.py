@@ -558,8 +558,8 @@ def main():
         ms = [a.elapsed_time(b_) for a, b_ in ev]
         # from the moment this rank's last chunk has finished to the moment the reduced gradients are usable: the collective
         # itself plus the wait for the slowest rank
-        comm = {"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
-                "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4}
+        comm.update({"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
+                     "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4})
     if world > 1:          # every rank: its share of the device (ranks sharing a GPU in a rehearsal must all fit; wgrad_group follows free memory)
         free_b, total_b = torch.cuda.mem_get_info()
         print(f"[bench rank {rank}/{world}] device memory free {free_b / 2**30:.1f} GiB of {total_b / 2**30:.1f} GiB; "

@@ -7,8 +7,8 @@ libknerf_probe.so  diagnostics for tests/ and tools/ (include/knerf_debug.h): la
     python keras_nerf_amd/build.py [--force] [-DNAME[=VALUE] ...] [--variant=NAME] [--add-shape=NL,SK,U[,LX,LD] ...]
 
 --add-shape (or KNERF_ADD_SHAPES="NL,SK,U;NL,SK,U,LX,LD" in the environment): further NeRF(n_layers, skip_layer, dense_units [, pos_emb_xyz,
-pos_emb_dir]) shapes for the fused kernels beside the built-in list of csrc/layout.h (dense_units 256 or 128; encodings: the reference's
-10 / 4 unless given, pos_emb_dir <= 4); three more hipcc runs and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
+pos_emb_dir]) shapes for the fused kernels beside the built-in list of csrc/layout.h (dense_units 256, 128 or 64; encodings: the reference's
+10 / 4 unless given, pos_emb_dir <= 8); three more hipcc runs and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
 """
 from __future__ import annotations
 
@@ -56,9 +56,9 @@ def parse_shapes(specs) -> list:
                 raise ValueError(f"--add-shape wants n_layers,skip_layer,dense_units[,pos_emb_xyz,pos_emb_dir], got {item!r}")
             nl, sk, u = v[:3]
             lx, ld = v[3:] if len(v) == 5 else (10, 4)
-            if u not in (128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0 or not 1 <= lx <= 16 or not 1 <= ld <= 4:
-                raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 128 or 256, 3 <= n_layers <= 16, "
-                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0), 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 4")
+            if u not in (64, 128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0 or not 1 <= lx <= 16 or not 1 <= ld <= 8:
+                raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 64, 128 or 256, 3 <= n_layers <= 16, "
+                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0), 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 8")
             if (lx, ld) == (10, 4):
                 v = v[:3]
             if v not in out:

@@ -23,6 +23,7 @@
 namespace knerf {
 
 constexpr int kLx = 10, kLd = 4;               // the reference's defaults (nerf.py:11-14): 63-d / 27-d encodings
+constexpr int kMaxLd = 8;                      // largest pos_emb_dir of a fused shape: 51-d direction encoding, four head k-steps (kAuxS, optim.hip)
 
 // ---- trunk shape ---------------------------------------------------------------------------------------------------------
 // The fused kernels cover NeRFMLP(n_layers = NL, dense_units = 256, skip_layer = SK) with 63-d / 27-d encodings (mlp.py:5-50):
@@ -35,7 +36,7 @@ constexpr int kLx = 10, kLd = 4;               // the reference's defaults (nerf
 template <int NL_, int SK_, int U_, int LX_, int LD_>
 struct ShapeImpl {
     static constexpr int NL = NL_, SK = SK_, U = U_, LX = LX_, LD = LD_;
-    static constexpr int kKs = U / 16, kOt = U / 32;        // k-steps / out tiles of a U-wide layer: 16 / 8 at 256, 8 / 4 at 128
+    static constexpr int kKs = U / 16, kOt = U / 32;        // k-steps / out tiles of a U-wide layer: 16 / 8 at 256, 8 / 4 at 128, 4 / 2 at 64
     // encodings: 3 + 6 L features in slots of 16 per k-step (8 per lane half: x, y | z, pad, then sin | cos of 2^i p_c), the k-step
     // count rounded up to EVEN -- the weight-gradient kernel takes its inputs in tiles of 32 rows = two blocks
     static constexpr int kXyzDim = 3 + 6 * LX, kDirDim = 3 + 6 * LD;
@@ -43,8 +44,8 @@ struct ShapeImpl {
     static constexpr int kEncQ = enc_q(LX), kDirQ = enc_q(LD);          // 4 and 2 for the reference's L = 10 / 4
     static constexpr bool concat_in(int l) { return l >= 2 && l < NL && (l - 1) % SK == 0; }
     static constexpr bool kConcatBehindLast = (NL - 1) % SK == 0 && NL - 1 > 0;
-    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128) &&
-                                       LX >= 1 && LX <= 16 && LD >= 1 && LD <= 4;      // LD: the head accumulator holds U + 27 rows (kAuxS)
+    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128 || U == 64) &&
+                                       LX >= 1 && LX <= 16 && LD >= 1 && LD <= kMaxLd;  // LD: the head accumulator holds U + 3 + 6 LD rows (kAuxS)
     static constexpr int first_concat() { for (int l = 2; l < NL; ++l) if (concat_in(l)) return l; return 0; }
     static constexpr int kFirstConcat = first_concat();
     // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias; behind the trunk
@@ -171,8 +172,9 @@ template <class S> constexpr int LSIG = S::NL;
 // packing tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
 // the same identity) from M = [h ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
 // in an auxiliary buffer (optim.hip head_expand).
-// auxiliary gradient buffer of one net: M[row][c] (row = 0..U-1 h, U..U+26 dir; c = 0..2), then s[c] at kAuxS (sized for U = 256)
-constexpr int kAuxM = 0, kAuxS = 283 * 3, kAuxCount = 864;
+// auxiliary gradient buffer of one net: M[row][c] (row = 0..U-1 h, then the 3 + 6 LD dir rows; c = 0..2), then s[c] at kAuxS (sized for U = 256, LD = kMaxLd)
+constexpr int kMaxDirDim = 3 + 6 * kMaxLd;                                     // 51
+constexpr int kAuxM = 0, kAuxS = (256 + kMaxDirDim) * 3, kAuxCount = 928;      // 921 + 3 sums, rounded up
 
 // ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
 // encoded position: 64 slots (4 k-steps).  half 0: x, y, sin(2^i p_c);  half 1: z, pad, cos(2^i p_c).

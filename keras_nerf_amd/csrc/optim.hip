@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
     float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
     const HeadOff o(off_l, U, D, DS);
     const int U2 = U / 2, R = U + D;
-    __shared__ float P[kMaxU + 27][3];   // W_r W_c : rows 0..U-1 = W_r1 W_c, U..U+26 = W_r2 W_c
+    __shared__ float P[kMaxU + kMaxDirDim][3];   // W_r W_c : rows 0..U-1 = W_r1 W_c, U..U+26 = W_r2 W_c
     __shared__ float wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
     for (int i = tid; i < U2 * 3; i += 256) wc[i / 3][i % 3] = w[o.wc + i];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
     if (tid == 3) w[o.head_bias + 3] = w[o.bs];
 }
 hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, int dir_dim, int dir_slots, hipStream_t stream) {
-    if (units > kMaxU || dir_dim > 27 || dir_slots > 64) return hipErrorInvalidValue;
+    if (units > kMaxU || dir_dim > kMaxDirDim || dir_slots > 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units, dir_dim, dir_slots);
     return hipGetLastError();
 }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
     const int U = a.U, U2 = U / 2, R = U + a.D;
     const HeadOff o(a.off_l, U, a.D, a.DS);
-    __shared__ float M[kMaxU + 27][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
+    __shared__ float M[kMaxU + kMaxDirDim][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
     for (int i = tid; i < R * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
     if (tid < 3) s_[tid] = aux[kAuxS + tid];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
 }
 hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int dir_dim, int dir_slots,
                               hipStream_t stream) {
-    if (units > kMaxU || dir_dim > 27) return hipErrorInvalidValue;
+    if (units > kMaxU || dir_dim > kMaxDirDim) return hipErrorInvalidValue;
     HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units, dir_dim, dir_slots};
     hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();

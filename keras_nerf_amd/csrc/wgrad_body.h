@@ -173,7 +173,7 @@ __device__ __forceinline__ int wait_barrier_next(const Seq& seq, int idx) {
 template <class S, int NI, int NO, class Seq>
 __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job, const int act_blk, const int act_blk2, const int dz_blk,
                                                const Seq seq, char* smem) {
-    constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : 1);     // waves across output tiles
+    constexpr int WO = NO >= 8 ? 8 : (NO >= 4 ? 4 : (NO >= 2 ? 2 : 1));     // waves across output tiles (8 / 4 / 2 at width 256 / 128 / 64; 1: the head)
     constexpr int WI = kWgWaves / WO;                        // waves across input tiles (+ the bias row)
     constexpr int ROWS = NI + 1;
     constexpr int NACC = (ROWS + WI - 1) / WI;

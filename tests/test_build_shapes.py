@@ -36,7 +36,7 @@ def test_parse_shapes_accepts_covered_triples_and_names_the_others():
     assert B.parse_shapes(["6,3,128", "8,2,128;6,4,256", "6,3,128"]) == [(6, 3, 128), (8, 2, 128), (6, 4, 256)]
     assert B.parse_shapes([]) == [] and B.parse_shapes([""]) == []
     assert B.parse_shapes(["8,4,256,6,2;8,4,128,10,4"]) == [(8, 4, 256, 6, 2), (8, 4, 128)]           # the reference's encodings need no ShapeL entry
-    for bad in ("8,4,64", "2,1,256", "9,4,256", "4,3,256", "8,4", "a,b,c", "8,0,256", "8,4,256,10", "8,4,256,17,4", "8,4,256,10,5", "8,4,256,0,4"):     # width, depth, concat behind the last layer (x2), arity, type, skip, arity, encodings (x3)
+    for bad in ("8,4,96", "2,1,256", "9,4,256", "4,3,256", "8,4", "a,b,c", "8,0,256", "8,4,256,10", "8,4,256,17,4", "8,4,256,10,9", "8,4,256,0,4"):     # width, depth, concat behind the last layer (x2), arity, type, skip, arity, encodings (x3)
         with pytest.raises(ValueError):
             B.parse_shapes([bad])
     with pytest.raises(ValueError):

@@ -37,13 +37,15 @@ def test_compiler_tracked_fragment_loads_give_identical_bits():
     assert len(a) >= 10
 
 
-XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3"]
+XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3",
+           "8,4,64", "4,2,64", "8,4,256,10,8", "8,4,128,10,6"]        # round 4: width 64 (--num_units 64), pos_emb_dir 5..8 (four head k-steps)
 
 
 def test_build_time_extra_shapes_run_on_the_fused_kernels():
-    """`build.py --add-shape=NL,SK,U[,LX,LD]` (csrc/layout.h KNERF_EXTRA_SHAPES): a library built with two more width-128 trunks and four
+    """`build.py --add-shape=NL,SK,U[,LX,LD]` (csrc/layout.h KNERF_EXTRA_SHAPES): a library built with two more width-128 trunks, four
     shapes with other positional-encoding depths (pos_emb_xyz 6 / 12 / 5 / 16, pos_emb_dir 2 / 4 / 1 / 3: four, six, four and eight
-    encoding k-steps; h0 recomputed or saved) runs them on the fused kernels: host tables consistent, images / losses / gradients at
+    encoding k-steps; h0 recomputed or saved), two width-64 trunks (two out tiles per layer: two waves across the weight-gradient
+    kernel's output strips) and two shapes with pos_emb_dir 8 / 6 (51-d / 39-d direction encodings: four head k-steps) runs them on the fused kernels: host tables consistent, images / losses / gradients at
     the built-in shapes' tolerances against the oracle."""
     from keras_nerf_amd import build as B
     lib = B.build(verbose=False, variant="xshape", add_shapes=XSHAPES)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
-#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts
+#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -19,6 +19,19 @@ for st in $STAGES; do
     cfgs)  for c in cfg3 cfg4 cfg5; do timeout -k 10 200 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err || fault $c; python -c "import json; l=json.load(open('$OUT/bench_$c.json')); print('$c', l['ms_per_step'], l['value'])"; done ;;
     fit)   for c in cfg2 cfg4; do timeout -k 10 200 python bench.py --mode fit --config $c > $OUT/fit_$c.json 2> $OUT/fit_$c.err || fault fit_$c; python -c "import json; l=json.load(open('$OUT/fit_$c.json')); print('fit $c', l['ms_per_step'], l['train_step_ms'], l['fit_vs_train_step'], l['metrics_ms_per_step'])"; done ;;
     opts)  for o in "--skip-dead-tiles 0" "--skip-dead-tiles 1" "--deterministic 1" "--skip-dead-tiles 0"; do n=$(echo $o | tr -d ' -'); timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $o > $OUT/opt_$n.json 2> $OUT/opt_$n.err || fault "$o"; python -c "import json; l=json.load(open('$OUT/opt_$n.json')); print('$o', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"; done ;;
+    bound) # upper bound of a forward that does not save what the backward skips; needs libknerf_hip_nofwdstores.so
+           timeout -k 10 600 python tools/fwd_save_bound.py --weights $OUT/fwd_bound_w_step600.npz > $OUT/fwd_save_bound.json 2> $OUT/fwd_save_bound.err || fault bound
+           python -c "import json; r=json.loads(open('$OUT/fwd_save_bound.json').read().splitlines()[-1]); print('bound', r['summary'])" ;;
+    shapes) # the round-4 fused shapes (width 64, pos_emb_dir 8 / 6) against the general-shape kernels; needs libknerf_hip_xshape.so
+           : > $OUT/shapes_kbench.jsonl
+           for sh in 8,256,4,10,4 8,64,4,10,4 4,64,2,10,4 8,256,4,10,8 8,128,4,10,6; do
+             timeout -k 10 120 python tools/kbench.py --lib keras_nerf_amd/libknerf_hip_xshape.so --shape $sh --tag fused_$sh >> $OUT/shapes_kbench.jsonl 2>> $OUT/shapes_kbench.err || fault "shapes $sh"
+             KNERF_FORCE_GENERIC=1 timeout -k 10 120 python tools/kbench.py --lib keras_nerf_amd/libknerf_hip_xshape.so --shape $sh --tag generic_$sh >> $OUT/shapes_kbench.jsonl 2>> $OUT/shapes_kbench.err || fault "shapes generic $sh"
+           done; python -c "
+import json
+for l in open('$OUT/shapes_kbench.jsonl'):
+    if l.startswith('{'):
+        r=json.loads(l); print(r.get('tag'), r.get('train_chunk_ms'), r.get('Mrs_per_s'))" ;;
   esac
 done
 exit 0
