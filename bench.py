@@ -296,7 +296,12 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     from keras_nerf_amd.data.loader import DatasetLoader
     from keras_nerf_amd.model.nerf.callback import NeRFTrainMonitor
     from keras_nerf_amd.model.nerf.nerf import NeRF
-    root = tempfile.mkdtemp(prefix="knerf_fit_")
+    # ONE directory for all ranks (rank 0 makes it and writes the dataset, the others learn its name: every rank reads the same
+    # transforms_*.json and derives the same shuffled order, data/loader.py)
+    box = [tempfile.mkdtemp(prefix="knerf_fit_") if rank == 0 else None]
+    if world > 1:
+        torch.distributed.broadcast_object_list(box, src=0)
+    root = box[0]
     if rank == 0:
         write_synthetic_dataset(os.path.join(root, "data"), wh)
     if world > 1:
@@ -379,8 +384,11 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
                           "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
-    import shutil
-    shutil.rmtree(root, ignore_errors=True)
+    if world > 1:
+        torch.distributed.barrier()            # nobody is still reading when rank 0 removes the directory
+    if rank == 0:
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def dist_env():
@@ -502,19 +510,25 @@ def main():
         except Exception as e:                 # noqa: BLE001
             rank_fail(rank, world, device_index, backend, "the first all_reduce", e)
 
+    try:
+        run(args, world, rank, device_index, backend)
+    except Exception as e:                     # noqa: BLE001 -- N > 1: ANY rank that raises says who it is and ends the job (exit 3);
+        if world > 1:                          # its peers would otherwise meet it as "connection closed by peer" in their next collective
+            rank_fail(rank, world, device_index, backend, "the benchmark body", e)
+        raise
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run(args, world, rank, device_index, backend):
+    """everything behind the process group's set-up: one of the three benchmark bodies"""
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
     if args.config == "cfg5":
-        bench_render(args, world, rank, wh, chunks, desc, backend)
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+        return bench_render(args, world, rank, wh, chunks, desc, backend)
     if args.mode == "fit":
         RANK_ELAPSED[:] = [0.0]
-        bench_fit(args, world, rank, wh, batch, chunks, desc, backend)
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+        return bench_fit(args, world, rank, wh, batch, chunks, desc, backend)
     nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: every rank draws its OWN initial weights; compile() must mirror rank 0's
     try:
         inject("compile", rank)
@@ -663,8 +677,6 @@ def main():
             "metrics_ms_per_step": metrics_ms, "options": opts, "dead_tile_frac": dead_frac, **comm,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

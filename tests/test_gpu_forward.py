@@ -160,7 +160,7 @@ def test_generate_rays(ctx_and_problem):
 
 def test_invalid_architecture_fails_loudly():
     from keras_nerf_amd.runtime import KnerfContext
-    for bad in (dict(dense_units=1), dict(n_layers=0), dict(skip_layer=0), dict(pos_emb_xyz=-1), dict(n_coarse=1), dict(n_coarse=300, n_fine=300)):
+    for bad in (dict(dense_units=1), dict(n_layers=0), dict(skip_layer=0), dict(pos_emb_xyz=-1), dict(n_coarse=1), dict(n_coarse=600, n_fine=300), dict(n_coarse=512, n_fine=600)):
         with pytest.raises(ValueError):
             KnerfContext(**bad)
     ctx = KnerfContext(dense_units=128)          # other shapes: further fused instantiations (test_gpu_fused_shapes.py) or the general-shape kernels (test_gpu_generic.py)

@@ -32,7 +32,7 @@ def leg(args):
     from tests.procedural_scene import make_scene
     WH, NTRAIN, BATCH, CHUNK = 128, 100, 2, 4096
     ctx0 = KnerfContext(white_background=True)
-    o, d, t, img = make_scene(ctx0, WH, NTRAIN + 4, 1.0, compact=True)
+    o, d, t, img = make_scene(ctx0, WH, NTRAIN + 4, 1.6, compact=True)     # --scale 1.6: the setting of every round-2/3 convergence experiment
     ctx0.close()
     z = np.load(args.weights)
     nerf = NeRF()
@@ -69,7 +69,7 @@ def main():
         return leg(args)
     if not os.path.exists(args.weights):      # the checkpoint: 600 steps on the compact scene (dead tiles ~33 % from step 500 on)
         pre = args.weights[:-len(f"_step{args.train_steps}.npz")]
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convergence128.py"), "--backend", "hip", "--scene", "compact", "--skip-dead", "--lr", "5e-4",
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convergence128.py"), "--backend", "hip", "--scene", "compact", "--skip-dead", "--lr", "5e-4", "--scale", "1.6",
                                "--steps", str(args.train_steps), "--eval-every", str(args.train_steps), "--out", pre + "_log.json", "--save-weights", pre])
     res = {}
     for name, lib in (("default_a", None), ("nostores_a", args.lib_nostores), ("default_b", None), ("nostores_b", args.lib_nostores)):
