@@ -31,9 +31,9 @@ typedef enum knerf_status {
 /* NeRF(...) constructor arguments (reference nerf.py:11-14) + compile() arguments (nerf.py:78) + Adam defaults
  * of tf.keras.optimizers.get('adam') (nerf.py:163-165). */
 typedef struct knerf_config {
-    int32_t n_coarse, n_fine;          /* 64, 128 */
+    int32_t n_coarse, n_fine;          /* 64, 128; 2 <= n_coarse <= 512, n_coarse + n_fine <= 1024 */
     int32_t pos_emb_xyz, pos_emb_dir;  /* 10, 4   */
-    int32_t n_layers, dense_units, skip_layer; /* 8, 256, 4; fused kernels: the triples of csrc/layout.h KNERF_FUSED_SHAPES (widths 256, 128); others: csrc/generic.hip */
+    int32_t n_layers, dense_units, skip_layer; /* 8, 256, 4; fused kernels: the triples of csrc/layout.h KNERF_FUSED_SHAPES (widths 256, 128; 64 at build time); others: csrc/generic.hip */
     int32_t white_background;          /* compile(white_background=...) */
     int32_t oob_clamp;                 /* 0: out-of-range mid-point gather yields 0 (tf.gather on GPU); 1: clamp */
     float lr, beta1, beta2, epsilon;   /* 1e-3, 0.9, 0.999, 1e-7 */
