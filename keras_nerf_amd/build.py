@@ -26,7 +26,7 @@ SOURCES = ["knerf_api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "generic.
 # per shape with -DKNERF_SHAPE_SLICE=<index> (that translation unit then defines the kernels of its shape only; slice 0 also holds
 # the run-time dispatchers), so the shapes build in parallel and the default shape's object is what it was before the others existed.
 SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
-N_BUILTIN_SHAPES = 12   # = kNumBuiltinShapes (csrc/layout.h static_asserts it); knerf_api.hip checks the total against KNERF_N_SHAPE_SLICES
+N_BUILTIN_SHAPES = 14   # = kNumBuiltinShapes (csrc/layout.h static_asserts it); knerf_api.hip checks the total against KNERF_N_SHAPE_SLICES
 MAX_EXTRA_SHAPES = 36   # a build-time budget, not a limit of csrc/layout.h (one more instantiation of the three big kernels each)
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
@@ -145,7 +145,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), variant: str = 
         add_shapes = [os.environ["KNERF_ADD_SHAPES"]] if os.environ.get("KNERF_ADD_SHAPES") else []
     extra = parse_shapes(add_shapes)
     n_slices = N_BUILTIN_SHAPES + len(extra)
-    if extra:       # a function-like macro on the command line: KNERF_EXTRA_SHAPES(X) = X(12, NL, SK, U) X(13, ...) ...
+    if extra:       # a function-like macro on the command line: KNERF_EXTRA_SHAPES(X) = X(14, NL, SK, U) X(15, ...) ...
         defines = tuple(defines) + ("KNERF_EXTRA_SHAPES(X)=" + " ".join(f"X({N_BUILTIN_SHAPES + i}, {', '.join(str(x) for x in v)})" for i, v in enumerate(extra)),)
     objdir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     lib = LIB if not variant else os.path.join(HERE, f"libknerf_hip_{variant}.so")

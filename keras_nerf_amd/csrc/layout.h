@@ -104,9 +104,9 @@ using DefaultShape = Shape<8, 4>;
 // -DKNERF_SHAPE_SLICE=<index>, and a translation unit built that way defines the kernels of its own shape only (explicit
 // instantiation; `extern template` for the others) -- slice 0 also holds the run-time dispatchers.
 #define KNERF_BUILTIN_SHAPES(X) X(0, 8, 4, 256) X(1, 8, 2, 256) X(2, 6, 3, 256) X(3, 4, 2, 256) X(4, 12, 4, 256) X(5, 8, 3, 256) X(6, 8, 5, 256) \
-    X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128)
+    X(7, 6, 2, 256) X(8, 6, 4, 256) X(9, 10, 5, 256) X(10, 8, 4, 128) X(11, 4, 2, 128) X(12, 8, 4, 64) X(13, 4, 2, 64)
 // Further entries chosen at BUILD time: `python keras_nerf_amd/build.py --add-shape=NL,SK,U[,LX,LD] ...` defines KNERF_EXTRA_SHAPES(X) as
-// X(12, NL, SK, U) X(13, NL, SK, U, LX, LD) ... (indices continue the built-in list).  A triple the
+// X(14, NL, SK, U) X(15, NL, SK, U, LX, LD) ... (indices continue the built-in list).  A triple the
 // kernels do not cover fails to compile on Shape's static_assert; one that repeats an earlier entry is never selected.
 #ifndef KNERF_EXTRA_SHAPES
 #define KNERF_EXTRA_SHAPES(X)
@@ -116,7 +116,7 @@ using DefaultShape = Shape<8, 4>;
 constexpr int kNumBuiltinShapes = 0 KNERF_BUILTIN_SHAPES(KNERF_X);
 constexpr int kNumFusedShapes = 0 KNERF_FUSED_SHAPES(KNERF_X);
 #undef KNERF_X
-static_assert(kNumBuiltinShapes == 12, "keras_nerf_amd/build.py N_BUILTIN_SHAPES");
+static_assert(kNumBuiltinShapes == 14, "keras_nerf_amd/build.py N_BUILTIN_SHAPES");
 // index of a shape in that list, -1 when the fused kernels do not cover it (-> general-shape path)
 template <class S> constexpr bool shape_is(int n_layers, int skip_layer, int dense_units, int lx, int ld) {
     return n_layers == S::NL && skip_layer == S::SK && dense_units == S::U && lx == S::LX && ld == S::LD;

@@ -1,5 +1,5 @@
 """Helper of tests/test_gpu_variants.py::test_build_time_extra_shapes...: run with KNERF_LIB / KNERF_PROBE_LIB pointing at a library built
-with `build.py --add-shape=...`; for every entry behind the built-in twelve: the host tables are checked (tests/test_shape_tables.py) and
+with `build.py --add-shape=...`; for every entry behind the built-in ones: the host tables are checked (tests/test_shape_tables.py) and
 one JSON line is printed -- the entry, whether NeRF(...) with those arguments runs on the fused kernels, and its images / losses /
 gradients against the oracle (kernel arithmetic)."""
 import json
@@ -21,7 +21,8 @@ def main():
     from tests.test_gpu_train import flat, per_tensor_err
     from keras_nerf_amd import _lib
     from tests.test_shape_tables import _check_tables
-    k = 12
+    from keras_nerf_amd import build as B
+    k = B.N_BUILTIN_SHAPES          # the first build-time entry
     while True:
         try:
             info = [int(v) for v in D.debug_table(5, k)]

@@ -20,7 +20,7 @@ int main() {
     std::printf("%d %d\n", kNumBuiltinShapes, kNumFusedShapes);
     const int ids[4] = {fused_shape_id(6, 3, 128), fused_shape_id(8, 2, 128), fused_shape_id(8, 4, 256), fused_shape_id(7, 3, 256)};
     std::printf("%d %d %d %d %d %d\n", ids[0], ids[1], ids[2], ids[3], fused_shape_id(8, 4, 256, 12, 3), fused_shape_id(8, 4, 256, 12, 4));
-    for (int k = 12; k < kNumFusedShapes; ++k) {
+    for (int k = kNumBuiltinShapes; k < kNumFusedShapes; ++k) {
         const ShapeInfo& s = shape_info(k);
         std::printf("%d %d %d %d %d %d %d %d %d %d\n", s.n_layers, s.skip, s.units, s.param_count, s.fwd_blocks, s.bwd_blocks, s.n_jobs, s.lx, s.ld, s.act_blocks);
     }
@@ -48,12 +48,12 @@ def test_layout_header_with_extra_shapes(tmp_path):
     src = tmp_path / "shapes.cpp"
     src.write_text(PROG)
     exe = tmp_path / "shapes"
-    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(12, 6, 3, 128) X(13, 8, 2, 128) X(14, 8, 4, 256, 12, 3)",
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(14, 6, 3, 128) X(15, 8, 2, 128) X(16, 8, 4, 256, 12, 3)",
                         str(src), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
-    assert out[0].split() == ["12", "15"]
-    assert out[1].split() == ["12", "13", "0", "-1", "14", "-1"]
+    assert out[0].split() == ["14", "17"]
+    assert out[1].split() == ["14", "15", "0", "-1", "16", "-1"]
     for line, (nl, sk, u, lx, ld, qx, qd) in zip(out[2:5], ((6, 3, 128, 10, 4, 4, 2), (8, 2, 128, 10, 4, 4, 2), (8, 4, 256, 12, 3, 6, 2))):
         v = [int(x) for x in line.split()]
         cfg = O.NerfConfig(n_layers=nl, dense_units=u, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld)

@@ -23,7 +23,7 @@ from keras_nerf_amd.debug import debug_buffer
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(8, 2, 256), (6, 3, 256), (4, 2, 256), (12, 4, 256), (8, 3, 256), (8, 5, 256), (6, 2, 256), (6, 4, 256), (10, 5, 256), (8, 4, 128), (4, 2, 128)]
+SHAPES = [(8, 2, 256), (6, 3, 256), (4, 2, 256), (12, 4, 256), (8, 3, 256), (8, 5, 256), (6, 2, 256), (6, 4, 256), (10, 5, 256), (8, 4, 128), (4, 2, 128), (8, 4, 64), (4, 2, 64)]
 
 
 def _cfg(nl, sk, units=256):

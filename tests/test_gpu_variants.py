@@ -38,7 +38,7 @@ def test_compiler_tracked_fragment_loads_give_identical_bits():
 
 
 XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3",
-           "8,4,64", "4,2,64", "8,4,256,10,8", "8,4,128,10,6"]        # round 4: width 64 (--num_units 64), pos_emb_dir 5..8 (four head k-steps)
+           "6,3,64", "8,4,64,6,2", "8,4,256,10,8", "8,4,128,10,6"]    # round 4: width 64 (8/4 and 4/2 are built in), pos_emb_dir 5..8 (four head k-steps)
 
 
 def test_build_time_extra_shapes_run_on_the_fused_kernels():

@@ -23,17 +23,17 @@ def _n_shapes():
         n += 1
 
 
-def test_the_list_has_the_default_shape_first_and_both_widths():
+def test_the_list_has_the_default_shape_first_and_all_three_widths():
     n = _n_shapes()
-    assert n >= 12
+    assert n >= 14
     infos = [tuple(D.debug_table(5, k)[:3]) for k in range(n)]
     assert infos[0] == (8, 4, 256)
     assert len(set(infos)) == n                                   # no triple twice
-    assert {u for _, _, u in infos} == {256, 128}
-    assert (8, 4, 128) in infos and (4, 2, 128) in infos and (8, 2, 256) in infos and (12, 4, 256) in infos
+    assert {u for _, _, u in infos} == {256, 128, 64}
+    assert (8, 4, 64) in infos and (4, 2, 64) in infos and (8, 4, 128) in infos and (4, 2, 128) in infos and (8, 2, 256) in infos and (12, 4, 256) in infos
 
 
-@pytest.mark.parametrize("k", range(12))
+@pytest.mark.parametrize("k", range(14))
 def test_tables_of_shape(k):
     _check_tables(k)
 
