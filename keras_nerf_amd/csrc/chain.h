@@ -321,11 +321,25 @@ __device__ __forceinline__ void store16_wt(char* base, unsigned off, const u32x4
 #endif
 }
 
+#ifdef KNERF_ABLATE_HALF_SAVED
+// TIMING EXPERIMENT ONLY (r04, DESIGN.md 5.5: the ceiling of 8-bit saved tensors): a saved block keeps its 1 KiB slot but only
+// its first 512 bytes are written (8 B per lane), and wgrad fetches only every second block from HBM (wgrad_body.h KNERF_SRC_BLOCK) -- half the HBM bytes of every saved
+// activation / dZ tensor at an unchanged instruction count (the StoreSched tables stay valid).  The backward's RESULTS are garbage.
+__device__ __forceinline__ void store8_wt(char* base, unsigned off, const u32x4& v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 w = {v[0] ^ v[2], v[1] ^ v[3]};
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(w), "s"(base) : "memory");
+}
+#endif
 // saved B-operand block (layout.h saved_off): lane (h = lane>>5, s = lane&31) -> (2*(s ^ 4*(block&1)) + h) * 16.
 // `base` must be wave-uniform (it lives in SGPRs).
 __device__ __forceinline__ void store_block(char* base, int block, int lane, const bf16x8& v) {
     const int s = lane & 31, h = lane >> 5;
+#ifdef KNERF_ABLATE_HALF_SAVED
+    store8_wt(base, (unsigned)(block * kSavedBlockStride + (2 * (s ^ ((block & 1) << 2)) + h) * 8), __builtin_bit_cast(u32x4, v));
+#else
     store16_wt(base, (unsigned)(block * kSavedBlockStride + (2 * (s ^ ((block & 1) << 2)) + h) * 16), __builtin_bit_cast(u32x4, v));
+#endif
 }
 
 }  // namespace knerf

@@ -49,6 +49,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// which block of a staged run a copy fetches
+#ifdef KNERF_ABLATE_HALF_SAVED     // timing experiment only (chain.h store8_wt): every odd block is fetched from its even neighbour's
+#define KNERF_SRC_BLOCK(b) ((b) & ~1)   // address (an L2 hit: a sister wave reads it in the same iteration), so HBM delivers HALF the bytes at an unchanged instruction count
+#else
+#define KNERF_SRC_BLOCK(b) (b)
+#endif
+
 #ifdef KNERF_WGRAD_STAMPS   // diagnostic build only (tools/kbench.py --stamps): per-workgroup cycle totals of the loop phases
 __device__ unsigned long long g_wgrad_stamps[1024 * 8];
 __device__ __forceinline__ unsigned long long stamp() {
@@ -223,7 +230,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_IN; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_IN;
-            const int blk = (ok ? b : 0) + ((ok && b >= S::kKs) ? act_blk2 : act_blk);     // block of the tile's act run (h: S::kKs blocks)
+            const int blk = (ok ? KNERF_SRC_BLOCK(b) : 0) + ((ok && b >= S::kKs) ? act_blk2 : act_blk);     // block of the tile's act run (h: S::kKs blocks)
 #ifdef KNERF_ABLATE_ENC_IO     // timing experiment only: the enc / dir blocks come from tile 0 (L2 hits) -- what wgrad would gain if it re-derived them for free
             const bool is_enc = (blk >= S::kActEnc && blk < S::kActEnc + S::kEncQ) || blk >= S::kActDir;
             const char* base = is_enc ? a.act + lane * 16 : tile_in;
@@ -236,7 +243,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
             const bool ok = b < BLK_DZ;
-            glds16(src_dz + (ok ? b : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch), late);
+            glds16(src_dz + (ok ? KNERF_SRC_BLOCK(b) : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + (BLK_IN + b) * 1024 : scratch), late);
         }
     };
     f32x16 acc[NACC];
@@ -396,11 +403,11 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
         const char* src_dz = a.dz + dz_tile_off<S>((size_t)t) + (size_t)16 * kSavedBlockStride + lane * 16;
         const unsigned dst = smem_base + slot * TILE_BYTES;
         const bool ok = wave < BLK_IN;
-        glds16(src_in + (ok ? wave : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
+        glds16(src_in + (ok ? KNERF_SRC_BLOCK(wave) : 0) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(ok ? dst + wave * 1024 : scratch), late);
 #pragma unroll
         for (int r = 0; r < G_DZ; ++r) {
             const int b = r * kWgWaves + wave;
-            glds16(src_dz + b * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024), late);
+            glds16(src_dz + KNERF_SRC_BLOCK(b) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + (BLK_IN + b) * 1024), late);
         }
     };
     f32x16 acc[NACC];
@@ -525,7 +532,7 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int b = r * kWgWaves + wave;
-            glds16(src_in + b * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
+            glds16(src_in + KNERF_SRC_BLOCK(b) * kSavedBlockStride, __builtin_amdgcn_readfirstlane(dst + b * 1024), late);
         }
         const char* src_x = wave == 1 ? a.mask + mask_tile_off<S>((size_t)t) + (S::NL - 1) * kSavedBlockStride + lane * 16
                                       : a.dz + dz_tile_off<S>((size_t)t) + (size_t)S::kDzHead * kSavedBlockStride + lane * 16;

@@ -123,7 +123,7 @@ def test_fused_shape_deterministic_and_skipping_exact(nl, sk, units):
 
 def test_shapes_outside_the_fused_set_use_the_general_path():
     from keras_nerf_amd.runtime import KnerfContext
-    for kw in (dict(n_layers=8, dense_units=64, skip_layer=4), dict(n_layers=6, dense_units=128, skip_layer=3), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
+    for kw in (dict(n_layers=8, dense_units=96, skip_layer=4), dict(n_layers=6, dense_units=64, skip_layer=3), dict(n_layers=6, dense_units=128, skip_layer=3), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
                dict(n_layers=8, dense_units=256, skip_layer=4, pos_emb_xyz=6), dict(n_layers=7, dense_units=256, skip_layer=3)):
         ctx = KnerfContext(white_background=True, **kw)
         assert ctx.get_option("general_shape_path") == 1.0, kw

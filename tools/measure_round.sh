@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
-#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes
+#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -22,6 +22,13 @@ for st in $STAGES; do
     bound) # upper bound of a forward that does not save what the backward skips; needs libknerf_hip_nofwdstores.so
            timeout -k 10 600 python tools/fwd_save_bound.py --weights $OUT/fwd_bound_w_step600.npz > $OUT/fwd_save_bound.json 2> $OUT/fwd_save_bound.err || fault bound
            python -c "import json; r=json.loads(open('$OUT/fwd_save_bound.json').read().splitlines()[-1]); print('bound', r['summary'])" ;;
+    half)  # ceiling of 8-bit saved tensors: every saved activation / dZ block written and read at HALF its bytes, same
+           # instruction counts; needs `build.py --variant=halfsaved -DKNERF_ABLATE_HALF_SAVED`.  Alternating with the default library.
+           for k in 1 2; do for v in default halfsaved; do
+             lib=keras_nerf_amd/libknerf_hip.so; [ $v = halfsaved ] && lib=keras_nerf_amd/libknerf_hip_halfsaved.so
+             KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/half_${v}_$k.json 2> $OUT/half_${v}_$k.err || fault "half $v"
+             python -c "import json; l=json.load(open('$OUT/half_${v}_$k.json')); print('$v', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"
+           done; done ;;
     shapes) # the round-4 fused shapes (width 64, pos_emb_dir 8 / 6) against the general-shape kernels; needs libknerf_hip_xshape.so
            : > $OUT/shapes_kbench.jsonl
            for sh in 8,256,4,10,4 8,64,4,10,4 4,64,2,10,4 8,256,4,10,8 8,128,4,10,6; do
