@@ -23,6 +23,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 constexpr int kWgThreads = 512, kWgWaves = 8;
+#ifdef KNERF_ABLATE_HALF_WGRAD_MATH     // timing experiment only: one of a tile's two k-steps in the recomputing jobs as well
+constexpr int kWgKSteps = 1;
+#else
+constexpr int kWgKSteps = 2;            // k-steps of 16 samples per 32-sample tile
+#endif
 constexpr int kWgScratch = kWgWaves * 1024;   // landing zone of padding LDS-DMA copies (never read)
 
 // LDS-DMA of 16 B per lane, invisible to hipcc's wait-count pass (the builtin form makes it drain vmcnt(0) before
@@ -296,6 +301,12 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         constexpr bool kBoth = NACC <= 9;      // register budget: 16 NACC accumulators + 2 x 4 (NACC + 1) operands
         bf16x8 b0, b1, afr0[NACC], afr1[NACC];
         read_k(0, b0, afr0);
+#ifdef KNERF_ABLATE_HALF_WGRAD_MATH     // timing experiment only: half the transposed reads and MFMAs per tile, as an 8-bit
+        (void)b1; (void)afr1; (void)kBoth;       // operand format would need (v_mfma_f32_32x32x64_f8f6f4 contracts 64 samples in the time of two bf16 k-steps)
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr0[n], b0, acc[n], 0, 0, 0);
+        issue(t_next, nslot, true);
+#else
         if (kBoth) read_k(1, b1, afr1);
 #pragma unroll
         for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr0[n], b0, acc[n], 0, 0, 0);
@@ -303,6 +314,7 @@ __device__ __forceinline__ void wgrad_job_body(const WgradArgs& a, const int job
         if (!kBoth) read_k(1, b1, afr1);
 #pragma unroll
         for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr1[n], b1, acc[n], 0, 0, 0);
+#endif
 #else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -451,7 +463,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
         const char* dz_reg = smem + slot * TILE_BYTES + BLK_IN * 1024;
         const char* xr = xch + (int)(i & 1) * (kXch / 2);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < kWgKSteps; ++kk) {
             const bf16x8 b = tr_frag(dz_reg, wo, kk, lane_off);
             bf16x8 afr[NACC];
 #pragma unroll
@@ -584,7 +596,7 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
         f32x16 dzf; unsigned mw[16];
         dz7_mfma(smem + slot * TILE_BYTES + BLK_IN * 1024, dzf, mw);           // tile i+1 (past the end: the clamped re-read, unused)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < kWgKSteps; ++kk) {
             bf16x8 afr[NACC];
 #pragma unroll
             for (int n = 0; n < NI; ++n) afr[n] = tr_frag(in_reg, n, kk, lane_off);

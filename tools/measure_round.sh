@@ -24,8 +24,9 @@ for st in $STAGES; do
            python -c "import json; r=json.loads(open('$OUT/fwd_save_bound.json').read().splitlines()[-1]); print('bound', r['summary'])" ;;
     half)  # ceiling of 8-bit saved tensors: every saved activation / dZ block written and read at HALF its bytes, same
            # instruction counts; needs `build.py --variant=halfsaved -DKNERF_ABLATE_HALF_SAVED`.  Alternating with the default library.
-           for k in 1 2; do for v in default halfsaved; do
-             lib=keras_nerf_amd/libknerf_hip.so; [ $v = halfsaved ] && lib=keras_nerf_amd/libknerf_hip_halfsaved.so
+           # halfsaved2 (+ -DKNERF_ABLATE_HALF_WGRAD_MATH): also half the transposed reads and MFMAs per tile in the weight-gradient kernel
+           for k in 1 2; do for v in default halfsaved halfsaved2; do
+             lib=keras_nerf_amd/libknerf_hip.so; [ $v != default ] && lib=keras_nerf_amd/libknerf_hip_$v.so
              KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/half_${v}_$k.json 2> $OUT/half_${v}_$k.err || fault "half $v"
              python -c "import json; l=json.load(open('$OUT/half_${v}_$k.json')); print('$v', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"
            done; done ;;
