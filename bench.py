@@ -173,14 +173,8 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
     copied = [torch.cuda.Event(), torch.cuda.Event()]
     frames_out = []
 
-    blocking = args.render_readback == "blocking"
-
     def frame(i, k):
         o, d, t = rg(poses[i])
-        if blocking:         # round 3's loop, kept for the same-box A/B: all six outputs, two blocking pageable copies per frame
-            _, fine = nerf.predict_and_render_images((o[None], d[None], t[None]))
-            pinned[k][0].copy_(fine["image"].cpu()); pinned[k][1].copy_(fine["depth"].cpu()); copied[k].record()
-            return
         _, fine = nerf.predict_and_render_images((o[None], d[None], t[None]), outputs=("image", "depth"))
         rendered = torch.cuda.Event(); rendered.record()
         with torch.cuda.stream(copy_stream):
@@ -224,7 +218,7 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                           "unit": "frames/s", "n_gpus": world, "steps": n_frames, "warmup": args.warmup,
                           "ms_per_step": elapsed / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
-                          "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}", "readback": args.render_readback},
+                          "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}", "readback": "pinned double buffers on a side stream (tools/cfg5_readback_probe.py: A/B against blocking copies)"},
                           "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}), flush=True)
 
 
@@ -466,8 +460,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=2, help="--mode fit: timed epochs")
     ap.add_argument("--skip-dead-tiles", type=int, default=None, help="override the library default of the skip_dead_tiles option (0/1)")
     ap.add_argument("--deterministic", type=int, default=None, help="set the deterministic option (0/1): gradient sums without atomics")
-    ap.add_argument("--render-readback", default="pipelined", choices=["pipelined", "blocking"], help="cfg5: how a frame's image and depth reach the "
-                    "host: pinned double buffers on a side stream and only the two outputs computed (default), or round 3's blocking copies of the full dictionaries")
+    ap.add_argument("--ignore-nonfinite", action="store_true", help="TIMING EXPERIMENTS with ablation builds only (their gradients are garbage): "
+                    "a step skipped for a non-finite gradient is not reported -- it costs the same launches, the Adam kernels are predicated off")
     ap.add_argument("--check-replicas", type=int, default=None, help="after the timed region: exact weight checksum of every rank reduced "
                     "with MAX and MIN; `replica_drift` (must be 0.0) goes on the line.  Default: on for N > 1 (two one-word collectives, "
                     "outside every timed region), off for N = 1")
@@ -546,6 +540,8 @@ def run(args, world, rank, device_index, backend):
         if world > 1:
             rank_fail(rank, world, device_index, backend, "NeRF.compile (weight broadcast)", e)
         raise
+    if args.ignore_nonfinite:
+        nerf._ctx.poll_nonfinite = lambda wait=False: None
     if args.skip_dead_tiles is not None:
         nerf._ctx.set_option("skip_dead_tiles", args.skip_dead_tiles)
     if args.deterministic is not None:

@@ -27,7 +27,7 @@ for st in $STAGES; do
            # halfsaved2 (+ -DKNERF_ABLATE_HALF_WGRAD_MATH): also half the transposed reads and MFMAs per tile in the weight-gradient kernel
            for k in 1 2; do for v in default halfsaved halfsaved2; do
              lib=keras_nerf_amd/libknerf_hip.so; [ $v != default ] && lib=keras_nerf_amd/libknerf_hip_$v.so
-             KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/half_${v}_$k.json 2> $OUT/half_${v}_$k.err || fault "half $v"
+             KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --ignore-nonfinite --skip-dead-tiles 0 > $OUT/half_${v}_$k.json 2> $OUT/half_${v}_$k.err || fault "half $v"
              python -c "import json; l=json.load(open('$OUT/half_${v}_$k.json')); print('$v', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"
            done; done ;;
     shapes) # the round-4 fused shapes (width 64, pos_emb_dir 8 / 6) against the general-shape kernels; needs libknerf_hip_xshape.so
