@@ -331,6 +331,12 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal():
     if torch.cuda.device_count() < 2:
         r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=base)
         assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr
+    # the render loop (cfg5) with two ranks: every rank renders its own frames, rank 0 reports frames/s of both
+    cmd5 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "cfg5"]
+    r5 = subprocess.run(cmd5, capture_output=True, text=True, timeout=600, env=dict(base, KNERF_DIST_BACKEND="gloo"))
+    assert r5.returncode == 0, r5.stderr[-2000:]
+    line5 = json.loads([x for x in r5.stdout.splitlines() if x.startswith("{")][-1])
+    assert line5["n_gpus"] == 2 and line5["unit"] == "frames/s" and line5["value"] > 0 and line5["steps"] == 4
 
 
 def test_zero_gradient_diagnostics_eager_mode(caplog):
