@@ -85,7 +85,7 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
         zhead[2] = (__bf16)(dr[2] * raw[2] * (1.f - raw[2]));
         zhead[3] = (__bf16)(raw[3] > 0.f ? dr[3] : 0.f);
     }
-    char* dz = a.dz + dz_tile_off<S>((size_t)tile);
+    char* dz = a.dz + dz_tile_off<S>((size_t)KNERF_STORE_TILE(tile));
     store_block(dz, S::kDzHead, lane, zhead);     // block kDzHead+1 stays zero (the buffer is zero-initialised)
 
     asm volatile("" ::: "memory");            // the store above stays ahead of the first LDS-DMA in program order

@@ -311,6 +311,9 @@ __device__ __forceinline__ void dense_stage(const Ring& ring, Prefetch& pf, int 
 __device__ __forceinline__ void store16_wt(char* base, unsigned off, const u32x4& v) {
 #ifdef KNERF_ABLATE_STORES      // timing experiment only: keeps the value alive, skips the store
     asm volatile("" ::"v"(v));
+#elif defined(KNERF_ABLATE_STORE_EXEC0)   // timing experiment only (r04): the store is ISSUED (same vmcnt accounting, same address VALU) with no lane active -- no data leaves the CU
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0\n\tglobal_store_dwordx4 %1, %2, %3 nt\n\ts_mov_b64 exec, %0\n\ts_nop 1" : "=&s"(keep) : "v"(off), "v"(v), "s"(base) : "memory");
 #elif defined(KNERF_PLAIN_STORES)
     *reinterpret_cast<u32x4*>(base + off) = v;
 #else
@@ -330,6 +333,13 @@ __device__ __forceinline__ void store8_wt(char* base, unsigned off, const u32x4&
     const u32x2 w = {v[0] ^ v[2], v[1] ^ v[3]};
     asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(w), "s"(base) : "memory");
 }
+#endif
+// tile whose slot of the saved runs a chain wave writes: its own -- or, in a timing experiment, one of 256 slots that
+// stay resident in the caches, so that the stores travel the whole on-chip path but (mostly) not to HBM
+#ifdef KNERF_ABLATE_STORE_L2
+#define KNERF_STORE_TILE(tile) ((tile) & 255)
+#else
+#define KNERF_STORE_TILE(tile) (tile)
 #endif
 // saved B-operand block (layout.h saved_off): lane (h = lane>>5, s = lane&31) -> (2*(s ^ 4*(block&1)) + h) * 16.
 // `base` must be wave-uniform (it lives in SGPRs).

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 
     char* act = nullptr; char* maskp = nullptr;
     if (SAVE) {
-        act = a.act + act_tile_off<S>((size_t)tile);
-        maskp = a.mask + mask_tile_off<S>((size_t)tile);
+        act = a.act + act_tile_off<S>((size_t)KNERF_STORE_TILE(tile));
+        maskp = a.mask + mask_tile_off<S>((size_t)KNERF_STORE_TILE(tile));
 #ifndef KNERF_ABLATE_ENC_IO      // timing experiment only (with -DKNERF_CONSERVATIVE_WAIT): the upper bound of re-deriving the encodings in wgrad
 #pragma unroll
         for (int q = 0; q < QX; ++q) store_block(act, S::kActEnc + q, lane, enc[q]);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
-#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half
+#   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half stores
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -29,6 +29,14 @@ for st in $STAGES; do
              lib=keras_nerf_amd/libknerf_hip.so; [ $v != default ] && lib=keras_nerf_amd/libknerf_hip_$v.so
              KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --ignore-nonfinite --skip-dead-tiles 0 > $OUT/half_${v}_$k.json 2> $OUT/half_${v}_$k.err || fault "half $v"
              python -c "import json; l=json.load(open('$OUT/half_${v}_$k.json')); print('$v', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"
+           done; done ;;
+    stores) # what a chain kernel's saved-tensor stores cost and where: issued with no lane active (storeexec0: issue + vmcnt only),
+           # or into 256 cache-resident tile slots (storel2: the whole on-chip path, little HBM); `build.py --variant=storeexec0
+           # -DKNERF_ABLATE_STORE_EXEC0`, `--variant=storel2 -DKNERF_ABLATE_STORE_L2`.  Alternating with the default library.
+           for k in 1 2; do for v in default storeexec0 storel2; do
+             lib=keras_nerf_amd/libknerf_hip.so; [ $v != default ] && lib=keras_nerf_amd/libknerf_hip_$v.so
+             KNERF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --ignore-nonfinite --skip-dead-tiles 0 > $OUT/stores_${v}_$k.json 2> $OUT/stores_${v}_$k.err || fault "stores $v"
+             python -c "import json; l=json.load(open('$OUT/stores_${v}_$k.json')); print('$v', l['ms_per_step'], l['roofline']['kernel_ms_per_step'])"
            done; done ;;
     shapes) # the round-4 fused shapes (width 64, pos_emb_dir 8 / 6) against the general-shape kernels; needs libknerf_hip_xshape.so
            : > $OUT/shapes_kbench.jsonl
