@@ -105,3 +105,39 @@ def test_random_configuration_matches_oracle(case):
     assert ec[0] < tol and ef[0] < tol, (ec, ef)
     assert abs(float(loss[0]) - float(lc)) < 2e-3 and abs(float(loss[1]) - float(lf)) < 2e-3
     ctx.close()
+
+
+def test_more_chunks_per_batch_than_the_counter_ring_held():
+    """every list of live tiles takes a counter from a ring that held 4,096 of them and was re-zeroed on wrap-around -- also
+    while a GROUP's counter was still being appended to by later coarse passes, which would have dropped live tiles from that
+    group's coarse weight gradients once a batch had more than ~1,800 chunks.  The ring is now sized per call (2 C + C / G + 8,
+    grow-only).  2,200 chunks of 32 rays (train_single.py accepts any --ray_chunks that divides the batch): skipping on = skipping off
+    up to the order of the fp32 atomics, on weights that have dead tiles (sigma's bias lowered)."""
+    from keras_nerf_amd.runtime import KnerfContext
+    cfg = O.NerfConfig()
+    P = make_problem(n_images=1, wh=16, seed=9, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    names = [n for n, _, _ in O.layer_shapes(cfg)]
+    for params in (P["cp"], P["fp"]):
+        params[2 * names.index("sigma") + 1][:] = -0.35              # closes sigma's gate on part of the samples: dead tiles exist
+    C, rc = 2200, 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    idx = torch.randint(0, P["N"], (C * rc,), device="cuda", generator=g)
+    o, d, t, img, u = (torch.as_tensor(P[k].reshape(P["N"], -1), device="cuda")[idx].contiguous() for k in ("o", "d", "t", "img", "u"))
+    res = {}
+    for skip in (1, 0):
+        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip))
+        ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+        loss = torch.zeros(2, device="cuda")
+        ctx.train_batch(o, d, t, img, u, ray_chunks=rc, loss=loss)
+        torch.cuda.synchronize()
+        live, total = ctx.tile_stats()
+        res[skip] = (ctx.grads_view().clone(), loss.clone(), live, total)
+        assert ctx.get_option("wgrad_group") == 4
+        ctx.close()
+    assert res[1][3] == C * rc * (64 + 192) // 32 and 0 < res[1][2] < res[1][3]          # every pass was listed; some tiles are dead
+    n = res[0][0].numel() // 2
+    for sl in (slice(0, n), slice(n, 2 * n)):
+        rel = float((res[1][0][sl] - res[0][0][sl]).abs().max() / res[0][0][sl].abs().max())
+        assert rel < 1e-4, rel                                        # a zeroed group counter showed as missing coarse contributions (percent level)
+    assert torch.allclose(res[1][1], res[0][1], rtol=1e-5)
+    log_stats("counter_ring_2200_chunks", dead=1.0 - res[1][2] / res[1][3])

@@ -218,3 +218,31 @@ def test_nerfmlp_initializer_names_follow_keras():
     assert float(c.get_weights()[0][0, 0]) == 0.25
     with pytest.raises(ValueError):
         NeRFMLP(initializer="orthogonal")
+
+
+def test_bench_quotes_pmc_traffic_of_the_instantiation_it_ran_only():
+    """`roofline.traffic` must come from counters of the kernel instantiation the bench ran.  The weight-gradient
+    kernel has a list-mode instantiation (`wgrad_kernel<Shape, NET, true>`, skip_dead_tiles on: what bench.py runs by default) and a
+    contiguous one; bench.pmc_traffic returns the committed summary that holds the matching row, never the other one's."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("knerf_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    for kernel in ("wgrad_fine", "wgrad_coarse", "mlp_bwd_fine", "mlp_fwd_fine"):
+        for skip in (True, False):
+            val, src = b.pmc_traffic(kernel, skip)
+            assert val and src, (kernel, skip)
+            rep = json.load(open(os.path.join(root, src)))
+            assert rep["_layout"] == b.LAYOUT_TAG
+            rows = [k for k, v in rep.items() if isinstance(v, dict) and v.get("hbm_bytes_per_launch") == val]
+            assert rows, (kernel, skip, src)
+            if kernel.startswith("wgrad"):
+                assert all(k.split(" grid=")[0].endswith(", true>" if skip else ", false>") for k in rows), (rows, skip)
+            if kernel.startswith("mlp_bwd"):
+                assert bool(rep.get("_options", {}).get("skip_dead_tiles")) == skip
+    # algorithmic bytes of the dominant kernel against the counters of its own instantiation: nothing re-read
+    val, _ = b.pmc_traffic("wgrad_fine", True)
+    assert 1.0 < val / (24576 * b.WGRAD_KIB_PER_TILE * 1024) < 1.05
+    assert b.pmc_traffic("composite", True) == (None, None)
