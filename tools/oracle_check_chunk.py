@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""One coarse + fine train chunk at the BENCH's chunk size (4,096 rays: 8,192 + 24,576 sample tiles, the launch sizes bench.py
+times) against the oracle, per gradient tensor -- the one-off, minutes-long big brother of tests/test_gpu_wgrad_regime.py (1,024
+rays).  The NumPy oracle (kernel arithmetic, oracle/nerf_oracle.py FUSED) runs in sub-batches of --sub rays to bound its memory:
+the chunk's loss is the mean over its rays, so its gradient is the ray-weighted mean of the sub-batches' gradients.
+
+    python tools/oracle_check_chunk.py [--rays 4096] [--sub 512]  ->  one JSON line (profiles/r04_oracle_check_4096_rays.json)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from keras_nerf_amd.debug import debug_buffer  # noqa: E402
+from keras_nerf_amd.runtime import KnerfContext  # noqa: E402
+from oracle import nerf_oracle as O  # noqa: E402  (a checking tool: the oracle is the checker, never the product)
+from tests.problem import make_problem  # noqa: E402
+from tests.test_gpu_train import per_tensor_err  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--sub", type=int, default=512)
+    args = ap.parse_args()
+    wh = int(round(args.rays ** 0.5))
+    assert wh * wh == args.rays and args.rays % args.sub == 0
+    P = make_problem(n_images=1, wh=wh, weight_scale=1.5, bias_std=0.05)
+    cfg, N = P["cfg"], P["N"]
+    o, d, t, u, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["u"].reshape(N, -1), P["img"].reshape(N, 3)
+    out = {"rays": N, "tiles": {"coarse": N * 64 // 32, "fine": N * 192 // 32}}
+    got = {}
+    for skip in (1, 0):
+        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip))
+        ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+        loss = torch.zeros(2, device="cuda")
+        ci = torch.empty((N, 3), device="cuda"); fi = torch.empty_like(ci)
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
+        torch.cuda.synchronize()
+        got[skip] = dict(g=ctx.grads_view().cpu().numpy().copy(), loss=loss.cpu().numpy().copy(), ci=ci.cpu().numpy(), fi=fi.cpu().numpy(),
+                         t_fine=debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * 192].reshape(N, 192).copy())
+        n = ctx.param_count
+        ctx.close()
+    t0 = time.time()
+    ref = {}
+    for net, (params, tt) in enumerate(((P["cp"], t), (P["fp"], got[1]["t_fine"]))):
+        gsum, lsum, img_err = None, 0.0, 0.0
+        for s0 in range(0, N, args.sub):
+            sl = slice(s0, s0 + args.sub)
+            r, l, gr = O.chunk_loss_and_grads(params, o[sl], d[sl], tt[sl], img[sl], cfg, True, emulate_bf16=O.FUSED)
+            g = O.flatten_params(gr).astype(np.float64) * (args.sub / N)
+            gsum = g if gsum is None else gsum + g
+            lsum += float(l) * args.sub / N
+            img_err = max(img_err, float(np.abs((got[1]["ci"] if net == 0 else got[1]["fi"])[sl] - r["image"]).max()))
+        ref[net] = (gsum.astype(np.float32), lsum, img_err)
+    out["oracle_seconds"] = round(time.time() - t0, 1)
+    for skip in (1, 0):
+        g = got[skip]["g"]
+        ec, ef = per_tensor_err(g[:n], ref[0][0], cfg), per_tensor_err(g[n:], ref[1][0], cfg)
+        out[f"skip_dead_tiles_{skip}"] = {"coarse_worst": ec[0], "coarse_where": ec[1], "fine_worst": ef[0], "fine_where": ef[1],
+                                          "loss_err": [abs(float(got[skip]["loss"][k]) - ref[k][1]) for k in (0, 1)]}
+    out["image_max_abs_err"] = [ref[0][2], ref[1][2]]
+    out["list_vs_contiguous_rel"] = float(np.abs(got[0]["g"] - got[1]["g"]).max() / np.abs(got[1]["g"]).max())
+    out["ok"] = all(out[f"skip_dead_tiles_{s}"][k] < 1.5e-2 for s in (0, 1) for k in ("coarse_worst", "fine_worst"))
+    print(json.dumps(out), flush=True)
+    sys.exit(0 if out["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()
