@@ -63,3 +63,27 @@ def test_1024_ray_chunk_list_and_contiguous_wgrad_meet_the_oracle():
     rel = np.abs(got[0]["g"] - got[1]["g"]).max() / np.abs(got[1]["g"]).max()
     log_stats("wgrad_regime_list_vs_contiguous", rel=rel)
     assert rel < 1e-4
+
+
+def test_4096_ray_chunk_the_bench_launch_sizes_meet_the_oracle():
+    """The chunk bench.py times -- 4,096 rays: 8,192 coarse + 24,576 fine tiles per launch, ~900 tiles per weight-gradient workgroup of a
+    256 x 256 job -- per gradient tensor against the oracle (tools/oracle_check_chunk.py: the oracle runs in sub-batches of 512 rays
+    to bound its memory; ~1.5 min of host time on the GPU box).  Measured (round 4): 6.9e-4 coarse / 1.0e-3 fine of each tensor's
+    max |g| in both list and contiguous mode, images 1.2e-3 / 1.7e-3."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_check_chunk.py"), "--rays", "4096", "--sub", "512"],
+                       capture_output=True, text=True, timeout=1200)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert lines, r.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert r.returncode == 0 and out["ok"], out
+    assert out["tiles"] == {"coarse": 8192, "fine": 24576}
+    for skip in (1, 0):
+        z = out[f"skip_dead_tiles_{skip}"]
+        log_stats(f"wgrad_regime_4096_rays_skip_dead_tiles_{skip}", coarse_worst=z["coarse_worst"], fine_worst=z["fine_worst"])
+        assert z["coarse_worst"] < GRAD_TOL_EMU and z["fine_worst"] < GRAD_TOL_EMU and max(z["loss_err"]) < 2e-3
+    assert max(out["image_max_abs_err"]) < 1e-2 and out["list_vs_contiguous_rel"] < 1e-4
