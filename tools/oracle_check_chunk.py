@@ -27,10 +27,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--sub", type=int, default=512)
+    ap.add_argument("--batch", default=None, help="IMAGES,WH,RAY_CHUNKS: a whole train_batch instead of one chunk, e.g. 2,128,4096 = BASELINE cfg2's step "
+                                                  "(8 chunks, grouped coarse weight-gradient launches); the oracle then needs ~12 min of host time")
     args = ap.parse_args()
-    wh = int(round(args.rays ** 0.5))
-    assert wh * wh == args.rays and args.rays % args.sub == 0
-    P = make_problem(n_images=1, wh=wh, weight_scale=1.5, bias_std=0.05)
+    n_images, ray_chunks = 1, None
+    if args.batch:
+        n_images, wh, ray_chunks = (int(v) for v in args.batch.split(","))
+        args.rays = n_images * wh * wh
+    else:
+        wh = int(round(args.rays ** 0.5))
+    assert n_images * wh * wh == args.rays and args.rays % args.sub == 0
+    P = make_problem(n_images=n_images, wh=wh, weight_scale=1.5, bias_std=0.05)
     cfg, N = P["cfg"], P["N"]
     o, d, t, u, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["u"].reshape(N, -1), P["img"].reshape(N, 3)
     out = {"rays": N, "tiles": {"coarse": N * 64 // 32, "fine": N * 192 // 32}}
@@ -40,10 +47,23 @@ def main():
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         loss = torch.zeros(2, device="cuda")
         ci = torch.empty((N, 3), device="cuda"); fi = torch.empty_like(ci)
-        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
-        torch.cuda.synchronize()
-        got[skip] = dict(g=ctx.grads_view().cpu().numpy().copy(), loss=loss.cpu().numpy().copy(), ci=ci.cpu().numpy(), fi=fi.cpu().numpy(),
-                         t_fine=debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * 192].reshape(N, 192).copy())
+        if ray_chunks:           # the whole chunk loop of a train step (knerf_train_batch: gradients accumulated with weight 1 / C)
+            ctx.train_batch(o, d, t, img, u, ray_chunks=ray_chunks, loss=loss, c_image=ci, f_image=fi)
+            torch.cuda.synchronize()
+            g_now = ctx.grads_view().cpu().numpy().copy()
+            # the merged t-values of every chunk: the sampler is bit-exact and the weights have not moved, so a render of the same
+            # rays with the same u reproduces them (the last chunk's are still in the training workspace: compared below)
+            tf_all = ctx.render_batch(o, d, t, u, ray_chunks=ray_chunks, out=dict(c_image=torch.empty_like(ci), f_image=torch.empty_like(fi),
+                                      t_fine=torch.empty((N, 192), device="cuda")))["t_fine"].cpu().numpy()
+            last = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:ray_chunks * 192].reshape(ray_chunks, 192)
+            out["t_fine_of_render_equals_training"] = bool(np.array_equal(tf_all[-ray_chunks:], last))
+            out["wgrad_group"] = ctx.get_option("wgrad_group")
+        else:
+            ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
+            torch.cuda.synchronize()
+            g_now = ctx.grads_view().cpu().numpy().copy()
+            tf_all = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * 192].reshape(N, 192).copy()
+        got[skip] = dict(g=g_now, loss=loss.cpu().numpy().copy(), ci=ci.cpu().numpy(), fi=fi.cpu().numpy(), t_fine=tf_all)
         n = ctx.param_count
         ctx.close()
     t0 = time.time()
@@ -57,6 +77,7 @@ def main():
             gsum = g if gsum is None else gsum + g
             lsum += float(l) * args.sub / N
             img_err = max(img_err, float(np.abs((got[1]["ci"] if net == 0 else got[1]["fi"])[sl] - r["image"]).max()))
+            print(f"oracle net {net} rays {s0 + args.sub}/{N} {time.time() - t0:.0f}s", file=sys.stderr, flush=True)
         ref[net] = (gsum.astype(np.float32), lsum, img_err)
     out["oracle_seconds"] = round(time.time() - t0, 1)
     for skip in (1, 0):
