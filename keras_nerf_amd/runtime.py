@@ -61,6 +61,15 @@ class KnerfContext:
             self._ctx = C.c_void_p()
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
         self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
+        if not force_generic and self.get_option("general_shape_path"):
+            # a shape outside the library's list: say what it costs and, where the fused kernels could cover it, how to get them
+            import logging
+            coverable = (dense_units in (64, 128, 256) and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
+                         and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8)
+            spec = f"{n_layers},{skip_layer},{dense_units}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
+            logging.info("NeRFMLP(n_layers=%d, dense_units=%d, skip_layer=%d), pos_emb %d/%d runs on the general-shape kernels (about 3x slower per "
+                         "FLOP than the fused chain)%s", n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir,
+                         f"; `python keras_nerf_amd/build.py --add-shape={spec}` builds the fused kernels for it" if coverable else "")
         opts = {}
         env = os.environ
         for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),
