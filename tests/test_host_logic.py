@@ -246,3 +246,41 @@ def test_bench_quotes_pmc_traffic_of_the_instantiation_it_ran_only():
     val, _ = b.pmc_traffic("wgrad_fine", True)
     assert 1.0 < val / (24576 * b.WGRAD_KIB_PER_TILE * 1024) < 1.05
     assert b.pmc_traffic("composite", True) == (None, None)
+
+
+def test_zero_gradient_messages_are_the_references(caplog):
+    """nerf.py:430-451: the three log lines, their levels, and 'once per published step' -- the host side of the device-side count,
+    driven by a stand-in context (the GPU test drives the real one)."""
+    import logging
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+
+    class Ctx:
+        def __init__(self):
+            self.seq, self.counts, self.stats = 0, (1, 1), ((5, 10), (7, 10))
+
+        def grad_diagnostics(self, wait=True):
+            return self.counts[0], self.counts[1], self.seq
+
+        def get_option(self, name):
+            return 1.0
+
+        def tile_stats_net(self, reset=True):
+            return self.stats
+    nerf = NeRF.__new__(NeRF)
+    nerf._ctx, nerf._diag_seen = Ctx(), 0
+    assert nerf._zero_gradient_diagnostics(wait=True) is None                      # nothing published yet
+    for counts, stats, want in (((0, 0), ((0, 8), (0, 24)), [(logging.ERROR, "Both Coarse and Fine Gradient are zero")]),
+                                ((0, 9), ((0, 8), (3, 24)), [(logging.WARNING, "Coarse Gradient is zero")]),
+                                ((4, 0), ((2, 8), (0, 24)), [(logging.WARNING, "Fine Gradient is zero")]),
+                                ((4, 9), ((2, 8), (3, 24)), [])):
+        nerf._ctx.seq += 1; nerf._ctx.counts, nerf._ctx.stats = counts, stats
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            assert nerf._zero_gradient_diagnostics(wait=True) == counts
+            assert nerf._zero_gradient_diagnostics(wait=True) is None              # the same step is not reported twice
+        got = [(r.levelno, r.getMessage()) for r in caplog.records]
+        for w in want:
+            assert w in got, (counts, got)
+        assert len([g for g in got if "Gradient" in g[1]]) == len(want)
+        dead = [g[1] for g in got if "Every sample tile" in g[1]]
+        assert len(dead) == sum(1 for live, total in stats if total > 0 and live == 0), (stats, dead)
