@@ -639,6 +639,17 @@ def run(args, world, rank, device_index, backend):
         roofline["avg_launch_ms"] = avg_ms
         roofline["launches"] = cnt
         roofline["kernel_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof.items()}
+        # the other big kernels against the same roof, algorithmic bytes per 32-sample tile: the training forward
+        # WRITES act + masks, dgrad writes dZ and reads masks + raw/draw, wgrad reads act + dZ (+ its re-reads).  The chain kernels are
+        # write-bound (the write path of this chip reaches ~5.4 TB/s in a bare probe), wgrad read-bound.
+        per_tile_kib = {"mlp_fwd": ACT_KIB + MASK_KIB + 0.5, "mlp_bwd": DZ_KIB + MASK_KIB + 1.0, "wgrad": WGRAD_KIB_PER_TILE}
+        roofline["kernels"] = {}
+        for k, (ms_k, cnt_k) in prof.items():
+            base = k.rsplit("_", 1)[0]
+            if base in per_tile_kib and cnt_k:
+                tiles_k = 2 * n_rays * (nerf.n_coarse if k.endswith("coarse") else nerf.n_coarse + nerf.n_fine) / 32 / cnt_k
+                gbs = tiles_k * per_tile_kib[base] * 1024 / (ms_k / cnt_k * 1e-3) / 1e9
+                roofline["kernels"][k] = {"avg_launch_ms": round(ms_k / cnt_k, 4), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
         roofline["step_train_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP / (elapsed / args.steps) / 1e12
         roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
         roofline["step_executed_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP_EXEC / (elapsed / args.steps) / 1e12
