@@ -586,7 +586,8 @@ def run(args, world, rank, device_index, backend):
     # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step), bracketed by the
     # plain loop before (the timed region above) and once more after it, so that clock drift does not pass for a difference
     # (these two loops run about 3 s each, at most 100 steps: two 20-step loops repeat to +-0.15 ms only, which is the size of the effect)
-    n_cmp = max(args.steps, min(100, int(3.0 / max(local_elapsed / args.steps, 1e-3))))
+    # from `elapsed`, the max over ranks: EVERY rank must run the same number of steps (each one holds an all-reduce)
+    n_cmp = max(args.steps, min(100, int(3.0 / max(elapsed / args.steps, 1e-3))))
 
     def loop(**kw):
         for _ in range(2):
