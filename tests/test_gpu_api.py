@@ -436,29 +436,30 @@ def _bench(args, env_extra, timeout=900):
                           env=dict(base, **env_extra))
 
 
-def test_cfg4_rehearsal_four_ranks_on_one_gpu_replicas_stay_identical():
-    """cfg4 (BASELINE configs[3]: one 128 x 128 image per GPU, 8 GPUs) as far as a one-GPU box allows: FOUR ranks share this device
-    over gloo (the pool admits at most six GPU processes of one user at a time, and this test process is one of them; eight ranks
-    are rehearsed on the CPU by tests/test_dp_gloo.py).  Every rank draws its OWN initial weights (seed 100 + rank), so the line's
+def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
+    """cfg4 (BASELINE configs[3]: one 128 x 128 image per GPU, 8 GPUs) as far as a one-GPU box allows: THREE ranks share this device
+    over gloo.  The pool kills a run in which more than six processes of one user have the GPU open: this test process, the launcher
+    and the ranks all count (four ranks ran at exactly six in round 4, a six-rank run was killed at seven), so three leaves a margin
+    of one; eight ranks are rehearsed on the CPU by tests/test_dp_gloo.py.  Every rank draws its OWN initial weights (seed 100 + rank), so the line's
     `replica_drift` == 0 proves the broadcast of NeRF.compile, the SUM all-reduce of every step and identical Adam updates on all
     ranks (train.py:75-93, 130-157); rank 0's line carries the collective's time and size; every rank says which device it sits on
     and how much of it is free; the launch environment (MASTER_ADDR, HSA_ENABLE_IPC_MODE_LEGACY) is NOT provided by the caller."""
     import json
-    r = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline"], {"KNERF_DIST_BACKEND": "gloo"})
+    r = _bench(["--gpus", "3", "--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline"], {"KNERF_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    assert line["n_gpus"] == 4 and line["dist_backend"] == "gloo" and line["config"]["parallelism"] == "dp4" and line["config"]["global_batch_images"] == 4
+    assert line["n_gpus"] == 3 and line["dist_backend"] == "gloo" and line["config"]["parallelism"] == "dp3" and line["config"]["global_batch_images"] == 3
     assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
     assert line["grad_bytes"] == 2 * 595844 * 4 and line["allreduce_ms_per_step"] > 0
     assert line["value"] > 0 and line["scaling"] == "weak"
-    for k in range(4):
-        assert f"[bench rank {k}/4] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
-        assert f"[bench rank {k}/4] device memory free" in r.stderr
+    for k in range(3):
+        assert f"[bench rank {k}/3] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
+        assert f"[bench rank {k}/3] device memory free" in r.stderr
     # the same through NeRF.fit (loader slices of the global batch, metrics, monitor on rank 0, barrier at epoch end)
-    r = _bench(["--gpus", "4", "--mode", "fit", "--config", "cfg4", "--epochs", "1"], {"KNERF_DIST_BACKEND": "gloo"})
+    r = _bench(["--gpus", "3", "--mode", "fit", "--config", "cfg4", "--epochs", "1"], {"KNERF_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    assert line["n_gpus"] == 4 and line["replica_drift"] == 0.0 and line["steps"] == 25 and line["value"] > 0      # 100 views / 4 ranks
+    assert line["n_gpus"] == 3 and line["replica_drift"] == 0.0 and line["steps"] == 33 and line["value"] > 0      # 100 views = 33 global batches of 3
 
 
 def test_a_failing_rank_ends_the_run_at_once_with_its_name():
