@@ -130,17 +130,17 @@ def sync(world):
         torch.cuda.synchronize()
 
 
-RANK_ELAPSED = []      # fastest and slowest rank's elapsed time of the last timed region (filled by max_over_ranks)
+RANK_ELAPSED = []      # every rank's elapsed time of the last timed region, in rank order (filled by max_over_ranks)
 
 
 def max_over_ranks(elapsed, world):
     RANK_ELAPSED[:] = [elapsed]
-    if world > 1:          # all_reduce is the one collective both RCCL and gloo run on device tensors
-        hi = torch.tensor([elapsed], device="cuda", dtype=torch.float64); lo = hi.clone()
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        RANK_ELAPSED[:] = [float(lo[0]), float(hi[0])]
-        elapsed = float(hi[0])
+    if world > 1:          # all_reduce is the one collective both RCCL and gloo run on device tensors: rank r fills slot r, SUM
+        every = torch.zeros(world, device="cuda", dtype=torch.float64)
+        every[torch.distributed.get_rank()] = elapsed
+        torch.distributed.all_reduce(every)
+        RANK_ELAPSED[:] = [float(v) for v in every.cpu()]
+        elapsed = max(RANK_ELAPSED)
     return elapsed
 
 
@@ -148,7 +148,7 @@ def dist_fields(world, backend, steps):
     per = [e / steps * 1e3 for e in RANK_ELAPSED]
     return {"rccl_ranks": torch.distributed.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
             "dist_backend": backend if world > 1 else None,
-            "ms_per_step_rank_min": min(per), "ms_per_step_rank_max": max(per)}
+            "ms_per_step_rank_min": min(per), "ms_per_step_rank_max": max(per), "ms_per_step_by_rank": [round(v, 4) for v in per]}
 
 
 def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
@@ -312,7 +312,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
         nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)
     except Exception as e:                     # noqa: BLE001
         if world > 1:
-            rank_fail(rank, world, torch.cuda.current_device(), backend, "NeRF.compile (weight broadcast)", e)
+            rank_fail("NeRF.compile (weight broadcast)", e)
         raise
     monitor = NeRFTrainMonitor(test, os.path.join(root, "log"), batch, update_freq=1, plots=False)
     marks = []
@@ -352,10 +352,13 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     sync(world); ts = (time.perf_counter() - t0) / 20
     for _ in range(3):
         nerf.train_step(data, sync=False)
+    nerf._metric_state.events = []               # HIP events around the three metric launches of every step (metrics.py)
     sync(world); t0 = time.perf_counter()
     for _ in range(20):
         nerf.train_step(data, sync=False)
     sync(world); tm = (time.perf_counter() - t0) / 20
+    ev, nerf._metric_state.events = nerf._metric_state.events, None
+    metrics_ms = sum(a_.elapsed_time(b_) for a_, b_ in ev) / max(len(ev), 1)
     # ... and what fit delivers with skipping on (the default), at this point of the training
     nerf._ctx.set_option("skip_dead_tiles", 1)
     skip_ms = dead_fit = None
@@ -377,7 +380,8 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": f"{args.config} through NeRF.fit: {desc}; 100 procedural training views in nerf_synthetic layout, "
                                                  f"{steps} steps per epoch, {args.epochs} timed epochs after one warm-up epoch", "parallelism": f"dp{world}"},
-                          "train_step_ms": ts * 1e3, "train_step_with_metrics_ms": tm * 1e3, "metrics_ms_per_step": (tm - ts) * 1e3,
+                          "train_step_ms": ts * 1e3, "train_step_with_metrics_ms": tm * 1e3, "metrics_ms_per_step": metrics_ms,
+                          "metrics_clock": "hip events around the 3 metric launches, mean of 20 steps",
                           "fit_vs_train_step": (loop / (steps * args.epochs)) and ts / (loop / (steps * args.epochs)),
                           "options_during_comparison": {"skip_dead_tiles": False, "deterministic": False},
                           "fit_ms_per_step_with_skip_dead_tiles": skip_ms, "dead_tile_frac_that_epoch": dead_fit,
@@ -391,30 +395,18 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def dist_env():
-    """The environment every rank needs, whichever way it was started (self-spawned or under an external torch.distributed.run):
-    rendezvous on 127.0.0.1 (the container's hostname may not resolve) and dmabuf IPC (the host driver supports nothing else:
-    without it RCCL fails with `hipIpcGetMemHandle: invalid argument`).  Called before anything touches HIP; existing values win."""
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def rank_fail(what, exc):
+    """keras_nerf_amd/parallel.py rank_fail under this script's tag: the rank names itself, prints the tail of its RCCL warnings
+    and leaves with exit code 3; the launcher stops the others"""
+    from keras_nerf_amd import parallel
+    parallel.rank_fail(what, exc, tag="bench")
 
 
-def rank_fail(rank, world, device_index, backend, what, exc):
-    """A rank that cannot join or use the process group says so and leaves with exit code 3 -- the launcher then stops the other
-    ranks -- instead of letting them sit in a collective until its time-out.  Never re-execs (the process has initialised the GPU)."""
-    import traceback
-    print(f"[bench rank {rank}/{world}] FAILED in {what} on cuda:{device_index} (backend {backend}): {type(exc).__name__}: {exc}\n"
-          f"{traceback.format_exc()}", file=sys.stderr, flush=True)
-    sys.stderr.flush(); sys.stdout.flush()
-    os._exit(3)
-
-
-def inject(stage, rank):
+def inject(stage):
     """fault injection for the fail-fast test (tests/test_gpu_api.py): KNERF_BENCH_INJECT_FAILURE="<rank>:<stage>" makes that rank
     raise at that stage (init | first_all_reduce | compile | warmup)"""
-    spec = os.environ.get("KNERF_BENCH_INJECT_FAILURE", "")
-    if spec and spec == f"{rank}:{stage}":
-        raise RuntimeError(f"injected failure at stage '{stage}'")
+    from keras_nerf_amd import parallel
+    parallel.inject(stage)
 
 
 def replica_drift(nerf, world):
@@ -431,20 +423,36 @@ def replica_drift(nerf, world):
     return float(int(hi[0]) - int(lo[0])), int(chk[0])
 
 
-def spawn_ranks(args, backend, n_dev):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
-    rendezvous on 127.0.0.1), wait, exit with their code.  Rank 0's JSON line goes to the inherited stdout.  The parent has
-    not initialised HIP and replaces no process (children, not exec)."""
-    import socket
-    import subprocess
-    if backend == "nccl" and n_dev < args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
-                         f"(KNERF_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    raise SystemExit(subprocess.run(cmd, env=dict(os.environ)).returncode)      # dist_env() has run: the children inherit it
+def allreduce_selftest(nerf, world, backend, n=20):
+    """N > 1, before the timed region: `n` stand-alone all-reduces of the REAL operand (the library-owned 4.77 MB gradient buffer;
+    all zeros at this point, so the sums change nothing) with HIP events on the stream the collective runs on -- the first RCCL run
+    with N > 1 happens on the driver's node with nobody to debug it, so the line itself must say whether the collective is healthy:
+    min / median microseconds, the implied bus bandwidth of a ring (2 (N-1)/N x bytes / time; one xGMI link is ~153 GB/s peak per
+    direction), RCCL's version.  Under gloo (rehearsal) the collective is synchronous on the host: wall clock is reported beside it."""
+    g = nerf._ctx.grads_view()
+    byts = int(g.numel()) * 4
+    for _ in range(3):
+        torch.distributed.all_reduce(g)
+    torch.cuda.synchronize()
+    ev, wall = [], []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(); torch.distributed.all_reduce(g); e1.record()
+        if backend != "nccl":
+            torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e6); ev.append((e0, e1))
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b_) * 1e3 for a, b_ in ev)
+    assert float(g.abs().max()) == 0.0          # the accumulators were zero and still are
+    med = statistics.median(us if backend == "nccl" else wall)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                            # noqa: BLE001
+        ver = None
+    return {"allreduce_us_standalone": {"min": us[0], "median": statistics.median(us), "max": us[-1], "n": n, "clock": "hip events on the collective's stream",
+                                        "host_wall_us_median": statistics.median(wall)},
+            "allreduce_busbw_GBps": byts * 2 * (world - 1) / world / (med * 1e-6) / 1e9, "rccl_version": ver}
 
 
 def main():
@@ -468,55 +476,30 @@ def main():
     args = ap.parse_args()
     if args.check_replicas is None:
         args.check_replicas = int(args.gpus > 1)
-    dist_env()                                 # the same environment for self-spawned ranks and for ranks of an external launcher
+    from keras_nerf_amd import parallel
+    # the same environment for self-spawned ranks and for ranks of an external launcher (MASTER_ADDR, dmabuf IPC; N > 1: RCCL's
+    # warnings to one file per rank, printed by a rank that fails)
+    parallel.dist_env(args.gpus)
 
     # KNERF_DIST_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("KNERF_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()          # counts devices without initialising the GPU
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        spawn_ranks(args, backend, n_dev)      # never returns; nothing in this process has touched the GPU
+        # `python bench.py --gpus N` without a launcher: keras_nerf_amd.parallel.launch re-runs this script as N rank processes
+        # (children started before this process touches the GPU, never an exec), waits, and exits with their code
+        parallel.launch(None, args.gpus, backend=backend)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py either plainly (it spawns its own ranks) or "
                          f"under torch.distributed.run with --nproc-per-node {args.gpus}")
-    if world > 1 and backend == "nccl" and local_rank >= n_dev:
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible (RCCL needs one GPU per rank)")
-    device_index = local_rank % max(n_dev, 1)
-    torch.cuda.set_device(device_index)
-    if world > 1:          # which device every rank really sits on (a run that silently shares devices would still print a number)
-        pr = torch.cuda.get_device_properties(device_index)
-        pci = ":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, k)) or "n/a"
-        print(f"[bench rank {rank}/{world}] local_rank {local_rank} -> cuda:{device_index} {pr.name} pci {pci} uuid {getattr(pr, 'uuid', 'n/a')} "
-              f"backend {backend} visible_devices {n_dev}", file=sys.stderr, flush=True)
-    if world > 1:
-        import datetime
-        try:
-            inject("init", rank)
-            if backend == "nccl":
-                torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=300))
-            else:
-                torch.distributed.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
-        except Exception as e:                 # noqa: BLE001 -- whatever the backend raises: say which rank and leave
-            rank_fail(rank, world, device_index, backend, "init_process_group", e)
-        try:                                   # the first collective creates the communicator (RCCL: ring / tree set-up over xGMI)
-            inject("first_all_reduce", rank)
-            probe = torch.ones(1, device="cuda")
-            torch.distributed.all_reduce(probe)
-            torch.cuda.synchronize()
-            if int(probe[0]) != world:
-                raise RuntimeError(f"all_reduce(1) over {world} ranks returned {float(probe[0])}")
-        except Exception as e:                 # noqa: BLE001
-            rank_fail(rank, world, device_index, backend, "the first all_reduce", e)
-
+    # joins the process group (300 s time-out) and proves it with a one-word all-reduce; every failure names rank, device and stage
+    rank, world, device_index = parallel.init_rank(backend, tag="bench")
     try:
         run(args, world, rank, device_index, backend)
     except Exception as e:                     # noqa: BLE001 -- N > 1: ANY rank that raises says who it is and ends the job (exit 3);
         if world > 1:                          # its peers would otherwise meet it as "connection closed by peer" in their next collective
-            rank_fail(rank, world, device_index, backend, "the benchmark body", e)
+            rank_fail("the benchmark body", e)
         raise
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -533,12 +516,12 @@ def run(args, world, rank, device_index, backend):
         return bench_fit(args, world, rank, wh, batch, chunks, desc, backend)
     nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: every rank draws its OWN initial weights; compile() must mirror rank 0's
     try:
-        inject("compile", rank)
+        inject("compile")
         nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
                      white_background=True)
     except Exception as e:                     # noqa: BLE001 -- N > 1: the weight broadcast of compile() is the second collective
         if world > 1:
-            rank_fail(rank, world, device_index, backend, "NeRF.compile (weight broadcast)", e)
+            rank_fail("NeRF.compile (weight broadcast)", e)
         raise
     if args.ignore_nonfinite:
         nerf._ctx.poll_nonfinite = lambda wait=False: None
@@ -551,15 +534,18 @@ def run(args, world, rank, device_index, backend):
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
 
     try:
-        inject("warmup", rank)
+        inject("warmup")
         for _ in range(args.warmup):
             nerf.train_step(data, with_metrics=False)
         sync(world)
     except Exception as e:                     # noqa: BLE001 -- N > 1: the first gradient all-reduce (4.77 MB) runs in here
         if world > 1:
-            rank_fail(rank, world, device_index, backend, "the warm-up steps (first gradient all-reduce)", e)
+            rank_fail("the warm-up steps (first gradient all-reduce)", e)
         raise
+    selftest = {}
     if world > 1:
+        selftest = allreduce_selftest(nerf, world, backend)
+        sync(world)
         nerf._allreduce_events = []            # HIP events on the compute stream around the gradient all-reduce of every timed step
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -582,25 +568,16 @@ def run(args, world, rank, device_index, backend):
         free_b, total_b = torch.cuda.mem_get_info()
         print(f"[bench rank {rank}/{world}] device memory free {free_b / 2**30:.1f} GiB of {total_b / 2**30:.1f} GiB; "
               f"wgrad_group {int(nerf._ctx.get_option('wgrad_group'))} (budget {nerf._ctx.get_option('wgrad_group_gb'):g} GB)", file=sys.stderr, flush=True)
-    # what the six logged metrics add to a step (SURVEY.md 8d reports them separately): the same loop with metrics on, still
-    # asynchronous (NeRF.fit's form: two image-metric launches + one update of the device-side means per step), bracketed by the
-    # plain loop before (the timed region above) and once more after it, so that clock drift does not pass for a difference
-    # (these two loops run about 3 s each, at most 100 steps: two 20-step loops repeat to +-0.15 ms only, which is the size of the effect)
-    # from `elapsed`, the max over ranks: EVERY rank must run the same number of steps (each one holds an all-reduce)
-    n_cmp = max(args.steps, min(100, int(3.0 / max(elapsed / args.steps, 1e-3))))
-
-    def loop(**kw):
-        for _ in range(2):
-            nerf.train_step(data, **kw)
-        sync(world)
-        t1 = time.perf_counter()
-        for _ in range(n_cmp):
-            nerf.train_step(data, **kw)
-        sync(world)
-        return (time.perf_counter() - t1) / n_cmp * 1e3
-    with_metrics_ms = loop(sync=False)
-    plain_again_ms = loop(with_metrics=False)
-    metrics_ms = with_metrics_ms - 0.5 * (local_elapsed / args.steps * 1e3 + plain_again_ms)
+    # what the six logged metrics add to a step (SURVEY.md 8d reports them separately): HIP events on the stream around the two
+    # image-metric launches and the update of the device-side means (MetricState.update), in NeRF.fit's asynchronous form.  (Rounds
+    # 3-4 took the difference of two ~3 s loops, which does not resolve three small launches: -0.14 ms on the r04 line.)
+    # Every rank runs the same number of steps (each holds an all-reduce).
+    nerf._metric_state.events = []
+    for _ in range(6):
+        nerf.train_step(data, sync=False)
+    sync(world)
+    ev, nerf._metric_state.events = nerf._metric_state.events[1:], None      # the first step's launches include one-time set-up
+    metrics_ms = sum(a_.elapsed_time(b_) for a_, b_ in ev) / max(len(ev), 1)
 
     roofline = None
     if not args.no_profile:
@@ -693,7 +670,8 @@ def run(args, world, rank, device_index, backend):
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
             "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
-            "metrics_ms_per_step": metrics_ms, "options": opts, "dead_tile_frac": dead_frac, **comm,
+            "metrics_ms_per_step": metrics_ms, "metrics_clock": "hip events around the 3 metric launches, mean of 5 steps",
+            "options": opts, "dead_tile_frac": dead_frac, **comm, **selftest,
         }
         print(json.dumps(out), flush=True)
 

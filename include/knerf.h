@@ -40,8 +40,13 @@ typedef struct knerf_config {
     int32_t flags;                     /* KNERF_FLAG_* */
 } knerf_config;
 
-/* run a shape the fused kernels cover through the general-shape kernels too (tests compare the two paths) */
-enum { KNERF_FLAG_FORCE_GENERIC = 1 };
+/* KNERF_FLAG_FORCE_GENERIC: run a shape the fused kernels cover through the general-shape kernels too (tests compare the two paths).
+ * KNERF_FLAG_ENCODED_WIDTHS: a stand-alone NeRFMLP (reference mlp.py:4-59; tests/model/nerf/test_nerf_mlp.py:6-45 feeds 99-wide
+ *   tensors to BOTH inputs).  Keras Dense takes its input size from the last dimension of the first call (mlp.py:11-27 names
+ *   none), so the two widths are free: with this flag pos_emb_xyz / pos_emb_dir hold the encoded input WIDTHS themselves
+ *   (1..4096 each, not the number of frequencies) and n_coarse / n_fine are ignored.  Such a context serves knerf_set_weights /
+ *   knerf_get_weights / knerf_weights_device / knerf_mlp_call only; the ray entry points return KNERF_ERR_INVALID. */
+enum { KNERF_FLAG_FORCE_GENERIC = 1, KNERF_FLAG_ENCODED_WIDTHS = 2 };
 
 enum { KNERF_COARSE = 0, KNERF_FINE = 1 };
 
@@ -73,8 +78,8 @@ int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, c
                         int n_rays, int n_samples, float* image, float* depth, float* weights);
 
 /* NeRFMLP.__call__((xyz_enc, dir_enc)) (mlp.py:29-50) on inputs that are ALREADY positional encodings:
- * xyz_enc [n, 3+6*pos_emb_xyz], dir_enc [n, 3+6*pos_emb_dir] fp32 device pointers; raw [n,4] = (rgb after sigmoid, sigma
- * after relu).  The reference calls its MLPs this way only to create weights and in a shape test; it runs on the
+ * xyz_enc [n, 3+6*pos_emb_xyz], dir_enc [n, 3+6*pos_emb_dir] (or [n, pos_emb_xyz], [n, pos_emb_dir] on a context created with
+ * KNERF_FLAG_ENCODED_WIDTHS) fp32 device pointers; raw [n,4] = (rgb after sigmoid, sigma after relu).  The reference calls its MLPs this way only to create weights and in a shape test; it runs on the
  * general-shape kernels (bf16 operands, fp32 accumulate) for every shape, including the default one. */
 int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, const float* dir_enc, uint64_t n, float* raw);
 
@@ -125,7 +130,8 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
 /* Run-time options of a context (no environment variables are read by the library).  Names:
  *   "deterministic"     0/1  weight gradients and losses without floating-point atomics: every workgroup writes its partial sums
  *                            to its own slab and an ordered second pass adds them, so two runs of the same step are bit-identical
- *                            (slower; the reference's TF ops give no such guarantee either -- this is a test/diagnosis mode).
+ *                            (slower; the reference's TF ops give no such guarantee either -- this is a test/diagnosis mode).  Both MLP paths: the
+ *                            fused kernels and, since round 5, the general-shape kernels (csrc/generic.hip).
  *   "skip_dead_tiles"   0/1  (default 1) the backward kernels skip every 32-sample tile whose dL/d(rgb, sigma) is EXACTLY zero for all samples
  *                            (empty space with a closed ReLU gate on sigma, rays whose pixel error is exactly 0): such samples add
  *                            exactly nothing to any of the 48 gradient tensors (utils.py:36-45, mlp.py:40), so the result is the

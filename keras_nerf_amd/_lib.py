@@ -20,6 +20,7 @@ class KnerfConfig(C.Structure):
 
 
 FLAG_FORCE_GENERIC = 1
+FLAG_ENCODED_WIDTHS = 2      # pos_emb_xyz / pos_emb_dir hold the two encoded input widths of a stand-alone NeRFMLP (include/knerf.h)
 
 
 _P = C.c_void_p

@@ -74,6 +74,7 @@ struct knerf_ctx {
     int n_cu = 256;
     // general-shape MLP path (generic.h): used when the fused kernels do not cover the config's MLP shape (layout.h KNERF_FUSED_SHAPES)
     bool generic = false;
+    bool mlp_only = false;              // created with KNERF_FLAG_ENCODED_WIDTHS: a stand-alone NeRFMLP (weights + knerf_mlp_call)
     int shape = 0;                      // fused path: layout.h fused_shape_id of the trunk
     knerf::ShapeInfo si = knerf::shape_info(0);
     int n_params = knerf::kParamCount;

@@ -57,6 +57,9 @@ struct Plan {
 bool is_default_shape(int n_layers, int units, int skip, int lx, int ld);
 int param_count(int n_layers, int units, int skip, int lx, int ld);
 Plan build_plan(int n_layers, int units, int skip, int lx, int ld);
+// the same from the two encoded input WIDTHS (any positive integers; knerf.h KNERF_FLAG_ENCODED_WIDTHS): a plan for
+// forward_encoded only
+Plan build_plan_widths(int n_layers, int units, int skip, int xyz_dim, int dir_dim);
 
 struct Workspace {             // per context, grow-only; Mp = padded sample count
     size_t mp = 0;
@@ -84,13 +87,16 @@ hipError_t expand_head(const Plan& p, const NetDev& net, const float* w_flat, fl
 // forward over n = R*S samples: fills raw [n][4] (rgb after sigmoid, sigma after relu); keeps activations for backward
 hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
                    const float* t, long long n, int S, float* raw, hipStream_t s);
-// the same on inputs that are already positional encodings: xyz_enc [n][3+6*lx], dir_enc [n][3+6*ld] (fp32)
+// the same on inputs that are already encoded: xyz_enc [n][p.xyz_dim], dir_enc [n][p.dir_dim] (fp32)
 hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* xyz_enc,
                            const float* dir_enc, long long n, float* raw, hipStream_t s);
 // backward from draw [n][4] (dL/d rgb, dL/d sigma): trunk gradients accumulate into grad_flat (fp32 atomics), the head's
 // sums into net.gaux (expand_head turns them into gradients)
+// partial: null (fp32 atomics), or wgrad_partial_floats(p) floats of scratch for the deterministic mode -- per-unit slabs and an
+// ordered second pass per weight-gradient launch, bit-identical between runs
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
-                    float* grad_flat, hipStream_t s);
+                    float* grad_flat, hipStream_t s, float* partial = nullptr);
+size_t wgrad_partial_floats(const Plan& p);
 size_t padded_rows(long long n);
 
 }  // namespace gen

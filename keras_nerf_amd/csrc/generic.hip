@@ -544,6 +544,11 @@ struct WgradArgs {
     float* grad;                // flat fp32 gradient of the net
     int w_off, b_off, n_real;
     int n_seg; Seg seg[2];
+    // deterministic mode (knerf_set_option "deterministic"): no fp32 atomics -- every accumulating unit (a wave of wgrad_kernel, a
+    // workgroup of wgrad_coop_kernel) stores its partial tile to its OWN slab and wgrad_reduce_kernel adds the slabs of a block in
+    // slab order into grad.  The step -> unit assignment is a function of the grid alone, so two launches give the same bits.
+    // Block (bx, by), slab sl: partial + ((bx gy + by) n_sl + sl) tile_floats; a tile is [TK][TN] sums then [bias_halves][TN].
+    float* partial;             // null: atomics
 };
 
 // 32 samples x 32 features (row-major; raw = the two 16-byte row pieces each lane loaded) -> two operand fragments with
@@ -632,6 +637,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
         }
     }
     // flush: lane (col = r, hh = h), register i -> input column k0 + 32a + (i&3) + 8(i>>2) + 4hh
+    if (g.partial) {            // deterministic mode: this wave's tile to its own slab (every element, also of a wave without steps)
+        constexpr int TK = KT * 32, TN = NT * 32, TF = TK * TN + 2 * TN;
+        const int n_sl = gridDim.z * 4, sl = blockIdx.z * 4 + wave;
+        float* tile = g.partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * n_sl + sl) * TF;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tile[(32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * TN + 32 * b + r] = acc[a][b][i];
+            if (do_bias) tile[TK * TN + h * TN + 32 * b + r] = bsum[b];       // the two lane halves hold different samples: two rows
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int col = n0 + 32 * b + r;
@@ -740,6 +759,20 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
         buf ^= 1;
     }
     // flush: lane (col = r, hh = h), register i -> input column 32 tile + (i&3) + 8(i>>2) + 4hh
+    if (g.partial) {            // deterministic mode: the workgroup's 256 x 256 block (its eight waves own disjoint parts) to its own slab
+        constexpr int TN = 256, TF = 256 * 256 + TN;
+        float* tile = g.partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * TF;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cl = 32 * (4 * wb + b) + r;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tile[(32 * (2 * wa + a) + (i & 3) + 8 * (i >> 2) + 4 * h) * TN + cl] = acc[a][b][i];
+            if (do_bias && h == 0) tile[256 * 256 + cl] = acc_b[b][0];
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int col = n0 + 32 * (4 * wb + b) + r;
@@ -758,6 +791,49 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     }
 }
 
+// deterministic mode, second pass: element e of block (bx, by) = the sum of its n_sl slabs IN SLAB ORDER, added to the gradient by
+// the one thread that owns the destination (launches follow each other on the stream, so the accumulation over passes and chunks
+// is ordered too)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int n_sl, int TK, int TN, int bias_halves, int gy) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int tf = TK * TN + bias_halves * TN;
+    if (e >= TK * TN + TN) return;
+    const int bx = blockIdx.y / gy, by = blockIdx.y % gy;
+    const float* base = g.partial + (size_t)blockIdx.y * n_sl * tf;
+    if (e < TK * TN) {
+        const int kc = bx * TK + e / TN, col = by * TN + e % TN;
+        if (col >= g.n_real) return;
+        int wrow = -1;
+        for (int sg = 0; sg < g.n_seg; ++sg)
+            if (kc >= g.seg[sg].col0 && kc < g.seg[sg].col0 + g.seg[sg].width) wrow = g.seg[sg].wrow0 + kc - g.seg[sg].col0;
+        if (wrow < 0) return;
+        float sum = 0.f;
+        for (int sl = 0; sl < n_sl; ++sl) sum += base[(size_t)sl * tf + e];
+        g.grad[g.w_off + (size_t)wrow * g.n_real + col] += sum;
+    } else {
+        const int cl = e - TK * TN, col = by * TN + cl;
+        if (bx != 0 || col >= g.n_real) return;
+        float sum = 0.f;
+        for (int sl = 0; sl < n_sl; ++sl)
+            for (int hh = 0; hh < bias_halves; ++hh) sum += base[(size_t)sl * tf + TK * TN + hh * TN + cl];
+        g.grad[g.b_off + col] += sum;
+    }
+}
+
+// slab floats one weight-gradient launch over a [K] x [N] layer can need (the grid's upper bound; independent of the sample count)
+size_t wgrad_partial_floats_for(int K, int N) {
+    const int kt = K / 32, nt = N / 32;
+    if (kt >= 4 && nt >= 4) {
+        const long long gx = (K + 255) / 256, gy = (N + 255) / 256;
+        long long gz = 256 / (gx * gy); if (gz < 1) gz = 1;
+        return (size_t)(gx * gy * gz) * (256 * 256 + 256);
+    }
+    const int KT = kt % 2 == 0 ? 2 : 1, NT = nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);      // the largest tiles launch_wgrad may pick
+    const long long gx = kt / KT, gy = nt / NT;
+    long long gz = 1024 / (gx * gy); if (gz < 1) gz = 1;
+    return (size_t)(gx * gy * gz * 4) * (KT * 32 * NT * 32 + 2 * NT * 32);
+}
+
 hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     const int kt = K / 32, nt = N / 32;
 #ifndef KNERF_GEN_NO_COOP
@@ -774,6 +850,8 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
         if (gz > g.steps) gz = g.steps;
         if (gz < 1) gz = 1;
         hipLaunchKernelGGL(wgrad_coop_kernel, dim3(gx, gy, (unsigned)gz), dim3(512), lds, s, g, K, N);
+        if (g.partial)
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((256 * 256 + 256 + 255) / 256, gx * gy), dim3(256), 0, s, g, (int)gz, 256, 256, 1, gy);
         return hipGetLastError();
     }
 #endif
@@ -799,6 +877,8 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     else if (KT == 1 && NT == 2) KNERF_GEN_WG(1, 2);
     else KNERF_GEN_WG(1, 1);
 #undef KNERF_GEN_WG
+    if (g.partial)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((KT * 32 * NT * 32 + NT * 32 + 255) / 256, gx * gy), dim3(256), 0, s, g, (int)gz * 4, KT * 32, NT * 32, 2, gy);
     return hipGetLastError();
 }
 
@@ -816,9 +896,18 @@ int param_count(int n_layers, int units, int skip, int lx, int ld) {
 }
 
 Plan build_plan(int n_layers, int units, int skip, int lx, int ld) {
+    Plan p = build_plan_widths(n_layers, units, skip, 3 + 6 * lx, 3 + 6 * ld);
+    p.lx = lx; p.ld = ld;
+    return p;
+}
+
+// Keras Dense builds its kernel from the LAST dimension of its first input (mlp.py:11-27 gives no input size), so a stand-alone
+// NeRFMLP takes any two input widths: the plan only ever needs the widths (encode_kernel alone uses lx / ld, and a plan made here
+// has none: lx = ld = -1, forward() refuses it)
+Plan build_plan_widths(int n_layers, int units, int skip, int xyz_dim, int dir_dim) {
     Plan p{};
-    p.n_layers = n_layers; p.units = units; p.skip = skip; p.lx = lx; p.ld = ld;
-    p.xyz_dim = 3 + 6 * lx; p.dir_dim = 3 + 6 * ld;
+    p.n_layers = n_layers; p.units = units; p.skip = skip; p.lx = -1; p.ld = -1;
+    p.xyz_dim = xyz_dim; p.dir_dim = dir_dim;
     p.kxp = r32(p.xyz_dim); p.kdp = r32(p.dir_dim); p.up = r32(units);
     const int u2 = units / 2;
     p.u2p = r32(u2);
@@ -989,7 +1078,7 @@ hipError_t run_layers(const Plan& p, const Workspace& ws, const NetDev& net, con
 hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const float* w_flat, const float* o, const float* d,
                    const float* t, long long n, int S, float* raw, hipStream_t s) {
     const long long mp = (long long)padded_rows(n);
-    if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
+    if ((size_t)mp > ws.mp || p.lx < 0 || p.ld < 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld,
                        act_buf(p, ws, p.buf_encx), p.kxp, act_buf(p, ws, p.buf_encd), p.kdp);
     GENCHK(hipGetLastError());
@@ -1006,8 +1095,17 @@ hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net
     return run_layers(p, ws, net, w_flat, n, mp, raw, s);
 }
 
+size_t wgrad_partial_floats(const Plan& p) {
+    size_t m = wgrad_partial_floats_for(p.head_K, 32);
+    for (int li = 0; li < p.n_layers; ++li) {
+        const size_t v = wgrad_partial_floats_for(p.buf_ld[p.layers[li].in_buf], p.layers[li].np);
+        if (v > m) m = v;
+    }
+    return m;
+}
+
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
-                    float* grad_flat, hipStream_t s) {
+                    float* grad_flat, hipStream_t s, float* partial) {
     const long long mp = (long long)padded_rows(n);
     if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
     const int nl = p.n_layers;
@@ -1040,6 +1138,7 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         w.Z = dz_buf(p, ws, L.dz_buf) + L.dz_col0; w.ldz = p.dz_ld[L.dz_buf];
         w.steps = mp / 32; w.grad = grad_flat; w.w_off = L.w_off; w.b_off = L.b_off; w.n_real = L.n_real;
         w.n_seg = L.n_seg; w.seg[0] = L.seg[0]; w.seg[1] = L.seg[1];
+        w.partial = partial;                    // one slab arena serves every launch: they follow each other on the stream
         GENCHK(launch_wgrad(w, w.ldx, L.np, s));
     }
     {   // head sums M = [h ; (xyz) ; dir]^T dZ_head [head_K][4] and s = column sums, into the aux buffer (expand_head)
@@ -1048,6 +1147,7 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         w.Z = dzh; w.ldz = 32;
         w.steps = mp / 32; w.grad = net.gaux; w.w_off = 0; w.b_off = p.head_K * 4; w.n_real = 4;
         w.n_seg = 1; w.seg[0] = Seg{0, p.head_K, 0};
+        w.partial = partial;
         GENCHK(launch_wgrad(w, w.ldx, 32, s));
     }
     return hipSuccess;

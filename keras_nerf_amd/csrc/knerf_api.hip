@@ -209,6 +209,13 @@ struct ProfScope {
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].e1, s); }
 };
 
+// a context created with KNERF_FLAG_ENCODED_WIDTHS is a stand-alone NeRFMLP: it has no ray encodings, samplers or workspaces
+int check_rays(knerf_ctx* ctx, const char* what) {
+    if (!ctx) return KNERF_ERR_INVALID;
+    if (ctx->mlp_only) return fail(ctx, KNERF_ERR_INVALID, std::string(what) + ": this context was created with KNERF_FLAG_ENCODED_WIDTHS (NeRFMLP.__call__ only)");
+    return KNERF_OK;
+}
+
 int check_net(knerf_ctx* ctx, int net) {
     if (!ctx) return KNERF_ERR_INVALID;
     if (net != KNERF_COARSE && net != KNERF_FINE) return fail(ctx, KNERF_ERR_INVALID, "net must be 0 (coarse) or 1 (fine)");
@@ -327,7 +334,12 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
     }
     if (train && ctx->generic) {
         ProfScope ps(ctx, s, net == KNERF_COARSE ? P_BWD_C : P_BWD_F);
-        HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s));
+        if (ctx->deterministic && !ctx->partial) {       // general-shape path: the slab arena of generic.hip (the fused path's lives in launch_wgrad_tiles)
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMalloc(&ctx->partial, gen::wgrad_partial_floats(ctx->gplan) * sizeof(float)));
+        }
+        HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s,
+                             ctx->deterministic ? ctx->partial : nullptr));
     } else if (train) {
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + saved_tile_off(tile0, ctx->si.dz_blocks);
@@ -406,6 +418,10 @@ size_t knerf_param_count(void) { return (size_t)kParamCount; }
 
 size_t knerf_param_count_for(const knerf_config* cfg) {
     if (!cfg || cfg->n_layers < 1 || cfg->dense_units < 2 || cfg->skip_layer < 1 || cfg->pos_emb_xyz < 0 || cfg->pos_emb_dir < 0) return 0;
+    if (cfg->flags & KNERF_FLAG_ENCODED_WIDTHS) {
+        if (cfg->pos_emb_xyz < 1 || cfg->pos_emb_dir < 1) return 0;
+        return (size_t)gen::build_plan_widths(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir).n_params;
+    }
     return (size_t)gen::param_count(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
 }
 
@@ -414,11 +430,15 @@ const char* knerf_last_error(const knerf_ctx* ctx) { return ctx ? ctx->err.c_str
 int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     knerf_ctx* ctx = nullptr;
     if (!cfg || !out) return fail(nullptr, KNERF_ERR_INVALID, "null argument");
-    if (cfg->n_layers < 1 || cfg->n_layers > 64 || cfg->dense_units < 2 || cfg->dense_units > 4096 || cfg->skip_layer < 1 ||
-        cfg->pos_emb_xyz < 0 || cfg->pos_emb_xyz > 32 || cfg->pos_emb_dir < 0 || cfg->pos_emb_dir > 32)
-        return fail(nullptr, KNERF_ERR_INVALID, "need 1 <= n_layers <= 64, 2 <= dense_units <= 4096, skip_layer >= 1, 0 <= pos_emb_* <= 32");
+    const bool widths = (cfg->flags & KNERF_FLAG_ENCODED_WIDTHS) != 0;      // stand-alone NeRFMLP: pos_emb_* ARE the two input widths
+    if (cfg->n_layers < 1 || cfg->n_layers > 64 || cfg->dense_units < 2 || cfg->dense_units > 4096 || cfg->skip_layer < 1)
+        return fail(nullptr, KNERF_ERR_INVALID, "need 1 <= n_layers <= 64, 2 <= dense_units <= 4096, skip_layer >= 1");
+    if (widths && (cfg->pos_emb_xyz < 1 || cfg->pos_emb_xyz > 4096 || cfg->pos_emb_dir < 1 || cfg->pos_emb_dir > 4096))
+        return fail(nullptr, KNERF_ERR_INVALID, "KNERF_FLAG_ENCODED_WIDTHS: need 1 <= input width <= 4096 in pos_emb_xyz / pos_emb_dir");
+    if (!widths && (cfg->pos_emb_xyz < 0 || cfg->pos_emb_xyz > 32 || cfg->pos_emb_dir < 0 || cfg->pos_emb_dir > 32))
+        return fail(nullptr, KNERF_ERR_INVALID, "need 0 <= pos_emb_* <= 32");
     // one wavefront walks a ray in compositing (a lane's run of up to 16 samples in registers) and in the sampler (tables in LDS)
-    if (cfg->n_coarse < 2 || cfg->n_coarse > 512 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 1024)
+    if (!widths && (cfg->n_coarse < 2 || cfg->n_coarse > 512 || cfg->n_fine < 0 || cfg->n_coarse + cfg->n_fine > 1024))
         return fail(nullptr, KNERF_ERR_INVALID, "need 2 <= n_coarse <= 512 and n_coarse + n_fine <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KNERF_ERR_NODEVICE, "no HIP device visible");
@@ -432,10 +452,12 @@ int knerf_create(const knerf_config* cfg, knerf_ctx** out) {
     ctx->cfg = *cfg;
     // the fused kernels cover the trunk shapes of layout.h KNERF_FUSED_SHAPES (widths 256 and 128; the reference's encodings unless the build added others); everything
     // else -- and, for tests, any shape under KNERF_FLAG_FORCE_GENERIC -- runs on the general-shape kernels
-    const int sid = fused_shape_id(cfg->n_layers, cfg->skip_layer, cfg->dense_units, cfg->pos_emb_xyz, cfg->pos_emb_dir);
+    const int sid = widths ? -1 : fused_shape_id(cfg->n_layers, cfg->skip_layer, cfg->dense_units, cfg->pos_emb_xyz, cfg->pos_emb_dir);
     ctx->generic = sid < 0 || (cfg->flags & KNERF_FLAG_FORCE_GENERIC) != 0;
+    ctx->mlp_only = widths;
     if (ctx->generic) {
-        ctx->gplan = gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
+        ctx->gplan = widths ? gen::build_plan_widths(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir)
+                            : gen::build_plan(cfg->n_layers, cfg->dense_units, cfg->skip_layer, cfg->pos_emb_xyz, cfg->pos_emb_dir);
         ctx->n_params = ctx->gplan.n_params;
     } else {
         ctx->shape = sid; ctx->si = shape_info(sid); ctx->n_params = ctx->si.param_count;
@@ -577,6 +599,7 @@ int knerf_refresh_weights(knerf_ctx* ctx, void* stream) {
 int knerf_forward_chunk(knerf_ctx* ctx, void* stream, int net, const float* o, const float* d, const float* t,
                         int n_rays, int n_samples, float* image, float* depth, float* weights) {
     if (int r = check_net(ctx, net)) return r;
+    if (int r = check_rays(ctx, "forward_chunk")) return r;
     if (!o || !d || !t || !image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: null/empty argument");
     if (n_samples < 1 || n_samples > ctx->cfg.n_coarse + ctx->cfg.n_fine) return fail(ctx, KNERF_ERR_INVALID, "forward_chunk: n_samples out of range");
     if (int r = ensure_ws(ctx, n_rays, false, (hipStream_t)stream)) return r;
@@ -589,7 +612,8 @@ int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, 
     hipStream_t s = (hipStream_t)stream;
     if (!ctx->call_plan_ok) {
         const knerf_config& c = ctx->cfg;
-        ctx->call_plan = gen::build_plan(c.n_layers, c.dense_units, c.skip_layer, c.pos_emb_xyz, c.pos_emb_dir);
+        ctx->call_plan = ctx->mlp_only ? gen::build_plan_widths(c.n_layers, c.dense_units, c.skip_layer, c.pos_emb_xyz, c.pos_emb_dir)
+                                       : gen::build_plan(c.n_layers, c.dense_units, c.skip_layer, c.pos_emb_xyz, c.pos_emb_dir);
         HIPCHK(hipMalloc(&ctx->call_net.packed, ctx->call_plan.packed_elems * sizeof(unsigned short)));
         HIPCHK(hipMalloc(&ctx->call_net.head, gen::head_floats(ctx->call_plan) * sizeof(float)));
         ctx->call_plan_ok = true;
@@ -615,7 +639,7 @@ int knerf_mlp_call(knerf_ctx* ctx, void* stream, int net, const float* xyz_enc, 
 
 int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const float* w_coarse, const float* u,
                       uint64_t seed, uint64_t stream_id, uint64_t ray_offset, int n_rays, float* t_out) {
-    if (!ctx) return KNERF_ERR_INVALID;
+    if (int r = check_rays(ctx, "sample_fine")) return r;
     if (!t_coarse || !w_coarse || !t_out || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "sample_fine: null/empty argument");
     SampleArgs sa{};
     sa.t_coarse = t_coarse; sa.w_coarse = w_coarse; sa.u = u; sa.t_out = t_out; sa.R = n_rays;
@@ -628,7 +652,7 @@ int knerf_sample_fine(knerf_ctx* ctx, void* stream, const float* t_coarse, const
 int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u,
                        uint64_t seed, uint64_t ray_offset, int n_rays, float* c_image, float* c_depth, float* c_weights,
                        float* f_image, float* f_depth, float* f_weights, float* t_fine) {
-    if (!ctx) return KNERF_ERR_INVALID;
+    if (int r = check_rays(ctx, "render_chunk")) return r;
     if (!o || !d || !t || !c_image || !f_image || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "render_chunk: null/empty argument");
     hipStream_t s = (hipStream_t)stream;
     if (int r = ensure_ws(ctx, n_rays, false, s)) return r;
@@ -662,7 +686,7 @@ int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float
 int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
                       const float* u, uint64_t seed, uint64_t ray_offset, int n_rays, float inv_chunks, float* loss,
                       float* c_image, float* f_image) {
-    if (!ctx) return KNERF_ERR_INVALID;
+    if (int r = check_rays(ctx, "train_chunk")) return r;
     if (!o || !d || !t || !target || n_rays <= 0) return fail(ctx, KNERF_ERR_INVALID, "train_chunk: null/empty argument");
     hipStream_t s = (hipStream_t)stream;
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
@@ -674,7 +698,7 @@ int knerf_train_chunk(knerf_ctx* ctx, void* stream, const float* o, const float*
 
 int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* target,
                       const float* u, uint64_t seed, int n_rays, int ray_chunks, float* loss, float* c_image, float* f_image) {
-    if (!ctx) return KNERF_ERR_INVALID;
+    if (int r = check_rays(ctx, "train_batch")) return r;
     if (!o || !d || !t || !target) return fail(ctx, KNERF_ERR_INVALID, "train_batch: null argument");
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "train_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
@@ -780,8 +804,7 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
     if (!ctx || !name) return KNERF_ERR_INVALID;
     const std::string n(name);
     if (n == "deterministic") {
-        if (ctx->generic && value != 0) return fail(ctx, KNERF_ERR_INVALID, "deterministic: implemented for the fused (default-shape) kernels only");
-        ctx->deterministic = value != 0;
+        ctx->deterministic = value != 0;         // fused path: wgrad slabs + wgrad_reduce_kernel; general-shape path: generic.hip's slabs (round 5)
     } else if (n == "grad_diagnostics") {
         ctx->grad_diag = value != 0;
     } else if (n == "skip_dead_tiles") {
@@ -841,7 +864,18 @@ int knerf_tile_stats(knerf_ctx* ctx, void* stream, int64_t* live, int64_t* total
 int knerf_grad_diagnostics(knerf_ctx* ctx, void* stream, int wait, int64_t* out) {
     if (!ctx || !out) return KNERF_ERR_INVALID;
     if (wait) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    // seqlock reader (optim.hip diag_publish_kernel): [2] = published, [3] = begun.  Equal on both sides of the reads <=> the two
+    // counts belong to step [2]; a publication in flight makes them differ for a few microseconds.
     volatile long long* h = ctx->h_diag;
+    for (int attempt = 0; attempt < 4096; ++attempt) {
+        const long long done = h[2];
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const long long c = h[0], f = h[1];
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const long long begun = h[3];
+        if (begun == done) { out[0] = c; out[1] = f; out[2] = done; return KNERF_OK; }
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // never seen in practice: settle it the slow way
     out[2] = h[2]; out[0] = h[0]; out[1] = h[1];
     return KNERF_OK;
 }

@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void count_nonzero_kernel(const float* g, int 
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(counts + net, (unsigned long long)c);
 }
-// host (pinned): [0] coarse count, [1] fine count, [2] number of steps published so far
+// host (pinned): [0] coarse count, [1] fine count, [2] number of steps published so far, [3] number of steps whose publication has
+// BEGUN -- a seqlock: [3] is raised before the counts are written, [2] after, so a reader that finds [2] == [3] on both
+// sides of its reads of [0] / [1] holds the two counts of ONE step (knerf_grad_diagnostics; the asynchronous `fit` path reads while
+// the next step's kernels run)
 __global__ void diag_publish_kernel(const unsigned long long* counts, long long* host) {
+    const long long seq = host[2] + 1;
+    host[3] = seq;
+    __threadfence_system();
     host[0] = (long long)counts[0]; host[1] = (long long)counts[1];
     __threadfence_system();
-    host[2] = host[2] + 1;
+    host[2] = seq;
     __threadfence_system();
 }
 hipError_t launch_grad_diagnostics(const float* g, int n, unsigned long long* counts, long long* host, hipStream_t stream) {

@@ -35,9 +35,11 @@ __device__ __forceinline__ float philox_u(unsigned long long seed, unsigned stre
 // Any sample count the reference's CLI can ask for (train_single.py:28-29: --num_coarse_samples / --num_fine_samples are free
 // integers) up to kMaxCoarse coarse and kMaxAll samples per ray: the per-wave tables live in DYNAMIC LDS sized by the launch
 // (t: Nc, cdf: Nc + 1, all: max(Nc + Nf, 2 Nc) floats -- the fine half of `all` doubles as scratch for the pdf), 20 KB per
-// workgroup at 64 + 128, 131 KB at the limits.
-constexpr int kMaxCoarse = 1024, kMaxAll = 4096;
-__host__ __device__ inline int sampler_wave_floats(int Nc, int Nf) { const int na = Nc + Nf > 2 * Nc ? Nc + Nf : 2 * Nc; return Nc + (Nc + 1) + na + 3; }
+// workgroup at 64 + 128, 32.8 KB at the limits -- the limits of knerf_create and include/knerf.h (the constants used to
+// advertise 1024 / 4096 and an opt-in to 160 KB of LDS that no context could reach).
+constexpr int kMaxCoarse = 512, kMaxAll = 1024;
+__host__ __device__ constexpr int sampler_wave_floats(int Nc, int Nf) { const int na = Nc + Nf > 2 * Nc ? Nc + Nf : 2 * Nc; return Nc + (Nc + 1) + na + 3; }
+static_assert(4 * sampler_wave_floats(kMaxCoarse, kMaxAll - kMaxCoarse) * sizeof(float) <= 48 * 1024, "the sampler's tables fit the default dynamic-LDS limit");
 
 __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
     extern __shared__ float s_dyn[];
@@ -132,13 +134,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(SampleArgs a) {
 
 hipError_t launch_sample_fine(const SampleArgs& a, hipStream_t stream) {
     if (a.Nc > kMaxCoarse || a.Nc + a.Nf > kMaxAll || a.Nc < 2) return hipErrorInvalidValue;
-    const size_t lds = 4 * (size_t)sampler_wave_floats(a.Nc, a.Nf) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > 48 * 1024) {
-        static AttrOnce once;
-        hipError_t ae = once([&]() -> hipError_t { return hipFuncSetAttribute(reinterpret_cast<const void*>(sample_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (ae != hipSuccess) return ae;
-    }
+    const size_t lds = 4 * (size_t)sampler_wave_floats(a.Nc, a.Nf) * sizeof(float);       // <= 48 KB by the static_assert above
     hipLaunchKernelGGL(sample_fine_kernel, dim3((a.R + 3) / 4), dim3(256), lds, stream, a);
     return hipGetLastError();
 }

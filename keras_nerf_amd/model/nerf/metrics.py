@@ -59,11 +59,15 @@ class MetricState:
     def __init__(self, device):
         self.device = device
         self.state = torch.zeros((len(NAMES), 2), device=device, dtype=torch.float64)
+        self.events = None           # a list: update() appends a pair of HIP events recorded on the stream around its three launches (bench.py)
 
     def update(self, images, coarse_images, fine_images, losses):
         """one step's contribution (nerf.py:306-330): `losses` = device tensor [2] (coarse, fine), or None for the whole-image
         mean squared errors of test_step (nerf.py:484-487).  Three launches, no synchronisation."""
         from ... import _lib
+        if self.events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         sc, _, _ = _image_sums(images, coarse_images)
         sf, _, _ = _image_sums(images, fine_images)
         B, H, W, C = images.shape
@@ -74,6 +78,9 @@ class MetricState:
         if rc != 0:
             from ...runtime import KnerfError
             raise KnerfError(f"knerf_metrics_update failed ({rc})")
+        if self.events is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            self.events.append((e0, e1))
 
     def snapshot(self) -> "MetricLogs":
         return MetricLogs(self.state.clone())

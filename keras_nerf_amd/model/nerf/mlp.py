@@ -73,32 +73,76 @@ def init_kernel(initializer, rng, fan_in: int, fan_out: int) -> np.ndarray:
 
 
 class NeRFMLP:
+    """mlp.py:4-59.  The reference's Dense layers are created WITHOUT an input size (mlp.py:11-27): Keras builds each kernel from
+    the last dimension of the first call, so the two input widths belong to the first call, not to the constructor -- the
+    reference's own test feeds 99-wide tensors to both arguments (tests/model/nerf/test_nerf_mlp.py:13-26).  Same here: an MLP
+    constructed without xyz_dim / dir_dim (extension arguments NeRF uses to fix 3 + 6 L up front) is UNBUILT; it takes its widths
+    from the first call (or build(input_shape), set_weights, load_weights) and from then on a call with other widths raises
+    ValueError naming both, as Keras does.  build() without a shape gives the reference NeRF's own encodings, 63 / 27
+    (nerf.py:116-130 builds its MLPs with dummy inputs of exactly those widths)."""
+
     def __init__(self, n_layers: int = 8, dense_units: int = 256, skip_layer=4, initializer="glorot_uniform", name=None,
-                 xyz_dim: int = 63, dir_dim: int = 27, seed=None, **kwargs):
+                 xyz_dim: int = None, dir_dim: int = None, seed=None, **kwargs):
         if not callable(initializer):
             init_kernel(initializer, np.random.default_rng(0), 1, 1)          # an unknown name fails here, as in Keras
         self.initializer = initializer
         self.n_layers, self.dense_units, self.skip_layer = n_layers, dense_units, skip_layer
         self.name = name or "nerf_mlp"
-        self.xyz_dim, self.dir_dim = xyz_dim, dir_dim
-        self._shapes = layer_shapes(n_layers, dense_units, skip_layer, xyz_dim, dir_dim)
+        self.xyz_dim = self.dir_dim = None
+        self._shapes = None
+        if (xyz_dim is None) != (dir_dim is None):
+            raise ValueError("xyz_dim and dir_dim are given together or not at all")
+        if xyz_dim is not None:
+            self._set_widths(xyz_dim, dir_dim)
         self._seed = seed
         self._host = None          # flat fp32 weights until bound to a device context
         self._ctx = None
         self._net = None
+        self._own_ctx = None
+
+    # ---- input widths (Keras: fixed by the first call)
+    def _set_widths(self, xyz_dim: int, dir_dim: int):
+        xyz_dim, dir_dim = int(xyz_dim), int(dir_dim)
+        if xyz_dim < 1 or dir_dim < 1:
+            raise ValueError(f"{self.name}: input widths must be positive, got {xyz_dim} / {dir_dim}")
+        self.xyz_dim, self.dir_dim = xyz_dim, dir_dim
+        self._shapes = layer_shapes(self.n_layers, self.dense_units, self.skip_layer, xyz_dim, dir_dim)
+
+    def _check_widths(self, xyz_dim: int, dir_dim: int):
+        """Keras' input-compatibility error for a built Dense: expected vs. found last dimension"""
+        for what, layer, want, got in (("ray_coordinate_inputs", "layer_0", self.xyz_dim, xyz_dim),
+                                       ("direction_inputs", "rgb_features", self.dir_dim, dir_dim)):
+            if int(got) != want:
+                raise ValueError(f'Input 0 of layer "{layer}" of {self.name} is incompatible with the layer: expected the last axis of '
+                                 f'{what} to have {want} features, found {got} (the widths were fixed when the model was built)')
 
     # ---- weights
     @property
     def built(self) -> bool:
         return self._host is not None or self._ctx is not None
 
+    def _require_widths(self, what: str):
+        if self._shapes is None:
+            raise ValueError(f"{self.name}.{what}: the model is not built yet -- its input widths come from the first call "
+                             f"(or build(input_shape) / set_weights / load_weights)")
+
     def count_params(self) -> int:
+        self._require_widths("count_params")          # Keras: "You tried to call count_params ... but the layer isn't built"
         return sum(i * o + o for _, i, o in self._shapes)
 
-    def build(self):
-        """kernels from `initializer` (default glorot_uniform: U(+-sqrt(6/(fan_in+fan_out)))), zero biases (Keras Dense defaults)."""
+    def build(self, input_shape=None):
+        """kernels from `initializer` (default glorot_uniform: U(+-sqrt(6/(fan_in+fan_out)))), zero biases (Keras Dense defaults).
+        input_shape: ((..., xyz_dim), (..., dir_dim)) as Keras passes it; None = the widths known so far, else 63 / 27."""
+        if input_shape is not None:
+            xs, ds = input_shape
+            if self._shapes is None:
+                self._set_widths(xs[-1], ds[-1])
+            else:
+                self._check_widths(xs[-1], ds[-1])
         if self.built:
             return
+        if self._shapes is None:
+            self._set_widths(63, 27)
         rng = np.random.default_rng(self._seed)
         parts = []
         for _, fi, fo in self._shapes:
@@ -120,6 +164,8 @@ class NeRFMLP:
 
     def set_flat_weights(self, flat):
         flat = np.ascontiguousarray(np.asarray(flat, np.float32).reshape(-1))
+        if self._shapes is None:          # unbuilt: a flat vector carries no shapes; only the reference NeRF's widths can be meant
+            self._set_widths(63, 27)
         if flat.size != self.count_params():
             raise ValueError(f"{self.name}: expected {self.count_params()} weights, got {flat.size}")
         if self._ctx is not None:
@@ -128,7 +174,9 @@ class NeRFMLP:
             self._host = flat.copy()
 
     def get_weights(self) -> List[np.ndarray]:
-        """list of 24 arrays, Keras get_weights() order"""
+        """list of 24 arrays, Keras get_weights() order ([] while the model is unbuilt, as in Keras)"""
+        if not self.built and self._shapes is None:
+            return []
         flat, out, off = self.get_flat_weights(), [], 0
         for _, fi, fo in self._shapes:
             out.append(flat[off:off + fi * fo].reshape(fi, fo)); off += fi * fo
@@ -136,7 +184,18 @@ class NeRFMLP:
         return out
 
     def set_weights(self, weights):
-        self.set_flat_weights(np.concatenate([np.asarray(w, np.float32).reshape(-1) for w in weights]))
+        weights = [np.asarray(w, np.float32) for w in weights]
+        self._widths_from_kernels(weights[0::2], "set_weights")
+        self.set_flat_weights(np.concatenate([w.reshape(-1) for w in weights]))
+
+    def _widths_from_kernels(self, kernels, what: str):
+        """an unbuilt model adopts the widths its weights were made for: layer_0/kernel is [xyz_dim, units], rgb_features/kernel
+        [units + dir_dim, units / 2] (mlp.py:13-24)"""
+        if self._shapes is not None:
+            return
+        if len(kernels) != self.n_layers + 4 or any(k.ndim != 2 for k in kernels):
+            raise ValueError(f"{self.name}.{what}: expected {2 * (self.n_layers + 4)} arrays (kernel, bias per Dense layer), got {2 * len(kernels)}")
+        self._set_widths(kernels[0].shape[0], kernels[self.n_layers + 2].shape[0] - self.dense_units)
 
     @property
     def trainable_variables(self):
@@ -148,9 +207,10 @@ class NeRFMLP:
     # loads here and a Keras model can load ours.  Any other name is a NumPy .npz archive keyed by Keras weight names; on
     # load the container is told from the file's magic bytes, so round-1 checkpoints (an .npz named coarse.h5) still load.
     def _layer_names(self):
-        return [name for name, _, _ in self._shapes]
+        return [f"layer_{i}" for i in range(self.n_layers)] + ["sigma", "features", "rgb_features", "rgb"]
 
     def save_weights(self, path: str, save_format: str = None):
+        self._require_widths("save_weights")         # Keras refuses to save a model that has not created its variables
         fmt = save_format or ("h5" if str(path).lower().endswith((".h5", ".hdf5", ".keras")) else "npz")
         if fmt in ("h5", "hdf5"):
             from ...io.hdf5_min import write_keras_weights
@@ -176,7 +236,8 @@ class NeRFMLP:
             if magic[:2] != b"PK":
                 raise ValueError(f"{path}: neither an HDF5 file (Keras save_weights) nor a NumPy .npz archive")
             z = np.load(path)
-            pairs = [(z[f"{name}/kernel:0"], z[f"{name}/bias:0"]) for name, _, _ in self._shapes]
+            pairs = [(z[f"{name}/kernel:0"], z[f"{name}/bias:0"]) for name in self._layer_names()]
+        self._widths_from_kernels([np.asarray(k) for k, _ in pairs], "load_weights")
         ws = []
         for (name, fi, fo), (k, b) in zip(self._shapes, pairs):
             if k.shape != (fi, fo) or b.shape != (fo,):
@@ -192,17 +253,27 @@ class NeRFMLP:
         """Evaluates the MLP on already encoded inputs [..., xyz_dim] / [..., dir_dim] (mlp.py:29-50).  The reference's
         NeRF never calls its MLPs this way outside _build_model (weight creation) and a shape test; the fused kernels
         start from ray origins/directions instead, so this entry point runs on the general-shape HIP kernels
-        (knerf_mlp_call: bf16 matmul operands, fp32 accumulate/bias/activation) for every shape."""
+        (knerf_mlp_call: bf16 matmul operands, fp32 accumulate/bias/activation) for every shape.  The first call of an unbuilt
+        model fixes its two input widths (any positive integers: Keras Dense builds from the last dimension it sees); later
+        calls with other widths raise ValueError."""
         xyz, dire = inputs
         if not torch.cuda.is_available():
             from ...runtime import KnerfError
             raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
+        xs, ds = tuple(np.shape(xyz) if not isinstance(xyz, torch.Tensor) else xyz.shape), \
+            tuple(np.shape(dire) if not isinstance(dire, torch.Tensor) else dire.shape)
+        if len(xs) < 1 or len(ds) < 1 or xs[:-1] != ds[:-1]:
+            raise ValueError(f"{self.name}: inputs must share their leading dimensions, got {xs} and {ds}")
+        if self._shapes is None:
+            self._set_widths(xs[-1], ds[-1])
+        else:
+            self._check_widths(xs[-1], ds[-1])
         ctx, net = self._ctx, self._net
         if ctx is None:                      # stand-alone MLP (reference test_nerf_mlp.py): a private context of this shape
-            if getattr(self, "_own_ctx", None) is None:
+            if self._own_ctx is None:
                 from ...runtime import KnerfContext
-                self._own_ctx = KnerfContext(pos_emb_xyz=(self.xyz_dim - 3) // 6, pos_emb_dir=(self.dir_dim - 3) // 6,
-                                             n_layers=self.n_layers, dense_units=self.dense_units, skip_layer=self.skip_layer)
+                self._own_ctx = KnerfContext(n_layers=self.n_layers, dense_units=self.dense_units, skip_layer=self.skip_layer,
+                                             encoded_widths=(self.xyz_dim, self.dir_dim))
             ctx, net = self._own_ctx, 0
             ctx.set_weights(0, self.get_flat_weights())
         xyz = ctx.f32(xyz); dire = ctx.f32(dire)
@@ -215,6 +286,7 @@ class NeRFMLP:
 
     def summary(self, print_fn=print):
         print_fn(f'Model: "{self.name}"')
+        self._require_widths("summary")             # Keras: "This model has not yet been built"
         for name, fi, fo in self._shapes:
             print_fn(f"  {name:<14} Dense  in={fi:<4} out={fo:<4} params={fi * fo + fo}")
         print_fn(f"Total params: {self.count_params():,}")

@@ -200,7 +200,15 @@ class NeRF:
         elif f == 0:
             logging.warning('Fine Gradient is zero')
         if wait and self._ctx.get_option("skip_dead_tiles_active"):
-            for name, (live, total) in zip(("coarse", "fine"), self._ctx.tile_stats_net(reset=True)):
+            # this step's share of the RUNNING totals: read without resetting them -- tile_stats() consumers (bench.py's dead_tile_frac,
+            # fit's per-epoch report, tools/) accumulate across steps -- and difference against the previous read
+            now = self._ctx.tile_stats_net(reset=False)
+            prev = getattr(self, "_tile_stats_seen", ((0, 0), (0, 0)))
+            self._tile_stats_seen = now
+            for name, (l1, t1), (l0, t0) in zip(("coarse", "fine"), now, prev):
+                if t1 < t0:                       # somebody reset the counters in between: the totals ARE the delta
+                    l0 = t0 = 0
+                live, total = l1 - l0, t1 - t0
                 if total > 0 and live == 0:
                     logging.warning(f'Every sample tile of the {name} passes is dead (no sample passes a gradient): sigma has collapsed to zero '
                                     f'or the pixel error is exactly zero everywhere')

@@ -8,6 +8,8 @@ cross GPUs, so there is no other data-path collective.  These helpers are backen
 CPU tests)."""
 from __future__ import annotations
 
+import os
+import sys
 from typing import Sequence
 
 import torch
@@ -69,3 +71,228 @@ def reduce_logs(logs: dict, device=None) -> dict:
     vec = torch.tensor([float(logs[k]) for k in keys], dtype=torch.float64, device=device)
     dist.all_reduce(vec)
     return {k: float(v) / dist.get_world_size() for k, v in zip(keys, vec)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Launching: what `tf.distribute.MirroredStrategy()` does for the reference (train.py:75-93, 110-148) -- plain `python train.py`
+# uses every GPU -- as one PROCESS per GPU.  Rules of this pool (and good manners anywhere): rank processes are CHILDREN started
+# before the parent has touched the GPU; a process that has initialised HIP never execs; a failing rank names itself and the
+# launcher stops the others by their own PIDs (no pattern kills, no collective time-outs).
+# ---------------------------------------------------------------------------------------------------------------------
+RANK_FAILED = 3          # exit code of a rank that raised (and of the launcher that saw it)
+
+
+def dist_env(world: int = 1) -> None:
+    """The environment every rank needs, whichever way it was started (self-spawned or under an external torch.distributed.run):
+    rendezvous on 127.0.0.1 (a container's hostname may not resolve) and dmabuf IPC (this host driver supports nothing else:
+    without it RCCL fails with `hipIpcGetMemHandle: invalid argument`).  Called before anything touches HIP; existing values win.
+    world > 1: RCCL's warnings go to one file per rank (NCCL_DEBUG=WARN, NCCL_DEBUG_FILE), whose tail `rank_fail` prints."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "knerf_rccl_%h_%p.log"))
+
+
+def rccl_log_tail(max_bytes: int = 4000) -> str:
+    """the tail of THIS process's RCCL debug file (dist_env), or '' -- NCCL_DEBUG_FILE's %h / %p are host name and pid"""
+    pat = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not pat:
+        return ""
+    import socket
+    path = pat.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2); n = f.tell(); f.seek(max(0, n - max_bytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def rank_fail(what: str, exc: BaseException, tag: str = "knerf") -> None:
+    """A rank that cannot join or use the process group says who and where it is and leaves with exit code 3 -- the launcher then
+    stops the other ranks -- instead of letting them sit in a collective until its time-out.  Never re-execs (the process may
+    have initialised the GPU).  Prints the tail of this rank's RCCL warnings when there are any."""
+    import traceback
+    r, w = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
+    n_dev = torch.cuda.device_count()          # no GPU initialisation: the device this rank was (or would have been) given
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % n_dev}" if n_dev else "cpu"
+    backend = dist.get_backend() if dist.is_available() and dist.is_initialized() else os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    tb = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
+    tail = rccl_log_tail()
+    print(f"[{tag} rank {r}/{w}] FAILED in {what} on {dev} (backend {backend}): {type(exc).__name__}: {exc}\n{tb}"
+          + (f"[{tag} rank {r}/{w}] RCCL log tail ({os.environ.get('NCCL_DEBUG', '')}):\n{tail}\n" if tail else ""), file=sys.stderr, flush=True)
+    sys.stderr.flush(); sys.stdout.flush()
+    os._exit(RANK_FAILED)
+
+
+def inject(stage: str) -> None:
+    """fault injection for the fail-fast tests: KNERF_INJECT_FAILURE (or KNERF_BENCH_INJECT_FAILURE) = "<rank>:<stage>" makes that
+    rank raise at that stage (init | first_all_reduce | compile | warmup | body)"""
+    spec = os.environ.get("KNERF_INJECT_FAILURE") or os.environ.get("KNERF_BENCH_INJECT_FAILURE", "")
+    if spec and spec == f"{os.environ.get('RANK', '0')}:{stage}":
+        raise RuntimeError(f"injected failure at stage '{stage}'")
+
+
+def init_rank(backend: str = None, timeout_s: float = 300.0, tag: str = "knerf") -> tuple:
+    """Join the process group as the rank the environment describes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: what
+    torch.distributed.run and `launch` set) and prove it works with a one-word all-reduce (RCCL builds its rings over xGMI in
+    there).  Returns (rank, world, device_index or None).  World size 1: nothing to join.  Every failure ends in rank_fail."""
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank_ = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    dist_env(world)
+    n_dev = torch.cuda.device_count()              # counts devices without initialising the GPU
+    dev = None
+    if n_dev:
+        if world > 1 and backend == "nccl" and local >= n_dev:
+            raise SystemExit(f"rank {rank_}: LOCAL_RANK {local} but only {n_dev} GPUs visible (RCCL needs one GPU per rank; "
+                             f"KNERF_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)")
+        dev = local % n_dev
+        torch.cuda.set_device(dev)
+    elif backend == "nccl" and world > 1:
+        raise SystemExit("no GPU visible: the nccl (RCCL) backend needs one per rank")
+    if world == 1 or (dist.is_available() and dist.is_initialized()):
+        return rank_, world, dev
+    if dev is not None:      # which device every rank really sits on (a job that silently shares devices would still train)
+        pr = torch.cuda.get_device_properties(dev)
+        pci = ":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, k)) or "n/a"
+        print(f"[{tag} rank {rank_}/{world}] local_rank {local} -> cuda:{dev} {pr.name} pci {pci} uuid {getattr(pr, 'uuid', 'n/a')} "
+              f"backend {backend} visible_devices {n_dev}", file=sys.stderr, flush=True)
+    import datetime
+    try:
+        inject("init")
+        kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    except Exception as e:                         # noqa: BLE001 -- whatever the backend raises: say which rank and leave
+        rank_fail("init_process_group", e, tag)
+    try:
+        inject("first_all_reduce")
+        probe = torch.ones(1, device="cuda" if dev is not None else "cpu")
+        dist.all_reduce(probe)
+        if dev is not None:
+            torch.cuda.synchronize()
+        if int(probe[0]) != world:
+            raise RuntimeError(f"all_reduce(1) over {world} ranks returned {float(probe[0])}")
+    except Exception as e:                         # noqa: BLE001
+        rank_fail("the first all_reduce", e, tag)
+    return rank_, world, dev
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _wait_ranks(procs, poll, kill, what: str) -> int:
+    """wait for rank processes; the first one that fails ends the job: the others (still blocked in a collective with the dead
+    rank) are terminated BY HANDLE.  Returns the job's exit code."""
+    import time
+    code = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = poll(p)
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else RANK_FAILED
+                print(f"[knerf launch] a rank of {what} exited with code {rc}: stopping the other {len(live)}", file=sys.stderr, flush=True)
+                for q in live:
+                    kill(q)
+        if live:
+            time.sleep(0.05)
+    return code
+
+
+def _rank_entry(fn, args, rank_: int, world: int, port: int, backend: str):
+    os.environ.update(RANK=str(rank_), LOCAL_RANK=str(rank_), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_PORT=str(port))
+    if backend:
+        os.environ["KNERF_DIST_BACKEND"] = backend
+    init_rank(backend)
+    try:
+        inject("body")
+        fn(*args)
+    except Exception as e:                         # noqa: BLE001 -- its peers would meet it as "connection closed by peer"
+        rank_fail(f"{getattr(fn, '__name__', 'fn')}()", e)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
+    """Run a training job on every GPU of this node, one process per GPU -- the MirroredStrategy() of this implementation.
+
+    launch(fn, nprocs, args): `fn(*args)` runs in `nprocs` fresh processes (multiprocessing "spawn": `fn` must be importable, i.e.
+        defined at module level, and the call sits under `if __name__ == "__main__":`); each has joined the process group
+        (init_rank: RCCL, or gloo when backend / KNERF_DIST_BACKEND says so) and has its GPU selected, so NeRF.compile finds
+        torch.distributed initialised: it broadcasts rank 0's weights and train_step all-reduces the gradients (train.py:110-148).
+    launch() without fn: re-run THIS script (sys.argv) as the ranks and exit with their code -- for an import-swapped train.py
+        that should behave like the reference's: put `parallel.launch()` (or `strategy = parallel.MirroredStrategy()`) where
+        train.py:75 builds its strategy.  Inside a rank it returns at once, after joining the process group.
+
+    nprocs None = torch.cuda.device_count() (which does not initialise the GPU).  With one device (or nprocs 1) nothing is
+    spawned: fn runs here / the script continues.  Inside a rank of ANY launcher (WORLD_SIZE set, e.g. torch.distributed.run) no
+    second level is spawned either.  Returns the job's exit code (0) -- a failed rank raises SystemExit(code) in the parent."""
+    if "WORLD_SIZE" in os.environ:                 # already a rank: join the group, run, leave
+        init_rank(backend)
+        if fn is not None:
+            try:
+                fn(*args)
+            except Exception as e:                 # noqa: BLE001
+                if int(os.environ["WORLD_SIZE"]) > 1:
+                    rank_fail(f"{getattr(fn, '__name__', 'fn')}()", e)
+                raise
+        return 0
+    backend = backend or os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    n = int(nprocs) if nprocs is not None else max(n_dev, 1)
+    if n < 1:
+        raise ValueError("nprocs must be >= 1")
+    if n == 1:
+        dist_env(1)
+        if fn is not None:
+            fn(*args)
+        return 0
+    if backend == "nccl" and n > n_dev:
+        raise SystemExit(f"launch: {n} ranks but only {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
+                         f"(KNERF_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)")
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        raise RuntimeError("launch must be called before this process touches the GPU (rank processes are started first)")
+    dist_env(n)
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    if fn is None:
+        import subprocess
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_PORT=str(port),
+                       KNERF_DIST_BACKEND=backend)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0]), *sys.argv[1:]], env=env))
+        code = _wait_ranks(procs, lambda p: p.poll(), lambda p: p.terminate(), os.path.basename(sys.argv[0]))
+        raise SystemExit(code)                     # the parent was only the launcher: the script's body ran in the ranks
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_entry, args=(fn, tuple(args), r, n, port, backend), daemon=False) for r in range(n)]
+    for p in procs:
+        p.start()
+    code = _wait_ranks(procs, lambda p: p.exitcode if not p.is_alive() else None, lambda p: p.terminate(), getattr(fn, "__name__", "fn"))
+    if code:
+        raise SystemExit(code)
+    return 0
+
+
+class MirroredStrategy:
+    """`strategy = tf.distribute.MirroredStrategy()` (train.py:75) for an import-swapped script: constructing it in a plain
+    `python train.py` starts one rank process per GPU that re-runs the script (launch()), and in each rank joins the process group;
+    `num_replicas_in_sync` (train.py:76, 84) is the world size, `scope()` (train.py:110) a no-op context -- NeRF.compile mirrors
+    the variables itself (weight broadcast from rank 0).  devices: a count or a list, like the reference's optional argument."""
+
+    def __init__(self, devices=None, backend: str = None):
+        n = len(devices) if isinstance(devices, (list, tuple)) else devices
+        launch(None, n, backend=backend)
+        self.num_replicas_in_sync = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def scope(self):
+        import contextlib
+        return contextlib.nullcontext(self)

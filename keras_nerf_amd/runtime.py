@@ -25,6 +25,9 @@ def _f32(x, device) -> torch.Tensor:
     return x.to(device=device, dtype=torch.float32).contiguous()
 
 
+_GENERIC_SHAPES_WARNED = set()      # shapes already reported as "coverable by build.py --add-shape" (one warning each per process)
+
+
 class _CudaView:
     def __init__(self, ptr: int, n: int, typestr: str):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
@@ -35,9 +38,10 @@ class KnerfContext:
 
     def __init__(self, n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4,
                  white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None,
-                 force_generic=None, options=None):
+                 force_generic=None, options=None, encoded_widths=None):
         """force_generic: run the default MLP shape through the general-shape kernels as well (tests).  options: {name: value}
-        for knerf_set_option.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
+        for knerf_set_option.  encoded_widths = (xyz_dim, dir_dim): a stand-alone NeRFMLP of those two input widths
+        (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
         KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
         KNERF_SKIP_DEAD_TILES into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
@@ -51,9 +55,12 @@ class KnerfContext:
         import os
         if force_generic is None:
             force_generic = bool(os.environ.get("KNERF_FORCE_GENERIC"))
+        flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+        if encoded_widths is not None:
+            pos_emb_xyz, pos_emb_dir = (int(v) for v in encoded_widths)
+            flags |= _lib.FLAG_ENCODED_WIDTHS
         self.cfg = KnerfConfig(n_coarse, n_fine, pos_emb_xyz, pos_emb_dir, n_layers, dense_units, skip_layer,
-                               int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon,
-                               _lib.FLAG_FORCE_GENERIC if force_generic else 0)
+                               int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon, flags)
         self.n_coarse, self.n_fine = n_coarse, n_fine
         rc = self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
         if rc != 0:
@@ -61,15 +68,20 @@ class KnerfContext:
             self._ctx = C.c_void_p()
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
         self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
-        if not force_generic and self.get_option("general_shape_path"):
+        if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
             # a shape outside the library's list: say what it costs and, where the fused kernels could cover it, how to get them
             import logging
             coverable = (dense_units in (64, 128, 256) and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
                          and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8)
             spec = f"{n_layers},{skip_layer},{dense_units}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
-            logging.info("NeRFMLP(n_layers=%d, dense_units=%d, skip_layer=%d), pos_emb %d/%d runs on the general-shape kernels (about 3x slower per "
-                         "FLOP than the fused chain)%s", n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir,
-                         f"; `python keras_nerf_amd/build.py --add-shape={spec}` builds the fused kernels for it" if coverable else "")
+            # visible at the default log level when there is something the user can do about it, once per shape
+            say = logging.info
+            if coverable and spec not in _GENERIC_SHAPES_WARNED:
+                _GENERIC_SHAPES_WARNED.add(spec)
+                say = logging.warning
+            say("NeRFMLP(n_layers=%d, dense_units=%d, skip_layer=%d), pos_emb %d/%d runs on the general-shape kernels (about 3x slower per "
+                "FLOP than the fused chain)%s", n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir,
+                f"; `python keras_nerf_amd/build.py --add-shape={spec}` builds the fused kernels for it" if coverable else "")
         opts = {}
         env = os.environ
         for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),

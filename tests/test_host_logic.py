@@ -21,8 +21,11 @@ def test_focal_known_answer_and_pose_match_oracle():
 
 def test_mlp_shapes_params_and_keras_order():
     m = NeRFMLP(8, 256, 4)
+    with pytest.raises(ValueError, match="not built"):       # Keras: count_params of an unbuilt model raises
+        m.count_params()
+    assert m.get_weights() == [] and not m.built             # ... and it has no variables yet (mlp.py:11-27 names no input size)
+    m.build()                                                # no shape given: the reference NeRF's own encodings, 63 / 27
     assert m.count_params() == 595844
-    m.build()
     ws = m.get_weights()
     assert len(ws) == 24 and ws[0].shape == (63, 256) and ws[10].shape == (319, 256) and ws[16].shape == (256, 1)
     assert ws[20].shape == (283, 128) and ws[22].shape == (128, 3)
@@ -31,6 +34,40 @@ def test_mlp_shapes_params_and_keras_order():
     assert np.abs(ws[0]).max() <= lim and np.abs(ws[0]).max() > 0.9 * lim          # glorot_uniform
     assert [s[0] for s in layer_shapes(8, 256, 4, 63, 27)] == [s[0] for s in O.layer_shapes(O.NerfConfig())]
     assert m.get_config()["n_layers"] == 8 and m.get_config()["dense_units"] == 256 and m.get_config()["skip_layer"] == 4
+
+
+def test_mlp_widths_are_fixed_by_build_weights_or_file_like_keras_dense(tmp_path):
+    """the host half of Keras Dense's lazy input size (the call itself needs the GPU: tests/test_gpu_reference_shapes.py)"""
+    m = NeRFMLP(8, 256, 4, seed=1)
+    m.build(((None, 32, 99), (None, 32, 99)))                # what Keras passes to build(): the reference test's 99-wide inputs
+    assert (m.xyz_dim, m.dir_dim) == (99, 99) and m.get_weights()[0].shape == (99, 256) and m.get_weights()[20].shape == (355, 128)
+    assert m.count_params() == sum(w.size for w in m.get_weights())
+    with pytest.raises(ValueError, match=r"99.*63"):
+        m.build(((None, 63), (None, 27)))                    # a built model refuses other widths, naming both
+    with pytest.raises(ValueError):
+        NeRFMLP(8, 256, 4, xyz_dim=63)                        # the two extension arguments come together
+    # an unbuilt model adopts the widths of the weights it is given ...
+    m2 = NeRFMLP(8, 256, 4)
+    m2.set_weights(m.get_weights())
+    assert (m2.xyz_dim, m2.dir_dim) == (99, 99)
+    np.testing.assert_array_equal(m2.get_flat_weights(), m.get_flat_weights())
+    with pytest.raises(ValueError):
+        NeRFMLP(8, 256, 4).set_weights(m.get_weights()[:-2])
+    # ... or of the file it loads (Keras-layout HDF5 and .npz)
+    for name in ("w.h5", "w.npz"):
+        m.save_weights(str(tmp_path / name))
+        m3 = NeRFMLP(8, 256, 4); m3.load_weights(str(tmp_path / name))
+        assert (m3.xyz_dim, m3.dir_dim) == (99, 99)
+        np.testing.assert_array_equal(m3.get_flat_weights(), m.get_flat_weights())
+    with pytest.raises(ValueError, match="not built"):
+        NeRFMLP(8, 256, 4).save_weights(str(tmp_path / "none.h5"))
+    with pytest.raises(ValueError, match="not built"):
+        NeRFMLP(8, 256, 4).summary()
+    # a flat vector carries no shapes: only the reference NeRF's widths can be meant
+    m4 = NeRFMLP(8, 256, 4); m4.set_flat_weights(np.zeros(595844, np.float32))
+    assert (m4.xyz_dim, m4.dir_dim) == (63, 27)
+    with pytest.raises(ValueError):
+        NeRFMLP(8, 256, 4).set_flat_weights(np.zeros(m.count_params(), np.float32))
 
 
 def test_weight_file_roundtrip(tmp_path):
@@ -129,7 +166,7 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_hip():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
-    assert "only" in r.stderr and "GPU(s) visible" in r.stderr and "--gpus 2" in r.stderr
+    assert "only" in r.stderr and "GPU(s) visible" in r.stderr and "2 ranks" in r.stderr       # keras_nerf_amd/parallel.py launch
     assert "{" not in r.stdout              # no JSON line
 
 
@@ -265,7 +302,10 @@ def test_zero_gradient_messages_are_the_references(caplog):
             return 1.0
 
         def tile_stats_net(self, reset=True):
-            return self.stats
+            # the library's counters are RUNNING totals; the diagnostics must read them without resetting (other consumers
+            # accumulate across steps) and difference against their previous read
+            assert reset is False
+            return self.running
     nerf = NeRF.__new__(NeRF)
     nerf._ctx, nerf._diag_seen = Ctx(), 0
     assert nerf._zero_gradient_diagnostics(wait=True) is None                      # nothing published yet
@@ -274,6 +314,8 @@ def test_zero_gradient_messages_are_the_references(caplog):
                                 ((4, 0), ((2, 8), (0, 24)), [(logging.WARNING, "Fine Gradient is zero")]),
                                 ((4, 9), ((2, 8), (3, 24)), [])):
         nerf._ctx.seq += 1; nerf._ctx.counts, nerf._ctx.stats = counts, stats
+        prev = getattr(nerf._ctx, "running", ((0, 0), (0, 0)))
+        nerf._ctx.running = tuple((p[0] + s_[0], p[1] + s_[1]) for p, s_ in zip(prev, stats))      # this step's tiles on top of the totals
         caplog.clear()
         with caplog.at_level(logging.WARNING):
             assert nerf._zero_gradient_diagnostics(wait=True) == counts
