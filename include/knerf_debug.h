@@ -25,7 +25,8 @@ int knerf_debug_table(int kind, int32_t* out, size_t* n);
  * kernel row0), seg1 (...), relu, head (-1 | 0 sigma | 1 rgb), padded width of the output buffer or -1}. */
 int knerf_debug_generic_plan(const knerf_config* cfg, int32_t* out, size_t* n);
 /* device buffers of the last knerf_train_chunk for kernel-level tests: 0 act, 1 mask, 2 dz, 3 raw, 4 draw,
- * 5 merged fine t-values, 6 coarse weights, 7 extended weight buffer of `net` (parameters + composed head) */
+ * 5 merged fine t-values, 6 coarse weights, 7 extended weight buffer of `net` (parameters + composed head); on a context of the
+ * general-shape path (csrc/generic.h): 8 all activation buffers, 9 all dZ buffers of the last pass (0-2 belong to the fused path) */
 int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* bytes);
 /* hardware-fact probes: kind 0 = one v_mfma_f32_32x32x16_bf16 (in0 = A fragments [64][8] bf16, in1 = B fragments,
  * out = [64][16] f32); kind 1 = one ds_read_b64_tr_b16 (in0 = 4 KiB LDS image, in1 = [64] int32 byte offsets,

@@ -85,6 +85,17 @@ def _spill_report(name: str, remarks: str):
     return None if n_kernels else f"{name}: hipcc printed no kernel-resource-usage remarks, the spill check cannot run"
 
 
+def _deps(obj: str, fallback):
+    """the headers an object was built from, from hipcc's own dependency file (`-MMD -MF <obj>.d`, written next to the object);
+    without one (objects of an older build): every header of the tree"""
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return fallback
+    txt = open(d).read().replace("\\\n", " ")
+    parts = txt.split(":", 1)[1].split() if ":" in txt else []
+    return [x for x in parts if x.endswith((".h", ".hpp")) and not x.startswith(("/opt/", "/usr/"))] or fallback
+
+
 def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
@@ -100,11 +111,11 @@ def _compile(hipcc, sources, objdir, flags, force, verbose, n_slices):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, obj)
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in hdr_paths):
+        if force or _newer(s, o) or any(_newer(h, o) for h in _deps(o, hdr_paths)):
             # the three big kernels wait on hand-counted vmcnt / lgkmcnt values (chain.h StoreSched, frag_wait): a register spill --
             # scratch traffic counts in vmcnt -- would break them silently, so every instantiation's resource report is checked
             guard = ["-Rpass-analysis=kernel-resource-usage"] if src in SLICED else []
-            todo.append((obj, [hipcc, *flags, *extra, *guard, "-c", s, "-o", o], bool(guard)))
+            todo.append((obj, [hipcc, *flags, *extra, *guard, "-MMD", "-MF", o + ".d", "-c", s, "-o", o], bool(guard)))
     limit = max(1, min(len(todo), (os.cpu_count() or 8)))      # hipcc processes in flight
     running = []
     while todo or running:
@@ -157,7 +168,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), variant: str = 
     if not os.path.exists(sig_file) or open(sig_file).read() != sig:
         force = force or any(f.endswith(".o") for f in os.listdir(objdir))
         for f in os.listdir(objdir):          # objects of slices that no longer exist must not linger
-            if f.endswith(".o"):
+            if f.endswith((".o", ".o.d")):
                 os.remove(os.path.join(objdir, f))
     objs, changed = _compile(hipcc, SOURCES, objdir, flags, force, verbose, n_slices)
     pobjs, pchanged = _compile(hipcc, PROBE_SOURCES, objdir, flags, force, verbose, n_slices)

@@ -70,6 +70,9 @@ int knerf_debug_buffer(knerf_ctx* ctx, int net, int which, void** dev, size_t* b
         case 7:
             if (net != 0 && net != 1) return KNERF_ERR_INVALID;
             *dev = ctx->net[net].w; *bytes = (size_t)(ctx->generic ? ctx->n_params : ctx->si.ext_param_count) * sizeof(float); break;
+        // general-shape path (generic.h): every activation buffer [Mp][ld] bf16 / every dZ buffer of the last pass
+        case 8: *dev = ctx->gws.act; *bytes = ctx->gplan.act_elems_per_row * ctx->gws.mp * sizeof(unsigned short); break;
+        case 9: *dev = ctx->gws.dz; *bytes = ctx->gplan.dz_elems_per_row * ctx->gws.mp * sizeof(unsigned short); break;
         default: return KNERF_ERR_INVALID;
     }
     // not allocated: no pass has run yet, or the buffer belongs to the fused path and this context runs the general-shape kernels

@@ -75,6 +75,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP(var)
 #endif
 
+// KNERF_WGRAD_ABLATE_LDS (PMC experiments only, DESIGN.md 2.5 "LDS bank conflicts"; results are wrong, the counters are the point):
+// bit 0: the sixteen ds_read_b32 of the layer-7 mask words per tile become one broadcast read; bit 1: the row-wise ds_read_b128 of
+// sample-major blocks (enc in the layer_1 job, dz_head in the layer_7 job) read linearly (lane * 16) instead of through saved_off
+#ifndef KNERF_WGRAD_ABLATE_LDS
+#define KNERF_WGRAD_ABLATE_LDS 0
+#endif
+
 struct WgradPlan {          // one entry per workgroup, built on the host (knerf_api.hip)
     int job, split, nsplit, pad;
 };
@@ -438,7 +445,7 @@ __device__ __forceinline__ void wgrad_l1_recompute(const WgradArgs& a, const Seq
         for (int r = 0; r < 16; ++r) h[r] = b0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 e = *reinterpret_cast<const bf16x8*>(reg + ks * 1024 + (enc_off ^ ((ks & 1) << 7)));
+            const bf16x8 e = *reinterpret_cast<const bf16x8*>(reg + ks * 1024 + ((KNERF_WGRAD_ABLATE_LDS & 2) ? lane * 16 : (enc_off ^ ((ks & 1) << 7))));
             h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e, w0[ks], h, 0, 0, 0);
         }
         bf16x8 lo, hi;
@@ -554,11 +561,11 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
     // my strip of dz7 for one tile's 32 samples, in two steps so that the loop can put the second one behind MFMAs of the
     // current tile: (1) the MFMA and the mask words, (2) select + round
     auto dz7_mfma = [&](const char* x_reg, f32x16& dzf, unsigned (&mw)[16]) {
-        const bf16x8 z = *reinterpret_cast<const bf16x8*>(x_reg + zoff);
+        const bf16x8 z = *reinterpret_cast<const bf16x8*>(x_reg + ((KNERF_WGRAD_ABLATE_LDS & 2) ? lane * 16 : zoff));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int smp = (r & 3) + 8 * (r >> 2) + 4 * hh;             // sample row of accumulator register r
-            mw[r] = *reinterpret_cast<const unsigned*>(x_reg + 1024 + smp * 16 + moff);
+            const int smp = (KNERF_WGRAD_ABLATE_LDS & 1) ? 0 : (r & 3) + 8 * (r >> 2) + 4 * hh;             // sample row of accumulator register r
+            mw[r] = *reinterpret_cast<const unsigned*>(x_reg + 1024 + smp * 16 + ((KNERF_WGRAD_ABLATE_LDS & 1) ? 0 : moff));
         }
         dzf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z, hfrag, zero_acc(), 0, 0, 0);
     };

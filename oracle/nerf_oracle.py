@@ -107,11 +107,17 @@ def unflatten_params(flat: np.ndarray, cfg: NerfConfig) -> List[np.ndarray]:
 
 
 def round_bf16(x: np.ndarray) -> np.ndarray:
-    """Round-to-nearest-even fp32 -> bf16 -> fp32 (finite inputs)."""
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (finite inputs): (u + 0x7FFF + bit 16 of u) & 0xFFFF0000 on the bit pattern u.
+    In uint32 with in-place steps (round 5; rounds 1-4 widened to uint64 and spent 70 % of every oracle call here): the sum cannot
+    wrap for finite inputs (u <= 0xFF7FFFFF).  tests/test_oracle_kat.py pins it against the widened form and hand-picked ties."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
-    return u.astype(np.uint32).view(np.float32).reshape(x.shape)
+    u = x.view(np.uint32)
+    r = u >> np.uint32(16)
+    r &= np.uint32(1)
+    r += np.uint32(0x7FFF)
+    r += u
+    r &= np.uint32(0xFFFF0000)
+    return r.view(np.float32).reshape(x.shape)
 
 
 # --------------------------------------------------------------------------------------
@@ -272,7 +278,7 @@ FUSED = "fused"
 
 def _rb(x):
     """a matmul operand as the MFMA kernels see it: rounded to bf16, held in fp32"""
-    return round_bf16(x).astype(np.float32)
+    return round_bf16(x)                   # already a fresh fp32 array
 
 
 def _mm(a, w, emulate_bf16):

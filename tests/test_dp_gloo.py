@@ -137,3 +137,59 @@ def test_eight_ranks_cfg4_shape_of_the_glue():
         assert z["mine"].size == 12
         seen += z["mine"].tolist()
     assert len(set(seen)) == 96 and rs[0]["gsum"] == rs[7]["gsum"]
+
+
+def _launch_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KNERF_DIST_BACKEND",
+                                                           "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_DEBUG_FILE")}
+
+
+def _check_ranks(out_dir, n):
+    import json
+    rs = [json.load(open(os.path.join(out_dir, f"rank{r}.json"))) for r in range(n)]
+    for r, z in enumerate(rs):
+        assert z["rank"] == r and z["world"] == n and z["w"] == 1.0 and z["g1"] == n * (n + 1) / 2 and z["loss"] == pytest.approx((n - 1) / 2)
+        assert z["master"] == "127.0.0.1" and z["ipc"] == "0" and z["nccl_debug"] == "WARN" and z["is_main"] == (r == 0)
+    assert len({z["pid"] for z in rs}) == n          # one process per rank
+    return rs
+
+
+def test_launch_runs_a_function_on_eight_ranks(tmp_path):
+    """keras_nerf_amd.parallel.launch(fn, nprocs): the MirroredStrategy() of this implementation (train.py:75-93, 110-148) -- eight
+    fresh rank processes (started before the parent touches any GPU, never an exec), each inside the process group with the launch
+    environment set for it (rendezvous on 127.0.0.1, dmabuf IPC, RCCL warnings to a per-rank file), run `fn`; here over gloo on the
+    CPU, on the driver's node over RCCL."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import body; "
+            "rc = parallel.launch(body, 8, args=(%r,), backend='gloo'); print('launch returned', rc)") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_launch_env())
+    assert r.returncode == 0 and "launch returned 0" in r.stdout, r.stderr[-3000:]
+    _check_ranks(str(tmp_path), 8)
+
+
+def test_launch_rerun_script_form_like_mirrored_strategy(tmp_path):
+    """`strategy = parallel.MirroredStrategy()` at the top of a script (where train.py:75 builds its strategy): plain `python script.py`
+    becomes the launcher of N ranks that re-run the script; `num_replicas_in_sync` is the world size inside them"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "launch_worker.py"), str(tmp_path), "4"],
+                       capture_output=True, text=True, timeout=300, env=_launch_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_ranks(str(tmp_path), 4)
+
+
+def test_launch_stops_everything_when_one_rank_fails(tmp_path):
+    """a rank that raises names itself, leaves with code 3, and the launcher terminates its peers (which are blocked in a collective
+    with it) by their handles within seconds -- no collective time-out, no orphan processes"""
+    import subprocess
+    import sys
+    import time
+    code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import hang_unless_zero; "
+            "parallel.launch(hang_unless_zero, 4, args=(%r,), backend='gloo')") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_launch_env())
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 120
+    assert "[knerf rank 1/4] FAILED in hang_unless_zero()" in r.stderr and "rank 1 fails on purpose" in r.stderr
+    assert "stopping the other" in r.stderr

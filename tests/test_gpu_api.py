@@ -312,9 +312,10 @@ def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
 
 
 def test_bench_spawns_its_own_ranks_gloo_rehearsal():
-    """`python bench.py --gpus 2` with no launcher: the parent starts two rank processes before touching HIP and rank 0's
-    line says n_gpus 2.  On this one-GPU box the ranks share the device over gloo (KNERF_DIST_BACKEND=gloo); with the default
-    backend the same command must refuse (RCCL needs one GPU per rank)."""
+    """`python bench.py --gpus 2` with no launcher: the parent (keras_nerf_amd.parallel.launch) starts two rank processes before touching
+    HIP and rank 0's line says n_gpus 2.  On this one-GPU box the ranks share the device over gloo (KNERF_DIST_BACKEND=gloo); with the
+    default backend the same command must refuse (RCCL needs one GPU per rank).  The render loop (cfg5) is the two-rank case here; the
+    train step's self-spawned ranks are asserted on the three-rank line of test_cfg4_rehearsal_* (one spawn for both, round 5)."""
     import json
     import subprocess
     import sys
@@ -322,21 +323,16 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal():
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KNERF_DIST_BACKEND")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "cfg4",
            "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(base, KNERF_DIST_BACKEND="gloo"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and line["dist_backend"] == "gloo"
-    assert line["config"]["parallelism"] == "dp2" and line["value"] > 0
-    assert line["ms_per_step_rank_min"] <= line["ms_per_step_rank_max"] <= line["ms_per_step"] * 1.0001
     if torch.cuda.device_count() < 2:
         r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=base)
-        assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr
+        assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr and not [x for x in r2.stdout.splitlines() if x.startswith("{")]
     # the render loop (cfg5) with two ranks: every rank renders its own frames, rank 0 reports frames/s of both
     cmd5 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "cfg5"]
-    r5 = subprocess.run(cmd5, capture_output=True, text=True, timeout=600, env=dict(base, KNERF_DIST_BACKEND="gloo"))
+    r5 = subprocess.run(cmd5, capture_output=True, text=True, timeout=420, env=dict(base, KNERF_DIST_BACKEND="gloo"))
     assert r5.returncode == 0, r5.stderr[-2000:]
     line5 = json.loads([x for x in r5.stdout.splitlines() if x.startswith("{")][-1])
     assert line5["n_gpus"] == 2 and line5["unit"] == "frames/s" and line5["value"] > 0 and line5["steps"] == 4
+    assert line5["rccl_ranks"] == 0 and line5["dist_backend"] == "gloo" and len(line5["ms_per_step_by_rank"]) == 2
 
 
 def test_zero_gradient_diagnostics_eager_mode(caplog):
@@ -426,7 +422,7 @@ def test_render_outputs_selection_gives_the_same_pixels():
     assert torch.equal(host, ff["image"].cpu())
 
 
-def _bench(args, env_extra, timeout=900):
+def _bench(args, env_extra, timeout=420):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -451,7 +447,17 @@ def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     assert line["n_gpus"] == 3 and line["dist_backend"] == "gloo" and line["config"]["parallelism"] == "dp3" and line["config"]["global_batch_images"] == 3
     assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
     assert line["grad_bytes"] == 2 * 595844 * 4 and line["allreduce_ms_per_step"] > 0
-    assert line["value"] > 0 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["rccl_ranks"] == 0
+    assert line["ms_per_step_rank_min"] <= line["ms_per_step_rank_max"] <= line["ms_per_step"] * 1.0001
+    # round 5: the first N > 1 run on real hardware has nobody to debug it, so the line diagnoses its own collective -- every rank's
+    # time (not only min / max), 20 stand-alone all-reduces of the real 4.77 MB operand before the timed region (HIP events), the bus
+    # bandwidth they imply, the library version -- and the metrics' cost comes from HIP events around their three launches
+    per = line["ms_per_step_by_rank"]
+    assert len(per) == 3 and min(per) == pytest.approx(line["ms_per_step_rank_min"], rel=1e-3) and max(per) == pytest.approx(line["ms_per_step_rank_max"], rel=1e-3)
+    st = line["allreduce_us_standalone"]
+    assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] and st["host_wall_us_median"] > 0 and line["allreduce_busbw_GBps"] > 0
+    assert "rccl_version" in line
+    assert 0 < line["metrics_ms_per_step"] < 5 and "hip events" in line["metrics_clock"]
     for k in range(3):
         assert f"[bench rank {k}/3] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
         assert f"[bench rank {k}/3] device memory free" in r.stderr
@@ -470,7 +476,7 @@ def test_a_failing_rank_ends_the_run_at_once_with_its_name():
     for stage in ("init", "warmup"):               # the first and the last guarded stage (bench.py also guards first_all_reduce and compile)
         t0 = time.time()
         r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline", "--no-profile"],
-                   {"KNERF_DIST_BACKEND": "gloo", "KNERF_BENCH_INJECT_FAILURE": f"1:{stage}"}, timeout=400)
+                   {"KNERF_DIST_BACKEND": "gloo", "KNERF_BENCH_INJECT_FAILURE": f"1:{stage}"}, timeout=300)
         assert r.returncode != 0, stage
         assert "[bench rank 1/2] FAILED in" in r.stderr and "injected failure" in r.stderr, (stage, r.stderr[-2000:])
         assert not [x for x in r.stdout.splitlines() if x.startswith("{")], stage          # no JSON line from a broken job

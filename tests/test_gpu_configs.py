@@ -5,7 +5,8 @@ cfg5  inference.py-shaped render, 256x256, ray_chunks 4096 (16 chunks): RaysGene
       the GPU's own t-values).
 cfg3  400x400, batch 1: ray_chunks 16384 violates the divisibility assert (nerf.py:100), 16000 trains; one train_batch
       equals ten train_chunk calls; the gradients of a sampled sub-chunk against the oracle.
-cfg1  the coarse-only configuration (n_fine = 0) TRAINED, not only rendered: gradients of both nets against the oracle.
+cfg1  the coarse-only configuration (n_fine = 0) TRAINED, not only rendered: gradients of both nets against the oracle -- at 16 x 16 in
+      one chunk, and AS WRITTEN (64 x 64, four chunks of 1,024 through knerf_train_batch) through an exact zero-gradient property.
 cfg4 needs eight GPUs and is the driver's to run; its per-GPU work is cfg2's with one image.
 """
 import numpy as np
@@ -269,6 +270,61 @@ def test_coarse_only_configuration_trains_both_nets_against_oracle():
     ctx.apply_adam()
     assert ctx.step == 1 and np.abs(ctx.get_weights(0) - O.flatten_params(cp)).max() > 0
     ctx.close()
+
+
+def test_cfg1_as_written_64x64_in_four_chunks_of_1024_against_oracle():
+    """BASELINE configs[0] AS WRITTEN on the GPU: lego-shaped 64 x 64 image, batch 1, ray_chunks 1024 -> 4 chunks,
+    coarse-only (n_fine = 0: the second network runs on the coarse t-values, nerf.py:182-191), through knerf_train_batch -- full-size
+    launches, the coarse weight gradients of the four chunks in one grouped launch.  The NumPy oracle cannot do 4,096 rays in
+    seconds, so the comparison uses an EXACT property instead of a smaller problem: a ray whose target equals the rendered pixel has
+    dL/dimage = 0 and contributes exactly nothing to any gradient (utils.py:36-58, train_single.py:127).  The step runs with the
+    net's own render as the target everywhere except on 256 sampled rays (64 from every chunk), which keep random targets: the
+    accumulated gradient of all 4,096 rays is then the oracle's gradient of those 256 rays x 256/4096, per tensor, and the step's
+    loss the oracle's x 256/4096.  Once per net (the two nets render different images), the coarse check with dead-tile skipping
+    on (lists with holes: 7/8 of the tiles are dead), the second net's with skipping off (contiguous launches)."""
+    from keras_nerf_amd.data.rays import RaysGenerator
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    from keras_nerf_amd.runtime import KnerfContext
+    wh, R, C = 64, 1024, 4
+    N = wh * wh
+    cfg = O.NerfConfig(n_coarse=64, n_fine=0)
+    cp, fp = problem_weights(cfg)
+    o, d, t = RaysGenerator(get_focal_from_fov(FOV, wh), wh, wh, 2.0, 6.0, 64, seed=4)(pose_spherical(55.0, -30.0, 4.0))
+    o, d, t = o.reshape(N, 3).contiguous(), d.reshape(N, 3).contiguous(), t.reshape(N, 64).contiguous()
+    rng = np.random.default_rng(12)
+    idx = np.sort(np.concatenate([c * R + rng.choice(R, 64, replace=False) for c in range(C)]))
+    ti = torch.as_tensor(idx, device="cuda")
+    rnd = torch.rand((N, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    so, sd, st, sg = (x[ti].cpu().numpy() for x in (o, d, t, rnd))
+    for net, params, skip in ((0, cp, 1), (1, fp, 0)):
+        ctx = KnerfContext(n_coarse=64, n_fine=0, white_background=False, options=dict(skip_dead_tiles=skip))
+        ctx.set_weights(0, O.flatten_params(cp)); ctx.set_weights(1, O.flatten_params(fp))
+        ren = ctx.render_batch(o, d, t, None, ray_chunks=R)
+        tgt = ren["c_image" if net == 0 else "f_image"].clone()
+        tgt[ti] = rnd[ti]
+        loss = torch.zeros(2, device="cuda"); ci = torch.empty((N, 3), device="cuda"); fi = torch.empty((N, 3), device="cuda")
+        ctx.zero_grads(); ctx.tile_stats(reset=True)
+        ctx.train_batch(o, d, t, tgt, None, ray_chunks=R, loss=loss, c_image=ci, f_image=fi)
+        torch.cuda.synchronize()
+        assert torch.equal(ci, ren["c_image"]) and torch.equal(fi, ren["f_image"])      # training and rendering share the kernels' arithmetic
+        assert ctx.get_option("wgrad_group") == 4.0                                     # the four coarse passes left in ONE weight-gradient launch
+        live, total = ctx.tile_stats(reset=True)
+        if skip:                                                                        # 2 passes x 4 chunks x 2,048 tiles; the net under test keeps its 256 rays' tiles
+            assert total == 2 * C * R * 64 // 32 and 0 < live <= 256 * 2 + total // 2, (live, total)
+        n = ctx.param_count
+        g = ctx.grads_view().cpu().numpy()[net * n:(net + 1) * n] * (N / 256.0)
+        got_loss = float(loss[net]) * (N / 256.0)
+        mine = (ci if net == 0 else fi)[ti].cpu().numpy()
+        for emu, tol in ((O.FUSED, GRAD_TOL_EMU), (False, GRAD_TOL_FP32)):
+            r, l, gr = O.chunk_loss_and_grads(params, so, sd, st, sg, cfg, False, emulate_bf16=emu)
+            e = per_tensor_err(g, O.flatten_params(gr), cfg)
+            log_stats(f"cfg1_as_written_net{net}_emulate_{emu}", worst=e[0], loss=abs(got_loss - float(l)), img=np.abs(mine - r["image"]).max())
+            assert e[0] < tol, (net, emu, e)
+            assert abs(got_loss - float(l)) < 3e-3, (got_loss, float(l))
+            np.testing.assert_allclose(mine, r["image"], atol=1e-2 if emu else 2e-2)
+        ctx.apply_adam()
+        assert ctx.step == 1
+        ctx.close()
 
 
 def test_lego_camera_of_the_reference_ray_test():

@@ -1,9 +1,11 @@
 """Race screen for the hand-synchronised kernels (LDS-DMA ring with counted vmcnt, staggered wave groups, inline-asm stores):
 the chain kernels contain no atomics, so at bench size their outputs and every saved block must be bit-identical from
-launch to launch; the sampler likewise.  Only the fp32-atomic gradient flush may differ in the last bits."""
-import hashlib
+launch to launch; the sampler likewise.  Only the fp32-atomic gradient flush may differ in the last bits -- and in deterministic
+mode not even that.  The same for the general-shape kernels (csrc/generic.hip: encode, per-layer GEMMs, head forward / backward
+are atomics-free).
 
-import numpy as np
+Digest: an exact position-weighted 64-bit checksum computed ON THE DEVICE (two independent weightings; integer arithmetic wraps, so
+it is deterministic) -- rounds 1-4 copied 6.5 GB per repetition to the host for a SHA-1, 30 s of the suite."""
 import pytest
 from keras_nerf_amd.debug import debug_buffer
 import torch
@@ -12,21 +14,44 @@ pytestmark = pytest.mark.gpu
 
 
 def _digest(t):
-    return hashlib.sha1(t.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()
+    """(sum_i w1_i x_i, sum_i w2_i x_i) mod 2^64 over the buffer's 64-bit words, w1 = 2 (i mod 8191) + 1, w2 = 2 (i mod 127 + 3 i mod 65521) + 1:
+    any change of one word changes both sums (odd weights are units mod 2^64); an exchange of two words changes at least one"""
+    b = t.contiguous().view(torch.uint8).reshape(-1)
+    n = b.numel() // 8 * 8
+    x = b[:n].view(torch.int64)
+    out = []
+    for lo in range(0, x.numel(), 1 << 26):            # bounded temporaries: 512 MB of words at a time
+        xs = x[lo:lo + (1 << 26)]
+        i = torch.arange(lo, lo + xs.numel(), device=xs.device, dtype=torch.int64)
+        out.append(((xs * (2 * (i % 8191) + 1)).sum(), (xs * (2 * (i % 127 + 3 * (i % 65521)) + 1)).sum()))
+    tail = int(b[n:].to(torch.int64).sum()) if n < b.numel() else 0
+    return (sum(int(a) for a, _ in out) & (2 ** 64 - 1), sum(int(c) for _, c in out) & (2 ** 64 - 1), tail)
+
+
+def test_digest_sees_single_bit_flips_and_exchanges():
+    x = torch.arange(100000, device="cuda", dtype=torch.float32)
+    d0 = _digest(x)
+    y = x.clone(); y[77777] = torch.nextafter(y[77777], y[77777] + 1); assert _digest(y) != d0
+    z = x.clone(); z[[5, 9000]] = z[[9000, 5]]; assert _digest(z) != d0
+    assert _digest(x.clone()) == d0
+
+
+def _bench_chunk(ctx, n_coarse=64):
+    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
+    o, d, t = ctx.generate_rays(pose_spherical(33.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, 64), 64, 64, 2.0, 6.0,
+                                n_coarse, None, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    return (o.reshape(-1, 3), d.reshape(-1, 3), t.reshape(-1, n_coarse), torch.rand((4096, 3), device="cuda", generator=g),       # 4096 rays = one bench chunk
+            torch.rand((4096, 128), device="cuda", generator=g))
 
 
 def test_chain_kernels_are_bit_reproducible_at_bench_size():
-    from keras_nerf_amd.data.utils import get_focal_from_fov, pose_spherical
     from keras_nerf_amd.model.nerf.mlp import NeRFMLP
     from keras_nerf_amd.runtime import KnerfContext
     ctx = KnerfContext(white_background=True)
     for net in (0, 1):
         m = NeRFMLP(seed=net); m.build(); ctx.set_weights(net, m.get_flat_weights() * 1.5)
-    o, d, t = ctx.generate_rays(pose_spherical(33.0, -30.0, 4.0)[None], get_focal_from_fov(0.6911112070083618, 64), 64, 64, 2.0, 6.0,
-                                64, None, seed=3)
-    o, d, t = o.reshape(-1, 3), d.reshape(-1, 3), t.reshape(-1, 64)          # 4096 rays = one bench chunk
-    tgt = torch.rand((4096, 3), device="cuda")
-    u = torch.rand((4096, 128), device="cuda")
+    o, d, t, tgt, u = _bench_chunk(ctx)
     ref = None
     for rep in range(6):
         out = ctx.render_chunk(o, d, t, u)
@@ -46,3 +71,48 @@ def test_chain_kernels_are_bit_reproducible_at_bench_size():
             assert float((g - gref).abs().max()) <= 1e-5 * float(gref.abs().max())     # atomics: order only
     assert float(gref.abs().max()) > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", [dict(n_layers=8, dense_units=256, skip_layer=4, force_generic=True),          # the default shape on the general-shape kernels
+                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2)])   # cooperative and per-wave weight-gradient kernels, a width the chain does not cover
+def test_general_shape_kernels_are_bit_reproducible_at_bench_size(shape):
+    """csrc/generic.hip at the bench's chunk size (4,096 rays x 192 samples through every GEMM): outputs, every activation buffer,
+    every dZ buffer identical from launch to launch; the gradient equal up to the order of its fp32 atomics by default and
+    BIT-IDENTICAL with the option `deterministic` (per-unit slabs + ordered second pass, round 5) -- also across two contexts."""
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    from keras_nerf_amd.runtime import KnerfContext
+    kw = {k: v for k, v in shape.items() if k != "force_generic"}
+    lx, ld = kw.get("pos_emb_xyz", 10), kw.get("pos_emb_dir", 4)
+    grads = {}
+    for det in (0, 1, 1):
+        ctx = KnerfContext(white_background=True, force_generic=shape.get("force_generic"), options=dict(deterministic=det), **kw)
+        assert ctx.get_option("general_shape_path") == 1.0 and ctx.get_option("deterministic") == float(det)
+        for net in (0, 1):
+            m = NeRFMLP(kw["n_layers"], kw["dense_units"], kw["skip_layer"], seed=net, xyz_dim=3 + 6 * lx, dir_dim=3 + 6 * ld)
+            ctx.set_weights(net, m.get_flat_weights() * 1.5)
+        o, d, t, tgt, u = _bench_chunk(ctx)
+        ref = None
+        for rep in range(3):
+            out = ctx.render_chunk(o, d, t, u)
+            dig = {k: _digest(v) for k, v in out.items()}
+            ctx.zero_grads()
+            loss = torch.zeros(2, device="cuda")
+            ctx.train_chunk(o, d, t, tgt, u, loss=loss)
+            torch.cuda.synchronize()
+            dig["act"] = _digest(debug_buffer(ctx, 8)); dig["dz"] = _digest(debug_buffer(ctx, 9))
+            dig["raw"] = _digest(debug_buffer(ctx, 3)[:4096 * 192 * 16]); dig["draw"] = _digest(debug_buffer(ctx, 4)[:4096 * 192 * 16])
+            if det:
+                dig["grads"] = _digest(ctx.grads_view()); dig["loss"] = _digest(loss)
+            g = ctx.grads_view().clone()
+            if ref is None:
+                ref, gref = dig, g
+            else:
+                assert dig == ref, (det, [k for k in dig if dig[k] != ref[k]])
+                assert float((g - gref).abs().max()) <= (0.0 if det else 1e-5 * float(gref.abs().max()))
+        assert float(gref.abs().max()) > 0 and bool(torch.isfinite(gref).all())
+        grads.setdefault(det, []).append((gref, ref))
+        ctx.close()
+    (ga, da), (gb, db) = grads[1]
+    assert torch.equal(ga, gb) and da == db                                          # two contexts (two sets of allocations): the same bits
+    g0 = grads[0][0][0]
+    assert float((ga - g0).abs().max()) <= 2e-5 * float(g0.abs().max())              # deterministic = the atomic sums in another order

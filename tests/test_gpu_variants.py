@@ -23,7 +23,7 @@ def _digests(lib=None):
     env.pop("KNERF_LIB", None)
     if lib:
         env["KNERF_LIB"] = lib
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_digest.py")], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_digest.py")], capture_output=True, text=True, env=env, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -50,7 +50,7 @@ def test_build_time_extra_shapes_run_on_the_fused_kernels():
     from keras_nerf_amd import build as B
     lib = B.build(verbose=False, variant="xshape", add_shapes=XSHAPES)
     env = dict(os.environ, KNERF_LIB=lib, KNERF_PROBE_LIB=lib.replace("libknerf_hip_", "libknerf_probe_"))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_check.py")], capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_check.py")], capture_output=True, text=True, env=env, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     want = [tuple(int(v) for v in x.split(",")) for x in XSHAPES]

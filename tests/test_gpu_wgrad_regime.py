@@ -76,7 +76,7 @@ def test_4096_ray_chunk_the_bench_launch_sizes_meet_the_oracle():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_check_chunk.py"), "--rays", "4096", "--sub", "512"],
-                       capture_output=True, text=True, timeout=1200)
+                       capture_output=True, text=True, timeout=500)
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     assert lines, r.stderr[-2000:]
     out = json.loads(lines[-1])

@@ -181,3 +181,22 @@ def test_lego_camera_fixture_of_the_reference_ray_test():
     np.testing.assert_array_equal(o[5, 7], c2w[:3, 3])
     # the centre pixel looks along -z of the camera frame (rays.py:82-113: x - W/2, -(y - H/2), -1)
     np.testing.assert_allclose(d[H // 2, W // 2], -c2w[:3, 2] / np.linalg.norm(c2w[:3, 2]), atol=1e-6)
+
+
+def test_round_bf16_is_round_to_nearest_even_on_the_bit_pattern():
+    """the oracle's bf16 emulation (the kernels' operand rounding: v_cvt_pk_bf16_f32, RNE): the fast uint32 form against the
+    definition written out in uint64, on random values of every magnitude, ties to even both ways, signed zeros, the largest finite
+    value that still rounds to a finite bf16 and denormals"""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 200000).astype(np.float32),
+                        rng.integers(0, 0x7F7F0000, 100000, dtype=np.uint32).view(np.float32),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -20, 1.0 + 3 * 2.0 ** -8, 3.3895314e38, -3.3895314e38, 1e-40, 2.0 ** -126],
+                                 np.float32)])
+    u = x.view(np.uint32).astype(np.uint64)
+    want = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    got = O.round_bf16(x)
+    np.testing.assert_array_equal(got.view(np.uint32), want)
+    assert got.dtype == np.float32 and got.shape == x.shape and not np.shares_memory(got, x)
+    # ties: 1 + 2^-8 is halfway between bf16 neighbours 1 and 1 + 2^-7 -> even mantissa (1); 1 + 3 * 2^-8 -> 1 + 2^-6 (even)
+    np.testing.assert_array_equal(O.round_bf16(np.array([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8], np.float32)), np.array([1.0, 1.0 + 2.0 ** -6], np.float32))
+    assert O.round_bf16(x.reshape(3, -1)).shape == (3, x.size // 3) if x.size % 3 == 0 else True
