@@ -67,7 +67,7 @@ __device__ __forceinline__ void mlp_bwd_tile(const BwdArgs& a, char* smem, long 
 
     // everything this wave reads with ordinary loads is fetched (and waited for) before the LDS-DMA ring starts
     u32x4 mk[S::NL];
-    const char* maskp = a.mask + mask_tile_off<S>((size_t)tile) + lane * 16;
+    const char* maskp = a.mask + mask_tile_off<S>((size_t)tile) + mask_lane_off(lane);
 #pragma unroll
     for (int l = 0; l < S::NL; ++l) mk[l] = *reinterpret_cast<const u32x4*>(maskp + l * kSavedBlockStride);
     const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[g];

@@ -295,6 +295,18 @@ inline void build_bwd(PackTables& pt) {
 // so that every wgrad job reads ONE contiguous range of each:  e.g. layer_5: act[h4..enc] x dz5, head: act[h7..dir] x dz_head.
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
+// relu-mask blocks (one per trunk layer and tile; 16 B = 128 mask bits per forward lane): lane (feature half hf = lane >> 5, sample
+// s = lane & 31) keeps its 16 bytes at mask_lane_off.  Round 5: the two halves of a sample ADJACENT (32 B per sample, as in the
+// saved activation blocks).  The layer-7 weight-gradient job reads one mask word per (sample row, hf) with ds_read_b32 -- two
+// addresses per 32-lane group; with the rounds-1-4 layout (lane * 16) they lay 512 B apart = the same bank of 32 (2-way, 60 % of the
+// kernel's LDS bank conflicts: tests/test_lds_bank_model.py, profiles/r05_wgrad_lds_conflicts.json), now 16 B apart.  The forward's
+// store and the dgrad's load stay whole 1 KiB blocks per wave.  KNERF_MASK_LAYOUT=0 rebuilds the old layout for the A/B.
+#ifndef KNERF_MASK_LAYOUT
+#define KNERF_MASK_LAYOUT 1
+#endif
+constexpr int mask_lane_off(int lane) { return KNERF_MASK_LAYOUT ? ((lane & 31) * 2 + (lane >> 5)) * 16 : lane * 16; }
+// byte offset inside a mask block of word w of (sample s, feature half hf)
+constexpr int mask_word_off(int s, int hf, int w) { return mask_lane_off(hf * 32 + s) + w * 4; }
 // (block offsets of the runs: Shape::kActEnc, act_h(l), kActDir, kActBlocks, kDzHead, kDzBlocks, kMaskBlocks)
 // Byte stride between consecutive sample tiles of each saved run.  All waves of the chip write the same block of their
 // own tile at about the same time, so a stride that is a large power of two times a small odd number (e.g. 156 KiB =

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
                 // mask word of tile ot in byte lanes: even tile -> bits 0-7 / 16-23, odd tile -> bits 8-15 / 24-31
                 const unsigned m = relu_mask_bits(out[2 * ot], out[2 * ot + 1]);
                 if (ot & 1) mbits[ot >> 1] |= m << 8; else mbits[ot >> 1] = m;
-                if (ot == T - 1) store16_wt(maskp, (unsigned)(layer * kSavedBlockStride + lane * 16), u32x4{mbits[0], mbits[1], mbits[2], mbits[3]});
+                if (ot == T - 1) store16_wt(maskp, (unsigned)(layer * kSavedBlockStride + mask_lane_off(lane)), u32x4{mbits[0], mbits[1], mbits[2], mbits[3]});
             }
         };
     };

@@ -537,7 +537,7 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
         // forward (mlp_fwd.hip relu_epi): the lane of sample s and half hf = (c >> 2) & 1 holds feature 32 ot + c of out tile ot in
         // accumulator register i = (c & 3) + 4 (c >> 3); its mask bit sits in word ot >> 1 at (ot & 1) * 8 + (i >> 1) + 16 (i & 1)
         const int c = lane & 31, hf = (c >> 2) & 1, i = (c & 3) + 4 * (c >> 3);
-        moff = hf * 32 * 16 + (wo >> 1) * 4;
+        moff = mask_word_off(0, hf, wo >> 1);             // + the sample row's stride below
         mbit = (wo & 1) * 8 + (i >> 1) + 16 * (i & 1);
     }
     static_assert((S::kDzHead & 1) == 0, "dz_head block parity");
@@ -565,7 +565,7 @@ __device__ __forceinline__ void wgrad_last_recompute(const WgradArgs& a, const S
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int smp = (KNERF_WGRAD_ABLATE_LDS & 1) ? 0 : (r & 3) + 8 * (r >> 2) + 4 * hh;             // sample row of accumulator register r
-            mw[r] = *reinterpret_cast<const unsigned*>(x_reg + 1024 + smp * 16 + ((KNERF_WGRAD_ABLATE_LDS & 1) ? 0 : moff));
+            mw[r] = *reinterpret_cast<const unsigned*>(x_reg + 1024 + smp * (mask_word_off(1, 0, 0) - mask_word_off(0, 0, 0)) + ((KNERF_WGRAD_ABLATE_LDS & 1) ? 0 : moff));
         }
         dzf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z, hfrag, zero_acc(), 0, 0, 0);
     };

@@ -298,7 +298,7 @@ def head_compose(params, cfg: NerfConfig):
     ks, bs, kf, bf, kr, br, kc, bc = params[2 * n:2 * n + 8]
     Tr = kf.shape[0]
     P = kr @ kc                                        # [U + dir_dim, 3]
-    H = np.zeros((Tr + cfg.dir_dim, 4), ks.dtype)
+    H = np.zeros((Tr + kr.shape[0] - U, 4), ks.dtype)    # rows of the rgb_features kernel behind `features`: the direction input's width (mlp.py:23-24, 44-46)
     H[:Tr, :3] = kf @ P[:U]
     H[Tr:, :3] = P[U:]
     H[:Tr, 3] = ks[:, 0]

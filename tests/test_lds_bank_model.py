@@ -51,10 +51,13 @@ ROW = (2 * (LANES & 31) + (LANES >> 5)) * 16          # enc_off / zoff: saved_of
 LINEAR = LANES * 16
 
 
-def mask_addr(r, wo):     # dz7_mfma: word of (sample row of accumulator register r, feature half of this lane's column)
+def mask_addr(r, wo, layout=1):     # dz7_mfma: word of (sample row of accumulator register r, feature half of this lane's column)
+    """layout 1 (round 5, csrc/layout.h mask_lane_off): the two feature halves of a sample adjacent, 32 B per sample;
+    layout 0 (rounds 1-4): lane * 16, i.e. the halves 512 B apart"""
     c, hh = LANES & 31, LANES >> 5
     hf = (c >> 2) & 1
-    return 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 16 + hf * 32 * 16 + (wo >> 1) * 4
+    smp = (r & 3) + 8 * (r >> 2) + 4 * hh
+    return 1024 + ((2 * smp + hf) * 16 if layout else (hf * 32 + smp) * 16) + (wo >> 1) * 4
 
 
 def test_transposed_reads_are_conflict_free_in_every_job():
@@ -71,15 +74,16 @@ def test_row_wise_b128_reads_of_sample_major_blocks_are_two_way():
         assert cycles("ds_read_b128", ROW ^ ((ks & 1) << 7)) == (8, 4)     # enc blocks (layer_1), dz_head block (layer_7)
 
 
-def test_mask_word_reads_are_two_way():
+def test_mask_word_reads_were_two_way_and_are_conflict_free_with_the_interleaved_mask_block():
     for r in range(16):
         for wo in range(8):
-            assert cycles("ds_read_b32", mask_addr(r, wo)) == (4, 2)
+            assert cycles("ds_read_b32", mask_addr(r, wo, layout=0)) == (4, 2)          # rounds 1-4: 512 B apart = the same bank of 32
+            assert cycles("ds_read_b32", mask_addr(r, wo, layout=1)) == (2, 0)          # round 5: 16 B apart
 
 
-def test_modelled_conflict_share_of_a_launch_matches_the_counter():
+def _modelled_share(layout):
     """LDS-array cycles per 32-sample tile, summed over the eight waves of a workgroup, job by job (each tile goes through all nine
-    jobs of the default shape): the conflict share is what SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE measures (7.7 %)."""
+    jobs of the default shape): the conflict share is what SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE measures."""
     tr = cycles("ds_read_b64_tr_b16", tr_plain(0))[0]                       # 2
     frag = 2 * tr                                                          # tr_frag = two transposed reads
 
@@ -90,12 +94,17 @@ def test_modelled_conflict_share_of_a_launch_matches_the_counter():
     conflicts = dict.fromkeys(total, 0)
     row_t, row_x = cycles("ds_read_b128", ROW)
     lin_t, _ = cycles("ds_read_b128", LINEAR)
-    m_t, m_x = cycles("ds_read_b32", mask_addr(0, 0))
+    m_t, m_x = cycles("ds_read_b32", mask_addr(0, 0, layout))
     # layer_1: 2 k-steps x 1 dz fragment, 16 h0 fragments (b128, linear), 4 enc rows (b128), 2 ds_write_b128 (8 LDS-array cycles each)
     total["layer_1"] = 8 * (2 * frag + 16 * lin_t + 4 * row_t + 2 * 8); conflicts["layer_1"] = 8 * 4 * row_x
     # layer_7: 2 k-steps x 8 h6 fragments, 1 dz_head row (b128), 16 mask words (b32)
     total["layer_7"] = 8 * (2 * 8 * frag + row_t + 16 * m_t); conflicts["layer_7"] = 8 * (row_x + 16 * m_x)
-    share = sum(conflicts.values()) / sum(total.values())
-    assert 0.06 < share < 0.09, share                                      # the counter: 0.077
-    mask_part = 8 * 16 * m_x / sum(conflicts.values())
-    assert 0.55 < mask_part < 0.70                                         # ~60 % of the conflict cycles are the mask words
+    return sum(conflicts.values()) / sum(total.values()), 8 * 16 * m_x / sum(conflicts.values())
+
+
+def test_modelled_conflict_share_of_a_launch_matches_the_counter():
+    share, mask_part = _modelled_share(layout=0)
+    assert 0.06 < share < 0.09, share                                      # the round-4 counter: 0.077
+    assert 0.55 < mask_part < 0.70                                         # ~60 % of the conflict cycles were the mask words
+    share, mask_part = _modelled_share(layout=1)
+    assert 0.02 < share < 0.04 and mask_part == 0.0, share                 # what is left: the row-wise b128 reads of enc / dz_head
