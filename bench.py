@@ -306,7 +306,8 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
         write_synthetic_dataset(os.path.join(root, "data"), wh)
     if world > 1:
         torch.distributed.barrier()
-    train, val, test = DatasetLoader(os.path.join(root, "data"), white_background=True).load_dataset(batch, wh, wh, 2.0, 6.0, 64)
+    # the GLOBAL batch, as train.py:84-93 passes it: every rank yields its slice of `batch` images
+    train, val, test = DatasetLoader(os.path.join(root, "data"), white_background=True).load_dataset(batch * world, wh, wh, 2.0, 6.0, 64)
     nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: own initial weights per rank; compile() mirrors rank 0's
     try:
         nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)

@@ -296,13 +296,14 @@ inline void build_bwd(PackTables& pt) {
 // =====================================================================================================
 constexpr int saved_off(int b, int h, int s) { return (2 * (s ^ ((b & 1) << 2)) + h) * 16; }
 // relu-mask blocks (one per trunk layer and tile; 16 B = 128 mask bits per forward lane): lane (feature half hf = lane >> 5, sample
-// s = lane & 31) keeps its 16 bytes at mask_lane_off.  Round 5: the two halves of a sample ADJACENT (32 B per sample, as in the
-// saved activation blocks).  The layer-7 weight-gradient job reads one mask word per (sample row, hf) with ds_read_b32 -- two
-// addresses per 32-lane group; with the rounds-1-4 layout (lane * 16) they lay 512 B apart = the same bank of 32 (2-way, 60 % of the
-// kernel's LDS bank conflicts: tests/test_lds_bank_model.py, profiles/r05_wgrad_lds_conflicts.json), now 16 B apart.  The forward's
-// store and the dgrad's load stay whole 1 KiB blocks per wave.  KNERF_MASK_LAYOUT=0 rebuilds the old layout for the A/B.
+// s = lane & 31) keeps its 16 bytes at mask_lane_off = lane * 16.  The layer-7 weight-gradient job reads one mask word per (sample
+// row, hf) with ds_read_b32 -- two addresses per 32-lane group, 512 B apart = the same bank of 32: 2-way, 61.5 % of the kernel's LDS
+// bank-conflict cycles (tests/test_lds_bank_model.py, profiles/r05_wgrad_lds_conflicts.json).  KNERF_MASK_LAYOUT=1 puts a sample's two
+// halves ADJACENT (32 B per sample, as in the saved activation blocks; forward store and dgrad load stay whole 1 KiB blocks per wave):
+// those reads become conflict-free (share 7.7 % -> 3.1 % by PMC) -- and the fine launch came out 0.4-1.0 % SLOWER in every pairing of
+// two A/B calls (profiles/r05_mask_layout_ab.json): measured, not adopted, kept as a build knob.
 #ifndef KNERF_MASK_LAYOUT
-#define KNERF_MASK_LAYOUT 1
+#define KNERF_MASK_LAYOUT 0
 #endif
 constexpr int mask_lane_off(int lane) { return KNERF_MASK_LAYOUT ? ((lane & 31) * 2 + (lane >> 5)) * 16 : lane * 16; }
 // byte offset inside a mask block of word w of (sample s, feature half hf)

@@ -7,11 +7,13 @@ reference's zipped/shuffled/batched tf.data pipeline: shuffle with a buffer of `
 Images are decoded on the host (ImageLoader); rays are generated on the GPU (RaysGenerator).
 
 Data parallel (one process per GPU, reference train.py:75-93): the reference builds ONE dataset with the GLOBAL batch
-`batch_size x replicas` and Keras hands replica r images [r*b, (r+1)*b) of every global batch.  Here every rank builds the
-same dataset with the per-replica `batch_size`; all ranks draw the same shuffled order (one shared seed, buffer = global
-batch), cut it into global batches of `batch_size x world` (remainder dropped) and keep their own slice, so the replicas
-see disjoint images and the SUM all-reduce of NeRF.train_step adds gradients of different data.  The ray jitter stream is
-keyed by the rank as well.
+(`load_dataset(batch_size=args.batch_size * strategy.num_replicas_in_sync)`, train.py:84-93) and Keras hands replica r images
+[r*b, (r+1)*b) of every global batch (b = args.batch_size, what NeRF.compile and NeRFTrainMonitor are given).  Same here, so that
+an import-swapped train.py needs no change: `batch_size` IS THE GLOBAL BATCH; inside a torch.distributed job of W ranks every
+rank builds the same dataset, all ranks draw the same shuffled order (one shared seed, shuffle buffer = the global batch as in
+loader.py:97-113), cut it into global batches (remainder dropped) and yield their own slice of batch_size / W images (W must divide
+it), so the replicas see disjoint images and the SUM all-reduce of NeRF.train_step adds gradients of different data.  The ray
+jitter stream is keyed by the rank as well.  (Rounds 1-4 took the per-replica batch here; train.py passes the global one.)
 
 Feeding the GPU (the reference prefetches with tf.data, loader.py:104-106): the decoded images and the camera matrices of a
 dataset are kept RESIDENT ON THE DEVICE (100 views of 800 x 800 x 4 floats are 1 GB of 288), filled as the first pass touches
@@ -95,8 +97,15 @@ class RayImageDataset:
             return self._rank, self._world
         return _dist_rank_world()
 
+    def _local_batch(self, world):
+        """images per step of ONE replica: the global batch split along dim 0 (train.py:84-93)"""
+        if self.batch_size % world:
+            raise ValueError(f"the global batch of {self.batch_size} images is not divisible by {world} replicas "
+                             f"(train.py:84: global_batch_size = batch_size x num_replicas_in_sync)")
+        return self.batch_size // world
+
     def __len__(self):
-        n = len(self.image_paths) // (self.batch_size * self._placement()[1])
+        n = len(self.image_paths) // self.batch_size          # global batches; every replica takes part in each
         return n if self._limit is None else min(n, self._limit)
 
     def take(self, n):
@@ -144,8 +153,8 @@ class RayImageDataset:
         if self._rg is None:
             self._rg = self._rg_factory(rank)
         # the same order on every rank (the rngs are seeded alike and advance alike), each rank keeps its slice
-        order = shuffled_order(len(self.image_paths), self.batch_size * world, self._rng)
-        batches = replica_batches(order, self.batch_size, rank, world, self._limit)
+        order = shuffled_order(len(self.image_paths), self.batch_size, self._rng)
+        batches = replica_batches(order, self._local_batch(world), rank, world, self._limit)
 
         def gen_resident(res):
             dev, have, cams = res
@@ -207,6 +216,8 @@ class DatasetLoader:
         return paths, [fr["transform_matrix"] for fr in json_config["frames"]]
 
     def load_dataset(self, batch_size: int, image_width: int, image_height: int, near: float, far: float, n_sample: int) -> List[RayImageDataset]:
+        """loader.py:55-113.  batch_size: the GLOBAL batch (train.py:84-93 passes batch_size x replicas; train_single.py:60-67 the
+        only batch there is); a rank of a data-parallel job yields its 1/world slice of every batch"""
         image_loader = ImageLoader(image_width, image_height, self.white_background)
         out = []
         for k, subset in enumerate(["train", "val", "test"]):

@@ -251,6 +251,35 @@ def test_loader_monitor_fit_end_to_end(tmp_path):
     assert NeRFTrainMonitor(te, log_dir, batch_size=1, update_freq=2).last_epoch == 3        # resume: last CSV epoch + 1
 
 
+def test_train_script_shaped_like_the_reference_uses_every_rank(tmp_path):
+    """The reference's multi-GPU script gets all GPUs from plain `python train.py` (train.py:75: `tf.distribute.MirroredStrategy()`).
+    tests/train_like_reference.py has that script's shape on this implementation -- strategy, GLOBAL batch into the loader
+    (train.py:84-93), monitor, model under `strategy.scope()`, `fit`, `save_model` -- and is started here as plain `python script`:
+    `parallel.MirroredStrategy(devices=2)` makes the process the launcher of two ranks (sharing this GPU over gloo) that re-run it.
+    Rank 0 alone writes the CSV, the PNGs and the checkpoints; both ranks end with bit-identical weights although they started
+    from different ones and saw different images; 6 training views with a global batch of 2 are 3 steps per epoch of 1 image each."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    from tests.synthetic_scene import write
+    root = write(str(tmp_path / "scene"), n=(6, 2, 2), wh=20)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_like_reference.py"), "--data_dir", root,
+                        "--log_dir", str(tmp_path / "logs"), "--model_dirs", str(tmp_path / "model"), "--devices", "2", "--num_epochs", "2"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, KNERF_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("Number of devices: 2") == 2                        # printed by both ranks, not by the launcher
+    a, b = (json.load(open(tmp_path / "logs" / f"rank{k}.json")) for k in (0, 1))
+    assert a["world"] == b["world"] == 2 and a["weight_checksum"] == b["weight_checksum"] != 0
+    assert a["steps_per_epoch"] == 3 and a["images_per_step"] == b["images_per_step"] == 1
+    assert a["history"] == b["history"] and len(a["history"]["fine_loss"]) == 2 and "val_fine_psnr" in a["history"]      # replica means
+    rows = list(csv.DictReader(open(tmp_path / "logs" / "scene" / "log.csv")))
+    assert [x["epoch"] for x in rows] == ["0", "1"]
+    assert sorted(os.listdir(tmp_path / "model" / "scene")) == ["coarse.h5", "fine.h5", "model_config.json"]
+    assert "test_0_1.png" in os.listdir(tmp_path / "logs" / "scene")
+
+
 def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     """train.py:75-157 semantics with two processes on this GPU (gloo; tests/dp_gpu_worker.py): both ranks start from rank
     0's weights, SUM their accumulated gradients and end with identical weights that equal a single-process step on the

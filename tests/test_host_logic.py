@@ -212,10 +212,13 @@ def test_data_parallel_batches_are_disjoint_slices_of_the_global_batches():
     assert len(seen) == len(set(seen))                                   # no image is used twice in an epoch
     # tf.data shuffle(buffer) semantics: element k of the output comes from the first k + buffer inputs
     assert all(v < k + b * world for k, v in enumerate(orders[0]))
-    # the dataset object applies exactly that plan (no GPU needed until a batch is materialised)
-    ds = [RayImageDataset([f"img{i}" for i in range(n)], [np.eye(4)] * n, None, None, b, seed=5, rank=r, world=world) for r in range(world)]
-    assert [len(d) for d in ds] == [3, 3, 3]
+    # the dataset object applies exactly that plan (no GPU needed until a batch is materialised).  Its batch_size is the GLOBAL batch,
+    # as the reference's train.py passes it (train.py:84-93: load_dataset(batch_size=args.batch_size * num_replicas_in_sync))
+    ds = [RayImageDataset([f"img{i}" for i in range(n)], [np.eye(4)] * n, None, None, b * world, seed=5, rank=r, world=world) for r in range(world)]
+    assert [len(d) for d in ds] == [3, 3, 3] and [d._local_batch(world) for d in ds] == [b, b, b]
     assert len(RayImageDataset(["x"] * n, [np.eye(4)] * n, None, None, b, seed=5)) == 11     # outside a process group: world 1
+    with pytest.raises(ValueError, match="not divisible"):
+        RayImageDataset(["x"] * n, [np.eye(4)] * n, None, None, 4, seed=5, rank=0, world=3)._local_batch(3)
 
 
 def test_reference_import_names_resolve_to_this_implementation():

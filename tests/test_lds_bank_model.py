@@ -9,7 +9,9 @@ kernel "bank-conflict-free"; that holds for its transposed reads (every plain jo
   layer_1 job   4 x ds_read_b128 of the enc blocks row-wise (lane = sample, 32 B per sample: layout.h saved_off): 2-way
 
 The model below reproduces the split (and the total to within a point of the counter); the per-variant counters of the ablation
-builds (-DKNERF_WGRAD_ABLATE_LDS=1|2|3) are in profiles/r05_wgrad_lds_conflicts.json."""
+builds (-DKNERF_WGRAD_ABLATE_LDS=1|2|3) are in profiles/r05_wgrad_lds_conflicts.json.  A mask block with a sample's two halves adjacent
+(-DKNERF_MASK_LAYOUT=1) makes the mask reads conflict-free (7.7 % -> 3.1 % by PMC, profiles/r05_wgrad_lds_conflicts_mask_layout.json) and
+was 0.4-1.0 % slower per fine launch in every pairing (profiles/r05_mask_layout_ab.json): the product keeps lane * 16."""
 import numpy as np
 
 # lane groups (one LDS cycle each when conflict-free) and bank modulus per instruction: MI355X_MICROARCH.md, LDS table
@@ -51,9 +53,9 @@ ROW = (2 * (LANES & 31) + (LANES >> 5)) * 16          # enc_off / zoff: saved_of
 LINEAR = LANES * 16
 
 
-def mask_addr(r, wo, layout=1):     # dz7_mfma: word of (sample row of accumulator register r, feature half of this lane's column)
-    """layout 1 (round 5, csrc/layout.h mask_lane_off): the two feature halves of a sample adjacent, 32 B per sample;
-    layout 0 (rounds 1-4): lane * 16, i.e. the halves 512 B apart"""
+def mask_addr(r, wo, layout=0):     # dz7_mfma: word of (sample row of accumulator register r, feature half of this lane's column)
+    """layout 0 (the product, csrc/layout.h mask_lane_off): lane * 16, i.e. a sample's two feature halves 512 B apart;
+    layout 1 (-DKNERF_MASK_LAYOUT=1, the round-5 experiment): the halves adjacent, 32 B per sample"""
     c, hh = LANES & 31, LANES >> 5
     hf = (c >> 2) & 1
     smp = (r & 3) + 8 * (r >> 2) + 4 * hh
@@ -74,11 +76,11 @@ def test_row_wise_b128_reads_of_sample_major_blocks_are_two_way():
         assert cycles("ds_read_b128", ROW ^ ((ks & 1) << 7)) == (8, 4)     # enc blocks (layer_1), dz_head block (layer_7)
 
 
-def test_mask_word_reads_were_two_way_and_are_conflict_free_with_the_interleaved_mask_block():
+def test_mask_word_reads_are_two_way_and_would_be_conflict_free_with_an_interleaved_mask_block():
     for r in range(16):
         for wo in range(8):
-            assert cycles("ds_read_b32", mask_addr(r, wo, layout=0)) == (4, 2)          # rounds 1-4: 512 B apart = the same bank of 32
-            assert cycles("ds_read_b32", mask_addr(r, wo, layout=1)) == (2, 0)          # round 5: 16 B apart
+            assert cycles("ds_read_b32", mask_addr(r, wo, layout=0)) == (4, 2)          # 512 B apart = the same bank of 32
+            assert cycles("ds_read_b32", mask_addr(r, wo, layout=1)) == (2, 0)          # KNERF_MASK_LAYOUT=1: 16 B apart
 
 
 def _modelled_share(layout):
@@ -104,7 +106,7 @@ def _modelled_share(layout):
 
 def test_modelled_conflict_share_of_a_launch_matches_the_counter():
     share, mask_part = _modelled_share(layout=0)
-    assert 0.06 < share < 0.09, share                                      # the round-4 counter: 0.077
-    assert 0.55 < mask_part < 0.70                                         # ~60 % of the conflict cycles were the mask words
+    assert 0.06 < share < 0.09, share                                      # the counter: 0.0766
+    assert 0.55 < mask_part < 0.70                                         # PMC on the ablation builds: 61.5 % of the conflict cycles are the mask words
     share, mask_part = _modelled_share(layout=1)
-    assert 0.02 < share < 0.04 and mask_part == 0.0, share                 # what is left: the row-wise b128 reads of enc / dz_head
+    assert 0.02 < share < 0.04 and mask_part == 0.0, share                 # PMC of the KNERF_MASK_LAYOUT=1 build: 0.0309 (the row-wise b128 reads of enc / dz_head)
