@@ -278,8 +278,17 @@ class NeRFMLP:
             ctx.set_weights(0, self.get_flat_weights())
         xyz = ctx.f32(xyz); dire = ctx.f32(dire)
         lead = tuple(xyz.shape[:-1])
-        raw = ctx.mlp_call(net, xyz.reshape(-1, self.xyz_dim), dire.reshape(-1, self.dir_dim))
+        x2, d2 = xyz.reshape(-1, self.xyz_dim), dire.reshape(-1, self.dir_dim)
+        n = x2.shape[0]
+        if n <= self.CALL_ROWS:
+            raw = ctx.mlp_call(net, x2, d2)
+        else:           # bound the library's per-call workspace (every layer's activations of the rows in flight: ~5 KB per row at width 256)
+            raw = torch.empty((n, 4), device=ctx.device, dtype=torch.float32)
+            for r0 in range(0, n, self.CALL_ROWS):
+                raw[r0:r0 + self.CALL_ROWS] = ctx.mlp_call(net, x2[r0:r0 + self.CALL_ROWS], d2[r0:r0 + self.CALL_ROWS])
         return raw[:, :3].reshape(lead + (3,)), raw[:, 3:4].reshape(lead + (1,))
+
+    CALL_ROWS = 1 << 20      # rows per knerf_mlp_call: the reference test's 640,000 go in one call, a [2, 400, 400, 192, .] tensor in 59
 
     def get_config(self):
         return {"name": self.name, "n_layers": self.n_layers, "dense_units": self.dense_units, "skip_layer": self.skip_layer}

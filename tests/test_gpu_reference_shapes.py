@@ -90,6 +90,15 @@ def test_nerf_mlp_takes_any_two_widths_from_its_first_call():
         np.testing.assert_allclose(rgb.cpu().numpy(), er, atol=2e-3); np.testing.assert_allclose(sigma.cpu().numpy(), es, atol=4e-3)
         with pytest.raises(ValueError):
             m((x[..., :-1], dd))
+    # more rows than one library call takes (NeRFMLP.CALL_ROWS): the same values as row-by-row slices
+    m3 = NeRFMLP(4, 64, 2, seed=2)
+    big = torch.rand((3 * 2 ** 19 + 5, 9), device="cuda"); bigd = torch.rand((3 * 2 ** 19 + 5, 4), device="cuda")
+    m3.CALL_ROWS = 1 << 19
+    r_all, s_all = m3((big, bigd))
+    assert r_all.shape == (3 * 2 ** 19 + 5, 3)
+    for lo in (0, 2 ** 19 - 3, 3 * 2 ** 19 - 2):
+        r_part, s_part = m3((big[lo:lo + 7], bigd[lo:lo + 7]))
+        assert torch.equal(r_part, r_all[lo:lo + 7]) and torch.equal(s_part, s_all[lo:lo + 7])
     # an MLP whose widths came from its weights (set_weights / load_weights on an unbuilt model) serves calls of those widths
     m2 = NeRFMLP(4, 64, 2)
     m2.set_weights(NeRFMLP(4, 64, 2, xyz_dim=50, dir_dim=7, seed=5).get_weights())
