@@ -81,6 +81,15 @@ def _adam_hyper(optimizer) -> Dict[str, float]:
     return h
 
 
+class History(dict):
+    """what tf.keras.Model.fit returns: `.history` = {log key: [one value per epoch]}, `.epoch` = the epochs run, `.params`.  Also a
+    dict itself (rounds 1-4 returned the plain dictionary), so both `h["fine_loss"]` and `h.history["fine_loss"]` read the curves."""
+
+    def __init__(self, history, epoch, params):
+        super().__init__(history)
+        self.history, self.epoch, self.params = self, list(epoch), dict(params)
+
+
 class NeRF:
     def __init__(self, n_coarse: int = 64, n_fine: int = 128, pos_emb_xyz: int = 10, pos_emb_dir: int = 4, n_layers: int = 8,
                  dense_units: int = 256, skip_layer=4, model_path: str = None, oob: str = "zero", seed: int = 42, **kwargs):
@@ -356,7 +365,8 @@ class NeRF:
     # ------------------------------------------------------------------ fit: the part of tf.keras.Model.fit the reference uses
     def fit(self, dataset, epochs=1, validation_data=None, callbacks=None, initial_epoch=0, verbose=1):
         """train_single.py:137-143.  dataset yields (images, (o, d, t)) batches and is re-iterable; callbacks get the Keras
-        hooks NeRFTrainMonitor uses (set_model, on_train_batch_end, on_epoch_end).  Returns {key: [per-epoch values]}."""
+        hooks NeRFTrainMonitor uses (set_model, on_train_batch_end, on_epoch_end).  Returns a Keras-style History ({key: [per-epoch
+        values]} as `.history`, and as the object itself)."""
         callbacks = list(callbacks or [])
         for cb in callbacks:
             if hasattr(cb, "set_model"):
@@ -364,6 +374,7 @@ class NeRF:
             else:
                 cb.model = self
         history: Dict[str, list] = {}
+        epochs_run = []
         self.stop_training = False
         for cb in callbacks:
             getattr(cb, "on_train_begin", lambda logs=None: None)({})
@@ -392,6 +403,7 @@ class NeRF:
             logs = parallel.reduce_logs(logs, self.device)    # replica means (one tiny all-reduce)
             for k, v in logs.items():
                 history.setdefault(k, []).append(v)
+            epochs_run.append(epoch)
             if verbose:
                 logging.info("Epoch %d/%d - %s", epoch + 1, epochs, " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
             for cb in callbacks:
@@ -400,5 +412,9 @@ class NeRF:
                 break
         for cb in callbacks:
             getattr(cb, "on_train_end", lambda logs=None: None)({})
-        self.history = history
-        return history
+        try:
+            steps = len(dataset)
+        except TypeError:
+            steps = None
+        self.history = History(history, epochs_run, {"epochs": epochs, "steps": steps, "verbose": verbose})
+        return self.history

@@ -89,6 +89,9 @@ def test_fit_runs_callbacks_and_reduces_loss():
     assert len(h["fine_loss"]) == 5 and h["fine_loss"][-1] < h["fine_loss"][0]
     assert ("e", 1, sorted(list(h))) in seen and ("b", 1) in seen and "val_fine_psnr" in h
     assert nerf._ctx.step == 10
+    # what tf.keras.Model.fit returns: a History whose .history holds the curves (also readable as the object itself), .epoch, .params
+    assert h.history["fine_loss"] == h["fine_loss"] and h.epoch == [1, 2, 3, 4, 5] and h.params["epochs"] == 6 and h.params["steps"] == 2
+    assert nerf.history is h
 
 
 def test_save_load_model_roundtrip(tmp_path, model):

@@ -116,3 +116,65 @@ def test_general_shape_kernels_are_bit_reproducible_at_bench_size(shape):
     assert torch.equal(ga, gb) and da == db                                          # two contexts (two sets of allocations): the same bits
     g0 = grads[0][0][0]
     assert float((ga - g0).abs().max()) <= 2e-5 * float(g0.abs().max())              # deterministic = the atomic sums in another order
+
+
+def test_every_launch_follows_the_callers_stream():
+    """The C ABI takes a hipStream_t per call (include/knerf.h) and torch hands it its CURRENT stream: a whole train chunk + Adam step
+    enqueued on a non-blocking side stream -- behind a long-running kernel on that stream that produces its inputs -- must see those
+    inputs (every kernel, memset and copy of the library on the caller's stream; a launch on the null stream would run early, on stale
+    data) and, in deterministic mode, give the bits of the same work on the default stream."""
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    from keras_nerf_amd.runtime import KnerfContext
+    res = {}
+    for where in ("default", "side"):
+        ctx = KnerfContext(white_background=True, options=dict(deterministic=1))
+        for net in (0, 1):
+            m = NeRFMLP(seed=net); m.build(); ctx.set_weights(net, m.get_flat_weights() * 1.5)
+        o, d, t, tgt, u = _bench_chunk(ctx)
+        o, d, t, tgt, u = (x[:1024].contiguous() for x in (o, d, t, tgt, u))
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream() if where == "side" else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            # inputs produced ON THIS STREAM by slow kernels right in front of the library's launches
+            big = torch.randn((4096, 4096), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+            for _ in range(6):
+                big = (big @ big).clamp_(-1, 1)
+            zero = (big.sum() * 0.0)
+            o2, d2, t2, tgt2, u2 = o + zero, d + zero, t + zero, tgt + zero, u + zero       # depend on the slow chain
+            loss = torch.zeros(2, device="cuda")
+            ctx.train_chunk(o2, d2, t2, tgt2, u2, loss=loss)
+            g = ctx.grads_view().clone()
+            ctx.apply_adam(check=False)
+            out = ctx.render_chunk(o2, d2, t2, u2)
+            img = out["f_image"].clone()
+        stream.synchronize()
+        ctx.poll_nonfinite(wait=True)
+        res[where] = (g, loss.clone(), img, torch.as_tensor(ctx.get_weights(0)))
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        ctx.close()
+    for a, b in zip(res["default"], res["side"]):
+        assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_creating_and_destroying_contexts_returns_their_memory():
+    """knerf_destroy frees everything knerf_create and the grow-only workspaces allocated (the GPU suite itself creates a few hundred
+    contexts in one process): device memory in use after 60 create / train / render / destroy cycles equals what it was after the first"""
+    from keras_nerf_amd.runtime import KnerfContext
+    used = []
+    for k in range(60):
+        shape = dict(n_layers=4, dense_units=128, skip_layer=2) if k % 3 == 1 else dict(pos_emb_xyz=6, pos_emb_dir=2) if k % 3 == 2 else {}
+        ctx = KnerfContext(white_background=True, options=dict(deterministic=k % 2), **shape)
+        o, d, t = ctx.generate_rays(torch.eye(4, device="cuda")[None], 20.0, 16, 16, 2.0, 6.0, 64, None, seed=k)
+        o, d, t = o.reshape(-1, 3), d.reshape(-1, 3), t.reshape(-1, 64)
+        ctx.train_chunk(o, d, t, torch.rand((256, 3), device="cuda"), None, seed=k)
+        ctx.apply_adam()
+        ctx.render_chunk(o, d, t, None, seed=k)
+        if k % 3 == 0:
+            ctx.mlp_call(0, torch.rand((100, 63), device="cuda"), torch.rand((100, 27), device="cuda"))
+        torch.cuda.synchronize()
+        ctx.close()
+        del o, d, t
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        used.append(total - free)
+    assert max(used[3:]) - min(used[3:]) <= 64 << 20, [u >> 20 for u in used]      # torch's own caching allocator settles within the first cycles
