@@ -185,25 +185,46 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def _wait_ranks(procs, poll, kill, what: str) -> int:
+def _wait_ranks(procs, poll, kill, what: str, hard_kill=None, grace_s: float = 10.0) -> int:
     """wait for rank processes; the first one that fails ends the job: the others (still blocked in a collective with the dead
-    rank) are terminated BY HANDLE.  Returns the job's exit code."""
+    rank) are terminated BY HANDLE (SIGTERM, then `hard_kill` = SIGKILL for those that have not left after `grace_s` seconds -- a
+    rank waiting inside a driver call does not see SIGTERM).  The same when the launcher itself is interrupted (Ctrl-C, SIGTERM
+    turned into an exception): no orphan ranks.  Returns the job's exit code."""
     import time
     code = 0
     live = list(procs)
-    while live:
-        for p in list(live):
-            rc = poll(p)
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0 and code == 0:
-                code = rc if rc > 0 else RANK_FAILED
-                print(f"[knerf launch] a rank of {what} exited with code {rc}: stopping the other {len(live)}", file=sys.stderr, flush=True)
+    deadline = None
+    try:
+        while live:
+            for p in list(live):
+                rc = poll(p)
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else RANK_FAILED
+                    print(f"[knerf launch] a rank of {what} exited with code {rc}: stopping the other {len(live)}", file=sys.stderr, flush=True)
+                    for q in live:
+                        kill(q)
+                    deadline = time.time() + grace_s
+            if live and deadline is not None and time.time() > deadline and hard_kill is not None:
                 for q in live:
-                    kill(q)
-        if live:
+                    hard_kill(q)
+                deadline = time.time() + grace_s
+            if live:
+                time.sleep(0.05)
+    except BaseException:                          # the launcher is going down (KeyboardInterrupt, SystemExit from a signal handler): take the ranks along
+        for q in live:
+            if poll(q) is None:
+                kill(q)
+        t_end = time.time() + grace_s
+        while time.time() < t_end and any(poll(q) is None for q in live):
             time.sleep(0.05)
+        if hard_kill is not None:
+            for q in live:
+                if poll(q) is None:
+                    hard_kill(q)
+        raise
     return code
 
 
@@ -269,14 +290,15 @@ def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_PORT=str(port),
                        KNERF_DIST_BACKEND=backend)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0]), *sys.argv[1:]], env=env))
-        code = _wait_ranks(procs, lambda p: p.poll(), lambda p: p.terminate(), os.path.basename(sys.argv[0]))
+        code = _wait_ranks(procs, lambda p: p.poll(), lambda p: p.terminate(), os.path.basename(sys.argv[0]), hard_kill=lambda p: p.kill())
         raise SystemExit(code)                     # the parent was only the launcher: the script's body ran in the ranks
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_rank_entry, args=(fn, tuple(args), r, n, port, backend), daemon=False) for r in range(n)]
     for p in procs:
         p.start()
-    code = _wait_ranks(procs, lambda p: p.exitcode if not p.is_alive() else None, lambda p: p.terminate(), getattr(fn, "__name__", "fn"))
+    code = _wait_ranks(procs, lambda p: p.exitcode if not p.is_alive() else None, lambda p: p.terminate(), getattr(fn, "__name__", "fn"),
+                       hard_kill=lambda p: p.kill())
     if code:
         raise SystemExit(code)
     return 0

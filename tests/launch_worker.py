@@ -41,6 +41,19 @@ def hang_unless_zero(out_dir):
     dist.all_reduce(torch.ones(1))           # never completes: rank 1 is gone
 
 
+def ignore_sigterm_and_hang(out_dir):
+    """a rank that cannot be talked out of its collective: SIGTERM ignored (as inside a driver call) -- the launcher must escalate"""
+    import signal
+    import torch
+    import torch.distributed as dist
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    if dist.get_rank() == 1:
+        raise RuntimeError("rank 1 fails on purpose")
+    with open(os.path.join(out_dir, f"pid{dist.get_rank()}"), "w") as f:
+        f.write(str(os.getpid()))
+    dist.all_reduce(torch.ones(1))
+
+
 if __name__ == "__main__":
     from keras_nerf_amd import parallel
     out, n = sys.argv[1], int(sys.argv[2])

@@ -193,3 +193,21 @@ def test_launch_stops_everything_when_one_rank_fails(tmp_path):
     assert time.time() - t0 < 120
     assert "[knerf rank 1/4] FAILED in hang_unless_zero()" in r.stderr and "rank 1 fails on purpose" in r.stderr
     assert "stopping the other" in r.stderr
+
+
+def test_launch_escalates_to_sigkill_for_ranks_that_ignore_sigterm(tmp_path, monkeypatch):
+    """a rank blocked where SIGTERM does not reach it (inside a driver call) must not keep the job alive: after a grace period the
+    launcher kills it by handle; afterwards none of the ranks' pids exists any more"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import ignore_sigterm_and_hang; "
+            "import functools; parallel._wait_ranks = functools.partial(parallel._wait_ranks, grace_s=2.0); "
+            "parallel.launch(ignore_sigterm_and_hang, 3, args=(%r,), backend='gloo')") % (root, str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_launch_env())
+    assert r.returncode == 3 and time.time() - t0 < 120, (r.returncode, r.stderr[-2000:])
+    for k in (0, 2):
+        pid = int(open(tmp_path / f"pid{k}").read())
+        assert not os.path.exists(f"/proc/{pid}"), f"rank {k} (pid {pid}) survived its launcher"
