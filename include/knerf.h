@@ -135,7 +135,8 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *   "skip_dead_tiles"   0/1  (default 1) the backward kernels skip every 32-sample tile whose dL/d(rgb, sigma) is EXACTLY zero for all samples
  *                            (empty space with a closed ReLU gate on sigma, rays whose pixel error is exactly 0): such samples add
  *                            exactly nothing to any of the 48 gradient tensors (utils.py:36-45, mlp.py:40), so the result is the
- *                            same; applies to the default MLP shape when n_coarse and n_coarse + n_fine are multiples of 32.
+ *                            same; applies when n_coarse and n_coarse + n_fine are multiples of 32 (every MLP shape: the fused kernels
+ *                            and, since round 5, the general-shape kernels walk the list of live tiles).
  *   "grad_diagnostics"  0/1  (default 0) knerf_train_batch counts the non-zero entries of the last chunk's gradient of each net
  *                            (knerf_grad_diagnostics; the reference does this when run_eagerly, nerf.py:430-451); one launch of the
  *                            coarse weight-gradient kernel per chunk while it is on.

@@ -94,8 +94,11 @@ hipError_t forward_encoded(const Plan& p, const Workspace& ws, const NetDev& net
 // sums into net.gaux (expand_head turns them into gradients)
 // partial: null (fp32 atomics), or wgrad_partial_floats(p) floats of scratch for the deterministic mode -- per-unit slabs and an
 // ordered second pass per weight-gradient launch, bit-identical between runs
+// live / n_live: null, or the device list of live 32-row tiles (composite.hip) and its device-side length: dead-tile skipping --
+// the dgrad GEMMs and the weight-gradient products walk the list; stats (optional): [0] += live, [1] += all tiles of the pass
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
-                    float* grad_flat, hipStream_t s, float* partial = nullptr);
+                    float* grad_flat, hipStream_t s, float* partial = nullptr, const int* live = nullptr, const int* n_live = nullptr,
+                    long long* stats = nullptr);
 size_t wgrad_partial_floats(const Plan& p);
 size_t padded_rows(long long n);
 

@@ -43,42 +43,45 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---- positional encoding (utils.py:176-210): rows [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] --------
+// One thread per (sample row, group of 8 columns): a row's groups are adjacent threads, so the 16-byte stores of a wavefront cover
+// whole rows back to back (round 5; rounds 2-4 had one thread per sample writing its 192 bytes two at a time: 7 % of a train chunk).
+// Values as before: sinf / cosf of 2^l x with the scaling exact.
+__device__ __forceinline__ float enc_column(int col, int dim, const float (&v)[3]) {
+    if (col < 3) return v[col];
+    if (col >= dim) return 0.f;
+    const int k = col - 3, l = k / 6, r = k % 6;
+    const float arg = __int_as_float((127 + l) << 23) * v[r % 3];          // 2^l * x (l <= 32)
+    return r < 3 ? sinf(arg) : cosf(arg);
+}
 __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ t,
                                                     long long n, long long mp, int S, int lx, int ld, u16* __restrict__ ex, int kxp,
                                                     u16* __restrict__ ed, int kdp) {
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= mp) return;
-    u16* rx = ex + (size_t)m * kxp;
-    u16* rd = ed + (size_t)m * kdp;
-    if (m >= n) {
-        for (int c = 0; c < kxp; ++c) rx[c] = 0;
-        for (int c = 0; c < kdp; ++c) rd[c] = 0;
-        return;
-    }
-    const long long ray = m / S;
-    const float tv = t[m];
-    float p[3], dv[3];
+    const int gx = kxp / 8, gd = kdp / 8, gpr = gx + gd;                    // 16-byte groups per row: xyz buffer, dir buffer
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= mp * gpr) return;
+    const long long m = idx / gpr;
+    const int grp = (int)(idx % gpr);
+    const bool is_dir = grp >= gx;
+    u16* dst = is_dir ? ed + (size_t)m * kdp + (size_t)(grp - gx) * 8 : ex + (size_t)m * kxp + (size_t)grp * 8;
+    u16 out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < n) {
+        const long long ray = m / S;
+        float v[3];
+        if (is_dir) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        dv[c] = d[ray * 3 + c];
-        p[c] = __fadd_rn(o[ray * 3 + c], __fmul_rn(dv[c], tv));       // o + d*t, separate mul and add like the reference
+            for (int c = 0; c < 3; ++c) v[c] = d[ray * 3 + c];
+        } else {
+            const float tv = t[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = __fadd_rn(o[ray * 3 + c], __fmul_rn(d[ray * 3 + c], tv));   // o + d*t, separate mul and add like the reference
+        }
+        const int col0 = (is_dir ? grp - gx : grp) * 8, dim = 3 + 6 * (is_dir ? ld : lx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = to_bf16(enc_column(col0 + j, dim, v));
     }
-    int col = 0;
-    for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(p[c]);
-    float f = 1.f;
-    for (int l = 0; l < lx; ++l, f *= 2.f) {
-        for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(sinf(f * p[c]));
-        for (int c = 0; c < 3; ++c) rx[col++] = to_bf16(cosf(f * p[c]));
-    }
-    for (; col < kxp; ++col) rx[col] = 0;
-    col = 0;
-    for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(dv[c]);
-    f = 1.f;
-    for (int l = 0; l < ld; ++l, f *= 2.f) {
-        for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(sinf(f * dv[c]));
-        for (int c = 0; c < 3; ++c) rd[col++] = to_bf16(cosf(f * dv[c]));
-    }
-    for (; col < kdp; ++col) rd[col] = 0;
+    uint4 pk;
+    __builtin_memcpy(&pk, out, 16);
+    *reinterpret_cast<uint4*>(dst) = pk;
 }
 
 // already-encoded fp32 rows [n][dim] -> zero-padded bf16 rows [mp][ld]   (NeRFMLP.__call__ on encoded inputs, mlp.py:29-31)
@@ -110,6 +113,9 @@ struct GemmArgs {
     const u16* aux; int ldaux;           // optional relu mask source (the saved post-relu activation)
     u16* Cb; int ldc;                    // bf16 output (may be null)
     float* Cf; int ldcf;                 // fp32 output (may be null)
+    // dead-tile skipping (backward only): the 32-row tiles to process = list entries [0, *n_live) (composite.hip appends the tiles
+    // whose dL/d(rgb, sigma) is not all zero); rows of other tiles are neither read nor written.  null: every tile of M
+    const int* live; const int* n_live;
 };
 
 // epilogue shared by the two GEMM kernels: bias, relu, relu mask of the dgrad, bf16 / fp32 stores.
@@ -194,9 +200,9 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
     constexpr int PER_T = (NB * 8 + kGemmWaves * 64 - 1) / (kGemmWaves * 64);   // 16-byte granules per thread per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    long long m0 = ((long long)blockIdx.x * kGemmWaves + wave) * 32;
-    const bool live = m0 < g.M;                       // M is a multiple of 128, the workgroup covers 256 rows
-    if (!live) m0 = 0;                                // idle waves still help staging and hit the barriers
+    const long long my_tile = (long long)blockIdx.x * kGemmWaves + wave;
+    const bool live = g.live ? my_tile < (long long)*g.n_live : my_tile * 32 < g.M;     // M is a multiple of 128, the workgroup covers 256 rows
+    long long m0 = live ? (g.live ? (long long)g.live[my_tile] : my_tile) * 32 : 0;    // idle waves still help staging and hit the barriers
     const int n0 = blockIdx.y * NB;
     const u16* A = g.A + (size_t)(m0 + r) * g.lda + 8 * h;
     const int nchunks = (g.K + kGemmKC - 1) / kGemmKC;
@@ -282,12 +288,13 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
             cc * 8 < g.K ? *reinterpret_cast<const uint4*>(g.Bt + (size_t)(n0 + NT * (row & 31) + (row >> 5)) * g.ldb + cc * 8) : uint4{0, 0, 0, 0};   // gemm_epilogue's column assignment
     }
     __syncthreads();
-    const long long n_tiles = g.M / 32;
+    const long long n_tiles = g.live ? (long long)*g.n_live : g.M / 32;
     const char* B = gsm + r * pitch + h * 16;
     const long long stride = (long long)gridDim.x * kGemmWaves;
     long long tile = (long long)blockIdx.x * kGemmWaves + wave;
+    auto row_tile = [&](long long i) -> long long { return g.live ? (long long)g.live[i] : i; };      // entry i of the tiles to process
     bf16x8 a_cur[4], a_nxt[4];
-    auto fetch_a = [&](long long t, int k, bf16x8 (&a)[4]) {          // one 64-wide chunk of this wave's 32 rows
+    auto fetch_a = [&](long long t, int k, bf16x8 (&a)[4]) {          // one 64-wide chunk of this wave's 32 rows (t = a row tile)
         const u16* A = g.A + (size_t)(t * 32 + r) * g.lda + 8 * h + k;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -299,9 +306,11 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
         }
     };
     auto frag = [&](int k, int f) { return *reinterpret_cast<const bf16x8*>(B + (f % NT) * 32 * pitch + (k + (f / NT) * 16) * 2); };
-    if (tile < n_tiles) fetch_a(tile, 0, a_cur);
-    for (; tile < n_tiles; tile += stride) {
-        const long long m0 = tile * 32;
+    long long rt = tile < n_tiles ? row_tile(tile) : 0, rt_next = 0;
+    if (tile < n_tiles) fetch_a(rt, 0, a_cur);
+    for (; tile < n_tiles; tile += stride, rt = rt_next) {
+        const long long m0 = rt * 32;
+        if (tile + stride < n_tiles) rt_next = row_tile(tile + stride);
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = zero16();
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
         for (int k = 0; k < K64; k += kGemmKC) {
             const bool more = k + kGemmKC < K64;
             const bool next_tile = !more && tile + stride < n_tiles;
-            if (more) fetch_a(tile, k + kGemmKC, a_nxt);
-            else if (next_tile) fetch_a(tile + stride, 0, a_nxt);
+            if (more) fetch_a(rt, k + kGemmKC, a_nxt);
+            else if (next_tile) fetch_a(rt_next, 0, a_nxt);
             const int kn = more ? k + kGemmKC : k;          // where the ring's look-ahead reads at the end of this chunk
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -549,6 +558,7 @@ struct WgradArgs {
     // slab order into grad.  The step -> unit assignment is a function of the grid alone, so two launches give the same bits.
     // Block (bx, by), slab sl: partial + ((bx gy + by) n_sl + sl) tile_floats; a tile is [TK][TN] sums then [bias_halves][TN].
     float* partial;             // null: atomics
+    const int* live; const int* n_live;     // dead-tile skipping: the 32-sample steps to contract over = list entries [0, *n_live); null: all
 };
 
 // 32 samples x 32 features (row-major; raw = the two 16-byte row pieces each lane loaded) -> two operand fragments with
@@ -574,6 +584,28 @@ __device__ __forceinline__ void transpose_tile(const RawTile& t, const bf16x8& i
     if (colsum) *colsum += s;
 }
 
+// Which 32-sample steps an accumulating unit (unit `u` of `units`) contracts over, as (first, stride, count) over INDICES that
+// step_of() maps to sample tiles.  Atomic mode: units interleave (u, u + units, ...) over all steps or over the live list -- the best
+// balance.  Deterministic mode (g.partial): unit u owns the CONTIGUOUS tile range [u T / units, (u + 1) T / units) of the pass's T
+// tiles and walks it in ascending order -- all of it, or (dead-tile skipping) its live tiles, found by binary search in the
+// ascending list the compaction kernel made: the dead tiles would only have added exact zeros, so a launch with skipping forms the
+// same sums in the same order as one without (bit-identical gradients, tests/test_gpu_det_skip.py).
+struct UnitSched { long long first, stride, count; };
+__device__ __forceinline__ UnitSched unit_schedule(const WgradArgs& g, long long u, long long units) {
+    const long long n_live = g.live ? (long long)*g.n_live : g.steps;
+    if (!g.partial) return {u, units, n_live > u ? (n_live - u + units - 1) / units : 0};
+    const long long lo = u * g.steps / units, hi = (u + 1) * g.steps / units;
+    if (!g.live) return {lo, 1, hi - lo};
+    auto lower = [&](long long v) {                 // first list index whose tile is >= v
+        long long a = 0, b = n_live;
+        while (a < b) { const long long m = (a + b) >> 1; if ((long long)g.live[m] < v) a = m + 1; else b = m; }
+        return a;
+    };
+    const long long i0 = lower(lo), i1 = lower(hi);
+    return {i0, 1, i1 - i0};
+}
+__device__ __forceinline__ long long step_of(const WgradArgs& g, long long idx) { return g.live ? (long long)g.live[idx] : idx; }
+
 #ifndef KNERF_GEN_WG_DEPTH
 #define KNERF_GEN_WG_DEPTH 3
 #endif
@@ -598,13 +630,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) bsum[b] = 0.f;
     const bool do_bias = blockIdx.x == 0;
-    const long long stride = (long long)gridDim.z * 4;
-    long long s = (long long)blockIdx.z * 4 + wave;
+    const UnitSched us = unit_schedule(g, (long long)blockIdx.z * 4 + wave, (long long)gridDim.z * 4);
+    const long long stride = us.stride, n_steps = us.first + us.count * us.stride;      // indices first, first + stride, ... < n_steps
+    long long s = us.first;
     // kWgDepth m-steps are in flight: one step of this wave is 16 MFMAs (~0.5 us with its SIMD partner), a first-touch
     // HBM load takes several times that
     constexpr int D = kWgDepth;
     RawTile xr[D][KT], zr[D][NT];
-    auto fetch = [&](long long st, RawTile (&x)[KT], RawTile (&z)[NT]) {
+    auto fetch = [&](long long st_i, RawTile (&x)[KT], RawTile (&z)[NT]) {
+        const long long st = step_of(g, st_i);
         const u16* X = g.X + (size_t)st * 32 * g.ldx + k0;
         const u16* Z = g.Z + (size_t)st * 32 * g.ldz + n0;
 #pragma unroll
@@ -614,18 +648,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     };
 #pragma unroll
     for (int dd = 0; dd < D; ++dd)
-        if (s + dd * stride < g.steps) fetch(s + dd * stride, xr[dd], zr[dd]);
-    for (; s < g.steps; s += D * stride) {
+        if (s + dd * stride < n_steps) fetch(s + dd * stride, xr[dd], zr[dd]);
+    for (; s < n_steps; s += D * stride) {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
             const long long st = s + dd * stride;
-            if (st < g.steps) {                       // wave-uniform
+            if (st < n_steps) {                       // wave-uniform
                 bf16x8 xa[KT][2], zb[NT][2];
 #pragma unroll
                 for (int a = 0; a < KT; ++a) transpose_tile(xr[dd][a], ilo, ihi, xa[a], nullptr);
 #pragma unroll
                 for (int b = 0; b < NT; ++b) transpose_tile(zr[dd][b], ilo, ihi, zb[b], do_bias ? &bsum[b] : nullptr);
-                if (st + D * stride < g.steps) fetch(st + D * stride, xr[dd], zr[dd]);
+                if (st + D * stride < n_steps) fetch(st + D * stride, xr[dd], zr[dd]);
 #pragma unroll
                 for (int a = 0; a < KT; ++a)
 #pragma unroll
@@ -697,7 +731,10 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     };
     // staging: 2 granules of X and 2 of dZ per thread and step
     uint4 sx[2], sz[2];
-    auto fetch = [&](long long st) {
+    const UnitSched us = unit_schedule(g, (long long)blockIdx.z, (long long)gridDim.z);
+    const long long stride = us.stride, n_steps = us.first + us.count * us.stride;
+    auto fetch = [&](long long st_i) {
+        const long long st = step_of(g, st_i);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = tid + 512 * j, row = q >> 5, cc = q & 31;
@@ -726,13 +763,13 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     const bool do_bias = blockIdx.x == 0 && wa == 0;                     // wave-uniform
     const bool k_ok[2] = {k0 + 32 * (2 * wa) < K, k0 + 32 * (2 * wa + 1) < K};
     const bool n_ok[4] = {n0 + 32 * (4 * wb) < N, n0 + 32 * (4 * wb + 1) < N, n0 + 32 * (4 * wb + 2) < N, n0 + 32 * (4 * wb + 3) < N};
-    long long st = blockIdx.z;
-    if (st < g.steps) { fetch(st); put(0); }
+    long long st = us.first;
+    if (st < n_steps) { fetch(st); put(0); }
     __syncthreads();
     int buf = 0;
-    for (; st < g.steps; st += gridDim.z) {
-        const bool more = st + gridDim.z < g.steps;
-        if (more) fetch(st + gridDim.z);                                 // flies under this step's reads and MFMAs
+    for (; st < n_steps; st += stride) {
+        const bool more = st + stride < n_steps;
+        if (more) fetch(st + stride);                                    // flies under this step's reads and MFMAs
         const char* xs = csm + buf * kCoopBuf;
         const char* zs = xs + kCoopSlab;
         if (k_ok[0] && n_ok[0]) {                                        // a wave whose first tiles are out of range has nothing to do
@@ -1079,7 +1116,7 @@ hipError_t forward(const Plan& p, const Workspace& ws, const NetDev& net, const 
                    const float* t, long long n, int S, float* raw, hipStream_t s) {
     const long long mp = (long long)padded_rows(n);
     if ((size_t)mp > ws.mp || p.lx < 0 || p.ld < 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld,
+    hipLaunchKernelGGL(encode_kernel, dim3(blocks_for(mp * ((p.kxp + p.kdp) / 8))), dim3(256), 0, s, o, d, t, n, mp, S, p.lx, p.ld,
                        act_buf(p, ws, p.buf_encx), p.kxp, act_buf(p, ws, p.buf_encd), p.kdp);
     GENCHK(hipGetLastError());
     return run_layers(p, ws, net, w_flat, n, mp, raw, s);
@@ -1104,18 +1141,31 @@ size_t wgrad_partial_floats(const Plan& p) {
     return m;
 }
 
+namespace {
+// running totals of the dead-tile statistics (knerf_tile_stats): stats[0] += live tiles of this pass, stats[1] += all its tiles
+__global__ void tile_stats_kernel(const int* n_live, long long total, long long* stats) {
+    stats[0] += (long long)*n_live; stats[1] += total;
+}
+}  // namespace
+
 hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const float* raw, const float* draw, long long n,
-                    float* grad_flat, hipStream_t s, float* partial) {
+                    float* grad_flat, hipStream_t s, float* partial, const int* live, const int* n_live, long long* stats) {
     const long long mp = (long long)padded_rows(n);
     if ((size_t)mp > ws.mp) return hipErrorInvalidValue;
     const int nl = p.n_layers;
     u16* dzh = dz_buf(p, ws, p.dz_head);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks_for(mp)), dim3(256), 0, s, raw, draw, n, mp, dzh);
     GENCHK(hipGetLastError());
+    if (live && stats) {
+        hipLaunchKernelGGL(tile_stats_kernel, dim3(1), dim3(1), 0, s, n_live, (n + 31) / 32, stats);
+        GENCHK(hipGetLastError());
+    }
+    // dead-tile skipping: every GEMM and weight-gradient product below walks the list of live 32-row tiles instead of all of mp
     auto dgrad = [&](const u16* A, int lda, int K, const u16* Wd, int ldb, int N, const u16* aux, int ldaux, u16* C, int ldc) {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.Bt = Wd; g.ldb = ldb; g.M = mp; g.N = N; g.K = K;
         g.aux = aux; g.ldaux = ldaux; g.Cb = C; g.ldc = ldc;
+        g.live = live; g.n_live = n_live;
         return launch_gemm(g, s);
     };
     // d trunk = dZ_head . H^T (the same product W_f (W_r1 (W_c dz_rgb)) + w_s dz_sigma the tape forms), masked by the last
@@ -1139,6 +1189,7 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         w.steps = mp / 32; w.grad = grad_flat; w.w_off = L.w_off; w.b_off = L.b_off; w.n_real = L.n_real;
         w.n_seg = L.n_seg; w.seg[0] = L.seg[0]; w.seg[1] = L.seg[1];
         w.partial = partial;                    // one slab arena serves every launch: they follow each other on the stream
+        w.live = live; w.n_live = n_live;
         GENCHK(launch_wgrad(w, w.ldx, L.np, s));
     }
     {   // head sums M = [h ; (xyz) ; dir]^T dZ_head [head_K][4] and s = column sums, into the aux buffer (expand_head)
@@ -1148,6 +1199,7 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         w.steps = mp / 32; w.grad = net.gaux; w.w_off = 0; w.b_off = p.head_K * 4; w.n_real = 4;
         w.n_seg = 1; w.seg[0] = Seg{0, p.head_K, 0};
         w.partial = partial;
+        w.live = live; w.n_live = n_live;
         GENCHK(launch_wgrad(w, w.ldx, 32, s));
     }
     return hipSuccess;

@@ -146,6 +146,13 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
             ctx->draw_bytes = ctx->raw_bytes;
             free_dev(ctx->loss_partial);
             HIPCHK(hipMalloc(&ctx->loss_partial, ((size_t)R + 3) / 4 * sizeof(float)));
+            // dead-tile skipping: per-tile flags (deterministic mode) and the list of live tiles of the current pass
+            free_dev(ctx->tile_flags); free_dev(ctx->tile_list);
+            const size_t tiles = tiles_for((long long)ns);
+            HIPCHK(hipMalloc(&ctx->tile_flags, tiles * sizeof(int)));
+            HIPCHK(hipMemsetAsync(ctx->tile_flags, 0, tiles * sizeof(int), s));
+            HIPCHK(hipMalloc(&ctx->tile_list, tiles * sizeof(int)));
+            ctx->ws_tiles = tiles;
         }
         ctx->ws_rays = R; ctx->ws_train = train; ctx->ws_train_rays = train ? R : 0; ctx->ws_group = 1;
         return KNERF_OK;
@@ -222,9 +229,10 @@ int check_net(knerf_ctx* ctx, int net) {
     return KNERF_OK;
 }
 
-// dead-tile skipping applies to the fused path when 32-sample tiles do not straddle rays in either pass
+// dead-tile skipping applies when 32-sample tiles do not straddle rays in either pass (both MLP paths since round 5: the
+// general-shape kernels walk the same list of live tiles, generic.hip)
 bool skipping(const knerf_ctx* ctx) {
-    return ctx->skip_dead && !ctx->generic && ctx->cfg.n_coarse % kTile == 0 && (ctx->cfg.n_coarse + ctx->cfg.n_fine) % kTile == 0;
+    return ctx->skip_dead && ctx->cfg.n_coarse % kTile == 0 && (ctx->cfg.n_coarse + ctx->cfg.n_fine) % kTile == 0;
 }
 
 // A fresh (zero) counter for one list of live tiles.  The ring is zeroed by one memset when a call takes its first counter, and again
@@ -339,7 +347,8 @@ int run_pass(knerf_ctx* ctx, hipStream_t s, int net, const float* o, const float
             HIPCHK(hipMalloc(&ctx->partial, gen::wgrad_partial_floats(ctx->gplan) * sizeof(float)));
         }
         HIPCHK(gen::backward(ctx->gplan, ctx->gws, ctx->gnet[net], ctx->raw, ctx->draw, fa.n_samples, ctx->net[net].g, s,
-                             ctx->deterministic ? ctx->partial : nullptr));
+                             ctx->deterministic ? ctx->partial : nullptr, skip ? ctx->tile_list : nullptr, skip ? live_count : nullptr,
+                             skip ? ctx->tile_stats + 4 * fa.net : nullptr));
     } else if (train) {
         BwdArgs ba{};
         ba.stream = ctx->net[net].bwd_stream; ba.raw = ctx->raw; ba.draw = ctx->draw; ba.mask = fa.mask; ba.dz = ctx->dz + saved_tile_off(tile0, ctx->si.dz_blocks);

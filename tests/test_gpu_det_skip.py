@@ -179,3 +179,54 @@ def test_skipping_changes_nothing_when_nothing_is_dead_and_handles_all_dead():
         if skip:
             assert ctx.tile_stats() == (0, 512 * 256 // 32)
         ctx.close()
+
+
+@pytest.mark.parametrize("shape", [dict(force_generic=True),                                              # the default shape on the general-shape kernels
+                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2)])     # a shape only they cover
+def test_dead_tile_skipping_on_the_general_shape_path_is_exact(shape):
+    """Round 5: the general-shape kernels (csrc/generic.hip) walk the same list of live 32-sample tiles in every dgrad GEMM and every
+    weight-gradient product.  A problem with a substantial dead fraction (sigma's bias lowered so that the ReLU on sigma is closed in
+    most of space; a quarter of the rays get their own rendered pixel as target, i.e. exactly zero pixel error): in deterministic
+    mode the gradients with and without skipping are BIT-identical (same sums, same order: flags + ordered compaction), in the
+    default mode equal up to the atomics' order; the statistics count what the fused path counts."""
+    from keras_nerf_amd.model.nerf.mlp import NeRFMLP
+    from keras_nerf_amd.runtime import KnerfContext
+    kw = {k: v for k, v in shape.items() if k != "force_generic"}
+    nl, units, skip_l = kw.get("n_layers", 8), kw.get("dense_units", 256), kw.get("skip_layer", 4)
+    lx, ld = kw.get("pos_emb_xyz", 10), kw.get("pos_emb_dir", 4)
+    ws = []
+    for net in (0, 1):
+        m = NeRFMLP(nl, units, skip_l, seed=40 + net, xyz_dim=3 + 6 * lx, dir_dim=3 + 6 * ld)
+        w = m.get_flat_weights() * 1.5
+        names = [n for n, _, _ in m._shapes]
+        off = sum(fi * fo + fo for _, fi, fo in m._shapes[:names.index("sigma")]) + m._shapes[names.index("sigma")][1]
+        w[off] -= 0.6                                                     # sigma/bias: the gate on sigma closes in the low-density regions
+        ws.append(w)
+    P = make_problem(n_images=2, wh=16, weight_scale=1.5, bias_std=0.05)
+    o, d, t, img, u = _batch(P, 512)
+    res = {}
+    for det in (1, 0):
+        for skip in (0, 1):
+            ctx = KnerfContext(white_background=True, force_generic=shape.get("force_generic"), options=dict(deterministic=det, skip_dead_tiles=skip), **kw)
+            assert ctx.get_option("general_shape_path") == 1.0 and ctx.get_option("skip_dead_tiles_active") == float(skip)
+            ctx.set_weights(0, ws[0]); ctx.set_weights(1, ws[1])
+            if "tgt" not in res:          # every fourth ray: the coarse net's own pixel as target (the coarse pass of those rays is dead)
+                ren = ctx.render_batch(o, d, t, u, ray_chunks=128)
+                tgt = img.clone(); tgt[::4] = ren["c_image"][::4]
+                res["tgt"] = tgt
+            g, loss = _step(ctx, (o, d, t, res["tgt"], u), 128)
+            res[det, skip] = (g, loss, ctx.tile_stats())
+            ctx.close()
+    live, total = res[1, 1][2]
+    assert total == 512 * 256 // 32 and res[1, 0][2] == (0, 0) and res[0, 1][2] == (live, total)
+    dead = 1.0 - live / total
+    log_stats(f"generic_dead_tile_frac_{'default_shape' if shape.get('force_generic') else 'l5_u192'}", dead=dead, live=live, total=total)
+    assert 0.05 < dead < 0.95, dead
+    g_ns, l_ns, _ = res[1, 0]; g_s, l_s, _ = res[1, 1]
+    assert float(g_ns.abs().max()) > 0 and bool(torch.isfinite(g_ns).all())
+    assert torch.equal(g_ns.view(torch.int32), g_s.view(torch.int32)), float((g_ns - g_s).abs().max())
+    assert torch.equal(l_ns.view(torch.int32), l_s.view(torch.int32))
+    n = g_ns.numel() // 2
+    for sl in (slice(0, n), slice(n, 2 * n)):
+        for g in (res[0, 0][0], res[0, 1][0]):
+            assert float((g[sl] - g_ns[sl]).abs().max()) <= 2e-5 * float(g_ns[sl].abs().max())
