@@ -59,6 +59,11 @@ def parse_shapes(specs) -> list:
             if u not in (64, 128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0 or not 1 <= lx <= 16 or not 1 <= ld <= 8:
                 raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 64, 128 or 256, 3 <= n_layers <= 16, "
                                  f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0), 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 8")
+            if u == 256 and lx == 16 and ld >= 5:
+                # measured (round 5 compile sweep): eight encoding k-steps AND four direction k-steps at width 256 need 12 bytes of
+                # scratch per lane in the training forward -- the spill check below would refuse the object after a minute of hipcc
+                raise ValueError(f"shape {item!r}: pos_emb_xyz = 16 together with pos_emb_dir >= 5 does not fit the register file at "
+                                 f"dense_units 256 (pos_emb_xyz <= 15 or pos_emb_dir <= 4 does; so does the same at width 128 / 64)")
             if (lx, ld) == (10, 4):
                 v = v[:3]
             if v not in out:

@@ -42,6 +42,12 @@ def test_parse_shapes_accepts_covered_triples_and_names_the_others():
     with pytest.raises(ValueError):
         B.parse_shapes([f"{nl},{sk},{u}" for nl in range(4, 17) for sk in (nl, nl + 1) for u in (128, 256)])       # 52 valid triples: over the build-time budget (MAX_EXTRA_SHAPES)
     assert len(B.parse_shapes([f"{nl},{nl},128" for nl in range(4, 17)])) == 13      # round 4: no cap at 12 any more (csrc/layout.h KNERF_PICK needs no per-index macro)
+    # round 5 compile sweep of the corners: the one combination that does not fit the register file is named up front (the spill check
+    # would refuse it after a minute of hipcc): eight encoding k-steps (pos_emb_xyz 16) with four direction k-steps (pos_emb_dir >= 5) at width 256
+    for bad in ("8,4,256,16,5", "16,4,256,16,8"):
+        with pytest.raises(ValueError, match="register file"):
+            B.parse_shapes([bad])
+    assert B.parse_shapes(["8,4,256,16,4", "8,4,256,15,8", "8,4,128,16,8", "7,4,64,16,8"]) == [(8, 4, 256, 16, 4), (8, 4, 256, 15, 8), (8, 4, 128, 16, 8), (7, 4, 64, 16, 8)]
 
 
 def test_layout_header_with_extra_shapes(tmp_path):
