@@ -445,7 +445,8 @@ def allreduce_selftest(nerf, world, backend, n=20):
         wall.append((time.perf_counter() - t0) * 1e6); ev.append((e0, e1))
     torch.cuda.synchronize()
     us = sorted(a.elapsed_time(b_) * 1e3 for a, b_ in ev)
-    assert float(g.abs().max()) == 0.0          # the accumulators were zero and still are
+    was_zero = float(g.abs().max()) == 0.0      # the accumulators were zero (Adam resets them) and sums of zeros still are;
+    nerf._ctx.zero_grads()                      # whatever happened, the timed steps start from zero accumulators
     med = statistics.median(us if backend == "nccl" else wall)
     try:
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -453,7 +454,8 @@ def allreduce_selftest(nerf, world, backend, n=20):
         ver = None
     return {"allreduce_us_standalone": {"min": us[0], "median": statistics.median(us), "max": us[-1], "n": n, "clock": "hip events on the collective's stream",
                                         "host_wall_us_median": statistics.median(wall)},
-            "allreduce_busbw_GBps": byts * 2 * (world - 1) / world / (med * 1e-6) / 1e9, "rccl_version": ver}
+            "allreduce_busbw_GBps": byts * 2 * (world - 1) / world / (med * 1e-6) / 1e9, "rccl_version": ver,
+            "allreduce_selftest_operand_stayed_zero": was_zero}
 
 
 def main():

@@ -488,7 +488,7 @@ def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     assert len(per) == 3 and min(per) == pytest.approx(line["ms_per_step_rank_min"], rel=1e-3) and max(per) == pytest.approx(line["ms_per_step_rank_max"], rel=1e-3)
     st = line["allreduce_us_standalone"]
     assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] and st["host_wall_us_median"] > 0 and line["allreduce_busbw_GBps"] > 0
-    assert "rccl_version" in line
+    assert "rccl_version" in line and line["allreduce_selftest_operand_stayed_zero"] is True
     assert 0 < line["metrics_ms_per_step"] < 5 and "hip events" in line["metrics_clock"]
     for k in range(3):
         assert f"[bench rank {k}/3] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
