@@ -211,3 +211,23 @@ def test_launch_escalates_to_sigkill_for_ranks_that_ignore_sigterm(tmp_path, mon
     for k in (0, 2):
         pid = int(open(tmp_path / f"pid{k}").read())
         assert not os.path.exists(f"/proc/{pid}"), f"rank {k} (pid {pid}) survived its launcher"
+
+
+def test_init_rank_refusals_name_the_problem(monkeypatch):
+    """the checks in front of init_process_group: a rank without a GPU under the RCCL backend, and a world of one (nothing to join)"""
+    import torch
+    from keras_nerf_amd import parallel
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert parallel.init_rank("gloo")[:2] == (0, 1)                   # world size 1: no process group is created
+    assert not dist.is_initialized()
+    if torch.cuda.device_count() == 0:
+        monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
+        with pytest.raises(SystemExit, match="no GPU visible"):
+            parallel.init_rank("nccl")
+    # the launch environment is set without overriding what the caller chose
+    monkeypatch.setenv("MASTER_ADDR", "10.0.0.7"); monkeypatch.delenv("NCCL_DEBUG", raising=False); monkeypatch.delenv("NCCL_DEBUG_FILE", raising=False)
+    parallel.dist_env(8)
+    assert os.environ["MASTER_ADDR"] == "10.0.0.7" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert os.environ["NCCL_DEBUG"] == "WARN" and "%p" in os.environ["NCCL_DEBUG_FILE"]
+    assert parallel.rccl_log_tail() == ""                             # no file yet: nothing to show
