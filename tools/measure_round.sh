@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
 #   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half stores
+#                                                          round 5: sparsity lds masklayout gensk fuzzgen rehearsal
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -48,6 +49,23 @@ import json
 for l in open('$OUT/shapes_kbench.jsonl'):
     if l.startswith('{'):
         r=json.loads(l); print(r.get('tag'), r.get('train_chunk_ms'), r.get('Mrs_per_s'))" ;;
+    sparsity) # exact zeros of the saved tensors per element / row / block, random and trained states (trains 2 x 600 steps)
+           timeout -k 10 500 python tools/saved_block_sparsity.py --state-dir $OUT/sparsity --out $OUT/saved_block_sparsity.json > $OUT/sparsity.log 2>&1 || fault sparsity
+           python -c "import json; r=json.loads(open('$OUT/saved_block_sparsity.json').read()); print('sparsity', r['verdict'])" ;;
+    lds)   # LDS bank conflicts of the weight-gradient kernel per ablation build; needs build.py --variant=ldsmask|ldsrows|ldsboth -DKNERF_WGRAD_ABLATE_LDS=1|2|3
+           bash tools/lds_pmc.sh $OUT/lds_pmc > $OUT/wgrad_lds_conflicts.json 2> $OUT/lds_pmc.err || fault lds; rm -rf $OUT/lds_pmc/*/
+           grep -E "conflict_share|^ \"" $OUT/wgrad_lds_conflicts.json ;;
+    masklayout) # the conflict-free mask block (build.py --variant=maskadj -DKNERF_MASK_LAYOUT=1) against the product, ABBA order
+           for v in default maskadj maskadj default default maskadj maskadj default; do
+             lib=keras_nerf_amd/libknerf_hip.so; [ $v != default ] && lib=keras_nerf_amd/libknerf_hip_$v.so
+             timeout -k 10 120 python tools/kbench.py --iters 20 --skip-dead-tiles 1 --lib $lib --tag $v >> $OUT/mask_layout_ab.jsonl 2>> $OUT/mask_layout_ab.err || fault "masklayout $v"
+           done; grep -c kernels $OUT/mask_layout_ab.jsonl ;;
+    gensk) # the general-shape kernels with and without exact dead-tile skipping on the compact scene
+           for sk in "--skip-dead" ""; do KNERF_FORCE_GENERIC=1 timeout -k 10 400 python tools/convergence128.py --backend hip --scene compact $sk --lr 5e-4 --scale 1.6 --steps 600 --eval-every 200 --out $OUT/conv_generic_skip_${sk:+on}.json > $OUT/gensk_${sk:+on}.log 2>&1 || fault gensk; tail -n 1 $OUT/gensk_${sk:+on}.log | cut -c1-200; done ;;
+    fuzzgen) timeout -k 10 800 python tools/fuzz_generic.py --cases 60 > $OUT/fuzz_generic.jsonl 2> $OUT/fuzz_generic.err; rc=$?; tail -n 1 $OUT/fuzz_generic.jsonl; [ $rc -eq 0 ] || fault fuzzgen ;;
+    rehearsal) # an N = 3 line over gloo on one GPU (control flow and the line's diagnostics fields, not a measurement)
+           KNERF_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 3 --config cfg4 --steps 10 --warmup 2 --no-cpu-baseline 2> $OUT/rehearsal.err | grep "^{" > $OUT/bench_cfg4_3ranks_gloo.json || fault rehearsal
+           python -c "import json; l=json.load(open('$OUT/bench_cfg4_3ranks_gloo.json')); print('rehearsal', l['n_gpus'], l['replica_drift'], l['allreduce_us_standalone']['median'])" ;;
   esac
 done
 exit 0
