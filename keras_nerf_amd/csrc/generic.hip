@@ -704,50 +704,66 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 }
 
 // Cooperative wgrad for layers of at least 128 x 128: a workgroup of 8 waves owns a 256 (inputs) x 256 (outputs) block of dW
-// and walks 32-sample steps; per step the X and dZ slabs [32][256] are staged ONCE in LDS (double-buffered, row pitch
-// 576 B = 16 banks mod 64: the transposed reads below are conflict-free) and every wave builds its operand fragments with
-// ds_read_b64_tr_b16 -- lane 4q+p of a 16-lane group supplies the address of sample row q / feature quad p and receives
-// feature `lane` of the four samples, i.e. exactly the MFMA operand layout with samples as k (tests/test_gpu_probe.py pins
-// the instruction).  Against the per-wave kernel above: operands cross L2 once per 256 x 256 block instead of 4 x, and
-// no MFMA is spent on transposing.  Wave (wa, wb) = (wave >> 1, wave & 1): input tiles 2wa, 2wa+1, output tiles 4wb..4wb+3.
-constexpr int kCoopPitch = 576, kCoopSlab = 32 * kCoopPitch, kCoopBuf = 2 * kCoopSlab;
+// and walks 32-sample steps; per step the X and dZ slabs [32][256] are staged ONCE in LDS and every wave builds its operand
+// fragments with ds_read_b64_tr_b16 -- lane 4q+p of a 16-lane group supplies the address of sample row q / feature quad p and
+// receives feature `lane` of the four samples, i.e. exactly the MFMA operand layout with samples as k (tests/test_gpu_probe.py
+// pins the instruction).  Against the per-wave kernel above: operands cross L2 once per 256 x 256 block instead of 4 x, and no
+// MFMA is spent on transposing.  Wave (wa, wb) = (wave >> 1, wave & 1): input tiles 2wa, 2wa+1, output tiles 4wb..4wb+3.
+// Round 5: the slabs arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, so THREE steps = 96 KiB per workgroup are in
+// flight instead of one -- rounds 2-4 ran this launch at 2.6 TB/s, latency-bound), four 32 KiB buffers.  A DMA instruction lands
+// 1 KiB contiguously (two unpadded 512-byte rows), so the rows cannot be padded apart: instead the 16-byte chunks of row r sit at
+// chunk ^ 4 (r & 3) -- the four rows a transposed read touches then cover the 64 banks exactly once (tests/test_lds_bank_model.py).
+// Each lane fetches the chunk that belongs at its LDS position.  Waits are counted by hand (4 DMA instructions per wave and step).
+constexpr int kCoopSlab = 32 * 512, kCoopBuf = 2 * kCoopSlab, kCoopDepth = 4;
+__device__ __forceinline__ void coop_glds16(const void* gsrc, unsigned lds_dst) {       // as wgrad_body.h glds16: invisible to hipcc's wait counting
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int N) {
     extern __shared__ __attribute__((aligned(16))) char csm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;
     const int k0 = blockIdx.x * 256, n0 = blockIdx.y * 256;
     const int r = lane & 31, h = lane >> 5;
-    // transposed-read lane offsets: group gq = lane >> 4 -> feature half (gq & 1), k half (gq >> 1); i = lane & 15 -> q = i >> 2, p = i & 3
-    const int gq = lane >> 4, il = lane & 15;
-    const int tr_off = ((8 * (gq >> 1) + (il >> 2)) * kCoopPitch) + (16 * (gq & 1) + 4 * (il & 3)) * 2;
+    // transposed-read lane offsets: group gq = lane >> 4 -> feature half (gq & 1), k half (gq >> 1); i = lane & 15 -> q = i >> 2, p = i & 3.
+    // Row 8 (gq >> 1) + q (+ 16 kk, + 4 for the second read: the low two bits stay q), chunk 4 tile + 2 (gq & 1) + (p >> 1), swizzled by q
+    const int gq = lane >> 4, il = lane & 15, tq = il >> 2;
+    const int tr_off = (8 * (gq >> 1) + tq) * 512 + (2 * (gq & 1) + ((il & 3) >> 1)) * 16 + (il & 1) * 8;
     typedef __attribute__((address_space(3))) s16x4g* lds_s16x4g_ptr;
     auto frag = [&](const char* slab, int tile, int kk) {
-        const char* p = slab + tr_off + (16 * kk) * kCoopPitch + tile * 64;
+        const char* p = slab + tr_off + (16 * kk) * 512 + ((tile ^ tq) << 6);
         const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4g_ptr)p);
-        const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4g_ptr)(p + 4 * kCoopPitch));
+        const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4g_ptr)(p + 4 * 512));
         typedef __attribute__((ext_vector_type(8))) short s16x8g;
         const s16x8g v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    // staging: 2 granules of X and 2 of dZ per thread and step
-    uint4 sx[2], sz[2];
     const UnitSched us = unit_schedule(g, (long long)blockIdx.z, (long long)gridDim.z);
-    const long long stride = us.stride, n_steps = us.first + us.count * us.stride;
-    auto fetch = [&](long long st_i) {
-        const long long st = step_of(g, st_i);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + 512 * j, row = q >> 5, cc = q & 31;
-            sx[j] = k0 + cc * 8 < K ? *reinterpret_cast<const uint4*>(g.X + (size_t)(st * 32 + row) * g.ldx + k0 + cc * 8) : uint4{0, 0, 0, 0};
-            sz[j] = n0 + cc * 8 < N ? *reinterpret_cast<const uint4*>(g.Z + (size_t)(st * 32 + row) * g.ldz + n0 + cc * 8) : uint4{0, 0, 0, 0};
-        }
+    const long long cnt = us.count;
+    // entry j of this unit's schedule -> sample tile; the list look-up is a SCALAR load in asm (a compiler-visible vector load
+    // inside the loop would make hipcc drain vmcnt(0), i.e. the whole DMA pipeline, every step)
+    auto tile_of = [&](long long j) -> long long {
+        const long long idx = us.first + (j < cnt ? j : cnt - 1) * us.stride;      // past the end: a harmless re-read keeps the vmcnt arithmetic uniform
+        if (!g.live) return idx;
+        const unsigned long long p = (unsigned long long)(g.live + idx);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+        int t;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(((unsigned long long)hi << 32) | lo) : "memory");
+        return (long long)t;
     };
-    auto put = [&](int buf) {
+    // this lane's part of a step: instruction m = wave + 8 i (i = 0, 1) of each slab covers rows 2m, 2m+1; the lane sits at LDS slot
+    // (row, lane & 31) and fetches chunk (lane & 31) ^ 4 (row & 3) of its row (clamped into the layer: tiles past K / N are never used)
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)csm;
+    const int kmax = (K - k0 + 7) / 8 - 1 < 31 ? (K - k0 + 7) / 8 - 1 : 31, nmax = (N - n0 + 7) / 8 - 1 < 31 ? (N - n0 + 7) / 8 - 1 : 31;
+    auto issue = [&](long long st, int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + 512 * j, row = q >> 5, cc = q & 31;
-            *reinterpret_cast<uint4*>(csm + buf * kCoopBuf + row * kCoopPitch + cc * 16) = sx[j];
-            *reinterpret_cast<uint4*>(csm + buf * kCoopBuf + kCoopSlab + row * kCoopPitch + cc * 16) = sz[j];
+        for (int i = 0; i < 2; ++i) {
+            const int m = wave + 8 * i, row = 2 * m + h;
+            const int c = r ^ ((row & 3) << 2);
+            const unsigned dst = smem_base + buf * kCoopBuf + m * 1024;
+            coop_glds16(g.X + (size_t)(st * 32 + row) * g.ldx + k0 + (c < kmax ? c : kmax) * 8, __builtin_amdgcn_readfirstlane(dst));
+            coop_glds16(g.Z + (size_t)(st * 32 + row) * g.ldz + n0 + (c < nmax ? c : nmax) * 8, __builtin_amdgcn_readfirstlane(dst + kCoopSlab));
         }
     };
     f32x16 acc[2][4], acc_b[4];
@@ -763,13 +779,16 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     const bool do_bias = blockIdx.x == 0 && wa == 0;                     // wave-uniform
     const bool k_ok[2] = {k0 + 32 * (2 * wa) < K, k0 + 32 * (2 * wa + 1) < K};
     const bool n_ok[4] = {n0 + 32 * (4 * wb) < N, n0 + 32 * (4 * wb + 1) < N, n0 + 32 * (4 * wb + 2) < N, n0 + 32 * (4 * wb + 3) < N};
-    long long st = us.first;
-    if (st < n_steps) { fetch(st); put(0); }
-    __syncthreads();
-    int buf = 0;
-    for (; st < n_steps; st += stride) {
-        const bool more = st + stride < n_steps;
-        if (more) fetch(st + stride);                                    // flies under this step's reads and MFMAs
+    if (cnt > 0) {
+#pragma unroll
+        for (int d = 0; d < kCoopDepth - 1; ++d) issue(tile_of(d), d);          // steps 0 .. D-2
+    }
+    for (long long i = 0; i < cnt; ++i) {
+        const int buf = (int)(i % kCoopDepth);
+        const long long t_next = tile_of(i + kCoopDepth - 1);                     // (its scalar load waits here, before the counted wait)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kCoopDepth - 2)) : "memory");    // step i landed (mine) ...
+        __builtin_amdgcn_s_barrier();                                             // ... everyone's; the buffer of step i-1 is free (its reads fed MFMAs already)
+        issue(t_next, (int)((i + kCoopDepth - 1) % kCoopDepth));
         const char* xs = csm + buf * kCoopBuf;
         const char* zs = xs + kCoopSlab;
         if (k_ok[0] && n_ok[0]) {                                        // a wave whose first tiles are out of range has nothing to do
@@ -791,10 +810,8 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
                 }
             }
         }
-        if (more) put(buf ^ 1);                                          // the other buffer was last read before the previous barrier
-        __syncthreads();
-        buf ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the trailing (unused) copies
     // flush: lane (col = r, hh = h), register i -> input column 32 tile + (i&3) + 8(i>>2) + 4hh
     if (g.partial) {            // deterministic mode: the workgroup's 256 x 256 block (its eight waves own disjoint parts) to its own slab
         constexpr int TN = 256, TF = 256 * 256 + TN;
@@ -876,7 +893,7 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
 #ifndef KNERF_GEN_NO_COOP
     if (kt >= 4 && nt >= 4) {
         static AttrOnce once;
-        const size_t lds = 2 * (size_t)kCoopBuf;
+        const size_t lds = (size_t)kCoopDepth * kCoopBuf;
         hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         if (ae != hipSuccess) return ae;
         const int gx = (K + 255) / 256, gy = (N + 255) / 256;

@@ -110,3 +110,24 @@ def test_modelled_conflict_share_of_a_launch_matches_the_counter():
     assert 0.55 < mask_part < 0.70                                         # PMC on the ablation builds: 61.5 % of the conflict cycles are the mask words
     share, mask_part = _modelled_share(layout=1)
     assert 0.02 < share < 0.04 and mask_part == 0.0, share                 # PMC of the KNERF_MASK_LAYOUT=1 build: 0.0309 (the row-wise b128 reads of enc / dz_head)
+
+
+def test_general_shape_cooperative_wgrad_swizzle_is_conflict_free():
+    """csrc/generic.hip wgrad_coop_kernel (round 5): unpadded 512-byte rows staged by LDS-DMA, the 16-byte chunks of row r at
+    chunk ^ 4 (r & 3); the transposed reads of every (tile, k-step, first / second read) touch four rows whose windows then cover the
+    64 banks exactly once -- and WITHOUT the swizzle the same reads would be 4-way (every row starts at bank 0)"""
+    gq, il = LANES >> 4, LANES & 15
+    tq = il >> 2
+    base = (8 * (gq >> 1) + tq) * 512 + (2 * (gq & 1) + ((il & 3) >> 1)) * 16 + (il & 1) * 8
+    for tile in range(8):
+        for kk in range(2):
+            for second in (0, 1):
+                swz = base + (16 * kk + 4 * second) * 512 + ((tile ^ tq) << 6)
+                assert cycles("ds_read_b64_tr_b16", swz) == (2, 0)
+                plain = base + (16 * kk + 4 * second) * 512 + (tile << 6)
+                assert cycles("ds_read_b64_tr_b16", plain) == (8, 6)
+    # the staging side: slot (lane & 31) of row 2m + (lane >> 5) receives chunk slot ^ 4 (row & 3): a permutation of the row's 32 chunks
+    for m in range(16):
+        for hh in range(2):
+            row = 2 * m + hh
+            assert sorted(int(x) ^ ((row & 3) << 2) for x in range(32)) == list(range(32))
