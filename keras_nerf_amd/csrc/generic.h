@@ -65,6 +65,7 @@ struct Workspace {             // per context, grow-only; Mp = padded sample cou
     size_t mp = 0;
     unsigned short* act = nullptr;     // all activation buffers, buffer b at act + off_b * mp
     unsigned short* dz = nullptr;
+    unsigned char* mask = nullptr;     // training workspaces only: the relu bits of every trunk layer (relu_bits_bytes; generic.hip GemmArgs)
     float* zs = nullptr;               // (unused since the head collapse; kept so that callers' allocation code stays valid)
     float* zc = nullptr;               // [Mp][32] head pre-activations: columns r, g, b, sigma
 };
@@ -101,6 +102,8 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
                     long long* stats = nullptr);
 size_t wgrad_partial_floats(const Plan& p);
 size_t padded_rows(long long n);
+size_t relu_bits_bytes_per_row(const Plan& p);          // one bit per padded trunk feature
+size_t relu_bits_bytes(const Plan& p, size_t mp);       // Workspace::mask for mp padded rows
 
 }  // namespace gen
 }  // namespace knerf

@@ -103,14 +103,19 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const u16* __restrict__ 
     *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + c) = *reinterpret_cast<const uint4*>(src + (size_t)r * lds + c);
 }
 
-// ---- C[M][N] = A[M][K] . Bt[N][K]^T (+bias) (relu) (* [aux > 0]) -----------------------------------------------------
+// ---- C[M][N] = A[M][K] . Bt[N][K]^T (+bias) (relu) (* relu bits) ------------------------------------------------------
 struct GemmArgs {
     const u16* A; int lda;
     const u16* Bt; int ldb;
     long long M; int N, K;
     const float* bias; int n_real;       // bias[col] for col < n_real (fp32 master weights), else 0
     int relu;
-    const u16* aux; int ldaux;           // optional relu mask source (the saved post-relu activation)
+    // relu bits of a trunk layer's output, one bit per (row, feature): [32-row tile][feature / 8][32 bytes], the 32 bytes of a
+    // (tile, feature octet) in the order the MFMA accumulator holds the tile's rows -- byte 16 hh + i is row (i & 3) + 8 (i >> 2)
+    // + 4 hh -- so that a lane's sixteen rows are ONE 16-byte access.  The forward GEMM writes them (mask_out; 1/16 of the
+    // activation's bytes), the dgrad GEMM of the same features reads them (mask_in) instead of the saved bf16 activation: a
+    // third of that GEMM's traffic, and its only load with a use right behind it
+    unsigned char* mask_out; const unsigned char* mask_in; int mask_cols;      // mask_cols = padded units / 8
     u16* Cb; int ldc;                    // bf16 output (may be null)
     float* Cf; int ldcf;                 // fp32 output (may be null)
     // dead-tile skipping (backward only): the 32-row tiles to process = list entries [0, *n_live) (composite.hip appends the tiles
@@ -130,19 +135,26 @@ template <> struct PackedRow<2> { typedef unsigned int type; };
 template <> struct PackedRow<4> { typedef __attribute__((ext_vector_type(2))) unsigned int type; };
 template <> struct PackedRow<8> { typedef __attribute__((ext_vector_type(4))) unsigned int type; };
 template <int NT>
-__device__ __forceinline__ typename PackedRow<NT>::type pack_row(const float (&v)[NT]) {
+__device__ __forceinline__ typename PackedRow<NT>::type pack_row(const float (&v)[NT], unsigned& bits) {
     u16 hw[NT];
+    bits = 0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) hw[t] = to_bf16(v[t]);
+    for (int t = 0; t < NT; ++t) { hw[t] = to_bf16(v[t]); bits |= ((short)hw[t] > 0 ? 1u : 0u) << t; }     // the bit = what a reader of the STORED value would decide
     typename PackedRow<NT>::type out;
     __builtin_memcpy(&out, hw, sizeof(out));
     return out;
 }
+// this lane's relu bits of the tile at row m0 (dgrad): requested at the top of the tile, used in its epilogue
 template <int NT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NT], long long m0, int n0, int r, int h) {
+__device__ __forceinline__ uint4 relu_bits_load(const GemmArgs& g, long long m0, int n0, int r, int h) {
+    return *reinterpret_cast<const uint4*>(g.mask_in + ((size_t)(m0 >> 5) * g.mask_cols + ((n0 + NT * r) >> 3)) * 32 + 16 * h);
+}
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NT], long long m0, int n0, int r, int h, uint4 mk) {
     // D[row][col]: lane (col = r, hh = h), register i -> row (i&3) + 8(i>>2) + 4hh; this lane's features: f0 .. f0 + NT - 1
     const size_t row0 = (size_t)(m0 + 4 * h);
     const int f0 = n0 + NT * r;
+    const unsigned sh = f0 & 7;                    // where this lane's NT bits sit in their octet
     float b[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = (g.bias && f0 + t < g.n_real) ? g.bias[f0 + t] : 0.f;
@@ -154,34 +166,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 #pragma unroll
             for (int t = 0; t < NT; ++t) q[t] = acc[t][i] + b[t];
         }
-    } else if (g.aux) {
-        // dgrad: dz = [saved post-relu activation > 0] * acc; the NT mask halfwords of a row are one load, the next row's
-        // requested while this one is masked and stored
+    } else if (g.mask_in) {                       // dgrad: dz = [relu bit] * acc
         typedef typename PackedRow<NT>::type P;
-        const u16* ax = g.aux + row0 * g.ldaux + f0;
         u16* p = g.Cb + row0 * g.ldc + f0;
-        P mk[2];
-        mk[0] = *reinterpret_cast<const P*>(ax);
+        const unsigned w4[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (i + 1 < 16) mk[(i + 1) & 1] = *reinterpret_cast<const P*>(ax + (size_t)(((i + 1) & 3) + 8 * ((i + 1) >> 2)) * g.ldaux);
-            u16 mh[NT];
-            __builtin_memcpy(mh, &mk[i & 1], sizeof(P));
+            const unsigned bits = w4[i >> 2] >> (8 * (i & 3) + sh);
             float v[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = (short)mh[t] > 0 ? acc[t][i] : 0.f;
-            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v);
+            for (int t = 0; t < NT; ++t) v[t] = (bits >> t) & 1u ? acc[t][i] : 0.f;
+            unsigned unused;
+            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v, unused);
         }
     } else {
         typedef typename PackedRow<NT>::type P;
         const bool relu = g.relu != 0;
         u16* p = g.Cb + row0 * g.ldc + f0;
+        unsigned w4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float v[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { v[t] = acc[t][i] + b[t]; v[t] = relu ? fmaxf(v[t], 0.f) : v[t]; }
-            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v);
+            unsigned bits;
+            *reinterpret_cast<P*>(p + (size_t)((i & 3) + 8 * (i >> 2)) * g.ldc) = pack_row<NT>(v, bits);
+            w4[i >> 2] |= bits << (8 * (i & 3) + sh);
+        }
+        if (g.mask_out) {
+            // an octet's bits sit in 8 / NT neighbouring lanes: OR them together, the first lane of the group stores
+#pragma unroll
+            for (int o = 1; o < 8 / NT; o <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w4[q] |= (unsigned)__shfl_xor((int)w4[q], o, 64);
+            }
+            if ((r & (8 / NT - 1)) == 0)
+                *reinterpret_cast<uint4*>(g.mask_out + ((size_t)(m0 >> 5) * g.mask_cols + (f0 >> 3)) * 32 + 16 * h) = uint4{w4[0], w4[1], w4[2], w4[3]};
         }
     }
 }
@@ -206,6 +226,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
     const int n0 = blockIdx.y * NB;
     const u16* A = g.A + (size_t)(m0 + r) * g.lda + 8 * h;
     const int nchunks = (g.K + kGemmKC - 1) / kGemmKC;
+    uint4 mk = uint4{0, 0, 0, 0};
+    if (g.mask_in && live) mk = relu_bits_load<NT>(g, m0, n0, r, h);
 
     uint4 stage[PER_T];
     auto fetch_b = [&](int kc) {                      // global -> registers: granule q = (row, 16-byte column chunk)
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
     if (!live) return;
-    gemm_epilogue<NT>(g, acc, m0, n0, r, h);
+    gemm_epilogue<NT>(g, acc, m0, n0, r, h, mk);
 }
 
 // Weights-stationary variant for the common case that a whole Bt slab [32 NT][K] fits in LDS: it is staged ONCE per workgroup
@@ -311,6 +333,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
     for (; tile < n_tiles; tile += stride, rt = rt_next) {
         const long long m0 = rt * 32;
         if (tile + stride < n_tiles) rt_next = row_tile(tile + stride);
+        uint4 mk = uint4{0, 0, 0, 0};
+        if (g.mask_in) mk = relu_bits_load<NT>(g, m0, n0, r, h);
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = zero16();
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
                 for (int ks = 0; ks < 4; ++ks) a_cur[ks] = a_nxt[ks];
             }
         }
-        gemm_epilogue<NT>(g, acc, m0, n0, r, h);
+        gemm_epilogue<NT>(g, acc, m0, n0, r, h, mk);
     }
 }
 
@@ -464,35 +488,54 @@ __global__ __launch_bounds__(1024) void head_compose_kernel(const float* __restr
     if (tid == 3) hb[3] = w[g.bs];
 }
 
-// gaux = M [K][4] (buffer-column order), s [4].  Phase a (one workgroup): Q = W_f^T M1 + b_f (x) s into the scratch behind
-// P, then the rgb kernel / bias.  Phase b (grid): everything that is one short dot product per element.
-__global__ __launch_bounds__(1024) void head_expand_a_kernel(const float* __restrict__ w, const float* __restrict__ gaux, float* __restrict__ head,
-                                                            float* __restrict__ grad, HeadGeom g) {
+// gaux = M [K][4] (buffer-column order), s [4].  Phase a (grid over blocks of 64 features): Q = W_f^T M1 + b_f (x) s into the
+// scratch behind P -- 64 columns x 16 slices of the Tr rows per workgroup, the slices summed in a fixed order through LDS (one
+// workgroup walking all Tr rows in one loop, as rounds 1-4 had it, took 216 us per call: 5 % of a chunk).  Phase c (one wave per
+// element): the rgb kernel / bias, which need all of Q.  Phase b (grid): everything that is one short dot product per element.
+__global__ __launch_bounds__(1024) void head_expand_a_kernel(const float* __restrict__ w, const float* __restrict__ gaux, float* __restrict__ head, HeadGeom g) {
+    __shared__ float part[16][64][3];
     const float* M = gaux;
     const float* sv = gaux + (size_t)g.K * 4;
     float* P = head + (size_t)g.K * 4 + 4;
     float* Q = P + (size_t)(g.U + g.dir_dim) * 3;
-    const int tid = threadIdx.x;
-    for (int j = tid; j < g.U; j += 1024) {
-        const float bf = w[g.bf + j];
-        float a0 = bf * sv[0], a1 = bf * sv[1], a2 = bf * sv[2];
-        for (int i = 0; i < g.Tr; ++i) {
+    const int jj = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (j < g.U) {
+        for (int i = sl; i < g.Tr; i += 16) {
             const float v = w[g.wf + (size_t)i * g.U + j];
             const float* m = M + (size_t)head_col_of_trunk_row(g, i) * 4;
             a0 += v * m[0]; a1 += v * m[1]; a2 += v * m[2];
         }
+    }
+    part[sl][jj][0] = a0; part[sl][jj][1] = a1; part[sl][jj][2] = a2;
+    __syncthreads();
+    if (sl == 0 && j < g.U) {
+        const float bf = w[g.bf + j];
+        a0 = bf * sv[0]; a1 = bf * sv[1]; a2 = bf * sv[2];
+        for (int q = 0; q < 16; ++q) { a0 += part[q][jj][0]; a1 += part[q][jj][1]; a2 += part[q][jj][2]; }
         Q[j * 3] = a0; Q[j * 3 + 1] = a1; Q[j * 3 + 2] = a2;
     }
-    __syncthreads();
-    for (int e = tid; e < g.u2 * 3; e += 1024) {          // rgb kernel [u2][3] += W_r1^T Q + W_r2^T M2 + b_r (x) s
+}
+__global__ __launch_bounds__(256) void head_expand_c_kernel(const float* __restrict__ w, const float* __restrict__ gaux, const float* __restrict__ head,
+                                                           float* __restrict__ grad, HeadGeom g) {
+    const float* M = gaux;
+    const float* sv = gaux + (size_t)g.K * 4;
+    const float* P = head + (size_t)g.K * 4 + 4;
+    const float* Q = P + (size_t)(g.U + g.dir_dim) * 3;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);    // rgb kernel [u2][3] += W_r1^T Q + W_r2^T M2 + b_r (x) s: one wave per element
+    if (e < g.u2 * 3) {
         const int k = e / 3, c = e % 3;
-        float a = w[g.br + k] * sv[c];
-        for (int j = 0; j < g.U; ++j) a += w[g.wr + (size_t)j * g.u2 + k] * Q[j * 3 + c];
-        for (int m = 0; m < g.dir_dim; ++m) a += w[g.wr + (size_t)(g.U + m) * g.u2 + k] * M[(size_t)(g.dir_col0 + m) * 4 + c];
-        grad[g.wc + e] += a;
+        float a = 0.f;
+        for (int j = lane; j < g.U; j += 64) a += w[g.wr + (size_t)j * g.u2 + k] * Q[j * 3 + c];
+        for (int m = lane; m < g.dir_dim; m += 64) a += w[g.wr + (size_t)(g.U + m) * g.u2 + k] * M[(size_t)(g.dir_col0 + m) * 4 + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) grad[g.wc + e] += a + w[g.br + k] * sv[c];
     }
-    if (tid < 3) grad[g.bc + tid] += sv[tid];
-    if (tid == 3) grad[g.bs] += sv[3];
+    if (blockIdx.x == 0 && threadIdx.x < 3) grad[g.bc + threadIdx.x] += sv[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 3) grad[g.bs] += sv[3];
 }
 __global__ __launch_bounds__(256) void head_expand_b_kernel(const float* __restrict__ w, const float* __restrict__ gaux, const float* __restrict__ head,
                                                            float* __restrict__ grad, HeadGeom g) {
@@ -703,7 +746,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     }
 }
 
-// Cooperative wgrad for layers of at least 128 x 128: a workgroup of 8 waves owns a 256 (inputs) x 256 (outputs) block of dW
+// Cooperative wgrad (every layer larger than one 64 x 64 tile, coop_serves below): a workgroup of 8 waves owns a 256 (inputs) x 256 (outputs) block of dW
 // and walks 32-sample steps; per step the X and dZ slabs [32][256] are staged ONCE in LDS and every wave builds its operand
 // fragments with ds_read_b64_tr_b16 -- lane 4q+p of a 16-lane group supplies the address of sample row q / feature quad p and
 // receives feature `lane` of the four samples, i.e. exactly the MFMA operand layout with samples as k (tests/test_gpu_probe.py
@@ -874,10 +917,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int n_sl
     }
 }
 
+// Which of the two weight-gradient kernels serves a [K] x [N] layer: the cooperative one, always (since round 5).  The per-wave
+// kernel re-reads X once per column block and dZ once per row block of its (at most 64 x 64) tiles -- the first layer (K = 64)
+// ran at 1.6 TB/s on it (306 us per fine launch, 105 us now), the head's [head_K] x [32] sums took 200 us (159 us now) -- and where
+// one tile covers the whole layer (widths <= 64) its 1,024 workgroups x 4 waves flush the SAME few thousand addresses with
+// atomics: 410-510 us per 64 x 64 layer for 40 us of traffic, 80 % of a width-64 train chunk.  Tiles past K or N cost the
+// cooperative kernel nothing but idle waves (k_ok / n_ok) and DMA copies of clamped chunks that hit in cache; it flushes once per
+// workgroup (256 of them).  For A/B runs: -DKNERF_GEN_COOP_MIN_TILES=n keeps layers with fewer than n tiles on BOTH sides on the
+// per-wave kernel, -DKNERF_GEN_NO_COOP everything.
+#ifndef KNERF_GEN_COOP_MIN_TILES
+#define KNERF_GEN_COOP_MIN_TILES 1      // kt or nt >= this
+#endif
+inline bool coop_serves(int kt, int nt) {
+#ifdef KNERF_GEN_NO_COOP
+    return false;
+#else
+    return kt >= KNERF_GEN_COOP_MIN_TILES || nt >= KNERF_GEN_COOP_MIN_TILES;
+#endif
+}
+
 // slab floats one weight-gradient launch over a [K] x [N] layer can need (the grid's upper bound; independent of the sample count)
 size_t wgrad_partial_floats_for(int K, int N) {
     const int kt = K / 32, nt = N / 32;
-    if (kt >= 4 && nt >= 4) {
+    if (coop_serves(kt, nt)) {
         const long long gx = (K + 255) / 256, gy = (N + 255) / 256;
         long long gz = 256 / (gx * gy); if (gz < 1) gz = 1;
         return (size_t)(gx * gy * gz) * (256 * 256 + 256);
@@ -890,8 +952,7 @@ size_t wgrad_partial_floats_for(int K, int N) {
 
 hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
     const int kt = K / 32, nt = N / 32;
-#ifndef KNERF_GEN_NO_COOP
-    if (kt >= 4 && nt >= 4) {
+    if (coop_serves(kt, nt)) {
         static AttrOnce once;
         const size_t lds = (size_t)kCoopDepth * kCoopBuf;
         hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -908,7 +969,6 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((256 * 256 + 256 + 255) / 256, gx * gy), dim3(256), 0, s, g, (int)gz, 256, 256, 1, gy);
         return hipGetLastError();
     }
-#endif
 #ifndef KNERF_GEN_MAXKT
 #define KNERF_GEN_MAXKT 2
 #endif
@@ -1029,6 +1089,8 @@ Plan build_plan_widths(int n_layers, int units, int skip, int xyz_dim, int dir_d
 }
 
 size_t padded_rows(long long n) { return (size_t)((n + 127) / 128 * 128); }
+size_t relu_bits_bytes_per_row(const Plan& p) { return (size_t)p.up / 8; }
+size_t relu_bits_bytes(const Plan& p, size_t mp) { return (size_t)p.n_layers * relu_bits_bytes_per_row(p) * mp; }
 
 namespace {
 u16* act_buf(const Plan& p, const Workspace& ws, int b) {
@@ -1084,7 +1146,8 @@ hipError_t pack_weights(const Plan& p, const float* w_flat, const NetDev& net, h
 
 hipError_t expand_head(const Plan& p, const NetDev& net, const float* w_flat, float* grad_flat, hipStream_t s) {
     const HeadGeom g = head_geom(p);
-    hipLaunchKernelGGL(head_expand_a_kernel, dim3(1), dim3(1024), 0, s, w_flat, net.gaux, net.head, grad_flat, g);
+    hipLaunchKernelGGL(head_expand_a_kernel, dim3((g.U + 63) / 64), dim3(1024), 0, s, w_flat, net.gaux, net.head, g);
+    hipLaunchKernelGGL(head_expand_c_kernel, dim3((g.u2 * 3 + 3) / 4), dim3(256), 0, s, w_flat, net.gaux, net.head, grad_flat, g);
     const long long total = (long long)g.Tr * g.U + g.U + (long long)(g.U + g.dir_dim) * g.u2 + g.u2 + g.Tr;
     hipLaunchKernelGGL(head_expand_b_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w_flat, net.gaux, net.head, grad_flat, g);
     hipError_t e = hipGetLastError();
@@ -1105,6 +1168,7 @@ hipError_t run_layers(const Plan& p, const Workspace& ws, const NetDev& net, con
         g.M = mp; g.N = L.np; g.K = g.lda;
         g.bias = w_flat + L.b_off; g.n_real = L.n_real; g.relu = L.relu;
         g.Cb = act_buf(p, ws, L.out_buf) + L.out_col0; g.ldc = p.buf_ld[L.out_buf];
+        if (ws.mask) { g.mask_out = ws.mask + (size_t)li * relu_bits_bytes_per_row(p) * mp; g.mask_cols = p.up / 8; }      // training workspace: the dgrad's relu bits
         GENCHK(launch_gemm(g, s));
         if (p.concat_after[li]) {
             hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(mp * (p.kxp / 8))), dim3(256), 0, s, ex, p.kxp,
@@ -1178,10 +1242,11 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
         GENCHK(hipGetLastError());
     }
     // dead-tile skipping: every GEMM and weight-gradient product below walks the list of live 32-row tiles instead of all of mp
-    auto dgrad = [&](const u16* A, int lda, int K, const u16* Wd, int ldb, int N, const u16* aux, int ldaux, u16* C, int ldc) {
+    if (!ws.mask) return hipErrorInvalidValue;       // the forward that preceded must have run on a training workspace
+    auto dgrad = [&](const u16* A, int lda, int K, const u16* Wd, int ldb, int N, int layer, u16* C, int ldc) {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.Bt = Wd; g.ldb = ldb; g.M = mp; g.N = N; g.K = K;
-        g.aux = aux; g.ldaux = ldaux; g.Cb = C; g.ldc = ldc;
+        g.mask_in = ws.mask + (size_t)layer * relu_bits_bytes_per_row(p) * mp; g.mask_cols = p.up / 8; g.Cb = C; g.ldc = ldc;
         g.live = live; g.n_live = n_live;
         return launch_gemm(g, s);
     };
@@ -1189,14 +1254,12 @@ hipError_t backward(const Plan& p, const Workspace& ws, const NetDev& net, const
     // trunk layer's relu; only the h columns carry a gradient (xyz_enc and dir_enc are constants)
     {
         const Layer& Ll = p.layers[nl - 1];
-        GENCHK(dgrad(dzh, 32, 32, net.packed + p.head_wd_off, 32, p.up, act_buf(p, ws, Ll.out_buf), p.buf_ld[Ll.out_buf],
-                     dz_buf(p, ws, Ll.dz_buf), p.up));
+        GENCHK(dgrad(dzh, 32, 32, net.packed + p.head_wd_off, 32, p.up, nl - 1, dz_buf(p, ws, Ll.dz_buf), p.up));
     }
     for (int i = nl - 2; i >= 0; --i) {
         const Layer& Ln = p.layers[i + 1];
         const Layer& Li = p.layers[i];
-        GENCHK(dgrad(dz_buf(p, ws, Ln.dz_buf), p.up, p.up, net.packed + Ln.wd_off, Ln.wd_ld, p.up, act_buf(p, ws, Li.out_buf),
-                     p.buf_ld[Li.out_buf], dz_buf(p, ws, Li.dz_buf), p.up));
+        GENCHK(dgrad(dz_buf(p, ws, Ln.dz_buf), p.up, p.up, net.packed + Ln.wd_off, Ln.wd_ld, p.up, i, dz_buf(p, ws, Li.dz_buf), p.up));
     }
     for (int li = 0; li < nl; ++li) {
         const Layer& L = p.layers[li];

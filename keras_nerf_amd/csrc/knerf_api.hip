@@ -132,7 +132,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         HIPCHK(hipMalloc(&ctx->t_f, ns * sizeof(float)));
         HIPCHK(hipMalloc(&ctx->img_tmp, (size_t)R * 8 * sizeof(float)));
         gen::Workspace& g = ctx->gws;
-        free_dev(g.act); free_dev(g.dz); free_dev(g.zs); free_dev(g.zc);
+        free_dev(g.act); free_dev(g.dz); free_dev(g.zs); free_dev(g.zc); free_dev(g.mask);
         g.mp = gen::padded_rows((long long)ns);
         const size_t ab = ctx->gplan.act_elems_per_row * g.mp * sizeof(unsigned short), zb = ctx->gplan.dz_elems_per_row * g.mp * sizeof(unsigned short);
         HIPCHK(hipMalloc(&g.act, ab));
@@ -142,6 +142,7 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         if (train) {
             HIPCHK(hipMalloc(&g.dz, zb));
             HIPCHK(hipMemsetAsync(g.dz, 0, zb, s));
+            HIPCHK(hipMalloc(&g.mask, gen::relu_bits_bytes(ctx->gplan, g.mp)));
             HIPCHK(hipMalloc(&ctx->draw, ctx->raw_bytes));
             ctx->draw_bytes = ctx->raw_bytes;
             free_dev(ctx->loss_partial);
@@ -560,7 +561,7 @@ int knerf_destroy(knerf_ctx* ctx) {
     free_dev(ctx->act); free_dev(ctx->mask); free_dev(ctx->dz);
     free_dev(ctx->tile_flags); free_dev(ctx->tile_list); free_dev(ctx->tile_list_g); free_dev(ctx->tile_count); free_dev(ctx->tile_stats);
     free_dev(ctx->partial); free_dev(ctx->loss_partial); free_dev(ctx->d_job_wg0);
-    free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc);
+    free_dev(ctx->gws.act); free_dev(ctx->gws.dz); free_dev(ctx->gws.zs); free_dev(ctx->gws.zc); free_dev(ctx->gws.mask);
     for (int n = 0; n < 2; ++n) { free_dev(ctx->gnet[n].packed); free_dev(ctx->gnet[n].head); free_dev(ctx->gnet[n].gaux); }
     free_dev(ctx->call_net.head);
     free_dev(ctx->call_ws.act); free_dev(ctx->call_ws.zs); free_dev(ctx->call_ws.zc); free_dev(ctx->call_net.packed); free_dev(ctx->call_raw);
