@@ -50,7 +50,16 @@ CONFIGS = {
     "cfg4": (128, 1, 4096, "chair-shaped 128x128, 1 image per GPU, ray_chunks 4096, coarse64+fine128"),
     # forward only: one "step" = one frame of the 360-degree sweep of inference.py (pose -> rays -> render -> D2H)
     "cfg5": (256, 1, 4096, "inference.py-shaped 360-degree render, 256x256, ray_chunks 4096, coarse64+fine128, forward only"),
+    # the command lines the reference's source comments quote a wall-clock time for: the only published numbers
+    # of this path, 1x / 2x Tesla V100.  Parity-of-configuration lines, not the headline (BASELINE.json's metric is quoted on cfg2).
+    "ref1": (128, 1, 2048, "train_single.py:16-17: --img_wh 128 --ray_chunks 2048, batch 1, coarse64+fine128 (reference: 3 s/step on 1x V100)"),
+    "ref2": (128, 1, 4096, "train_single.py:18: --img_wh 128 --ray_chunks 4096, batch 1 (reference, eager: 2 s/step on 1x V100)"),
+    "ref3": (128, 4, 4096, "train_single.py:19: --img_wh 128 --ray_chunks 4096 --batch_size 4 (reference, eager: 11 s/step on 1x V100)"),
+    "ref4": (128, 1, 2048, "train.py:16-17: --img_wh 128 --ray_chunks 2048, one image per GPU (reference: 5-6 s/step on 2x V100; run with --gpus 2)"),
 }
+# seconds per step the reference's comments state for those command lines -> vs_baseline of THAT line only
+PUBLISHED_S_PER_STEP = {"ref1": (3.0, "1x Tesla V100 32 GB, train_single.py:16-17"), "ref2": (2.0, "1x Tesla V100 32 GB, train_single.py:18"),
+                        "ref3": (11.0, "1x Tesla V100 32 GB, train_single.py:19"), "ref4": (5.5, "2x Tesla V100 32 GB, train.py:16-17 (5-6 s)")}
 
 
 def make_batch(nerf, wh, batch, rank, seed=42):
@@ -663,12 +672,20 @@ def run(args, world, rank, device_index, backend):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    # vs_baseline: null on the headline (nothing is published for cfg2); on a ref* line the reference's own stated seconds per step
+    # for that command line, on its hardware -- for ref4 only at the GPU count the comment was written for
+    vs_baseline, baseline_note = None, None
+    if args.config in PUBLISHED_S_PER_STEP and (args.config != "ref4" or world == 2) and (args.config == "ref4" or world == 1):
+        ref_s, where = PUBLISHED_S_PER_STEP[args.config]
+        vs_baseline = value / (n_rays * world * samples_per_ray / ref_s)
+        baseline_note = f"{ref_s:g} s/step = {n_rays * world * samples_per_ray / ref_s / 1e6:.2f} M rays*samples/s, {where}"
     if rank == 0:
         out = {
             "metric": "rays*samples/sec (train step), lego 128^2 coarse64+fine128" if args.config == "cfg2"
                       else f"rays*samples/sec (train step), {args.config}",
             "value": value, "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": vs_baseline,
+            **({"baseline": baseline_note} if baseline_note else {}),
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},

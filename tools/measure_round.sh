@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
 #   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half stores
-#                                                          round 5: sparsity lds masklayout gensk fuzzgen rehearsal
+#                                                          round 5: sparsity lds masklayout gensk fuzzgen rehearsal refs
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -66,6 +66,8 @@ for l in open('$OUT/shapes_kbench.jsonl'):
     rehearsal) # an N = 3 line over gloo on one GPU (control flow and the line's diagnostics fields, not a measurement)
            KNERF_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 3 --config cfg4 --steps 10 --warmup 2 --no-cpu-baseline 2> $OUT/rehearsal.err | grep "^{" > $OUT/bench_cfg4_3ranks_gloo.json || fault rehearsal
            python -c "import json; l=json.load(open('$OUT/bench_cfg4_3ranks_gloo.json')); print('rehearsal', l['n_gpus'], l['replica_drift'], l['allreduce_us_standalone']['median'])" ;;
+    refs)  # the command lines the reference's source comments quote a time for, as bench configs
+           for c in ref1 ref2 ref3; do timeout -k 10 200 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err || fault $c; python -c "import json; l=json.load(open('$OUT/bench_$c.json')); print('$c', l['ms_per_step'], l['value'], l['vs_baseline'], l['baseline'])"; done ;;
   esac
 done
 exit 0
