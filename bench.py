@@ -473,6 +473,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--ray-chunks", type=int, default=None, help="override the configuration's ray_chunks (sensitivity sweeps; the line's workload says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--mode", default="step", choices=["step", "fit"], help="step: the train_step loop on one resident batch (the contract's line); "
@@ -521,6 +522,8 @@ def run(args, world, rank, device_index, backend):
     """everything behind the process group's set-up: one of the three benchmark bodies"""
     from keras_nerf_amd.model.nerf.nerf import NeRF
     wh, batch, chunks, desc = CONFIGS[args.config]
+    if args.ray_chunks:
+        chunks, desc = args.ray_chunks, desc + f" [ray_chunks overridden: {args.ray_chunks}]"
     if args.config == "cfg5":
         return bench_render(args, world, rank, wh, chunks, desc, backend)
     if args.mode == "fit":

@@ -140,6 +140,14 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *   "grad_diagnostics"  0/1  (default 0) knerf_train_batch counts the non-zero entries of the last chunk's gradient of each net
  *                            (knerf_grad_diagnostics; the reference does this when run_eagerly, nerf.py:430-451); one launch of the
  *                            coarse weight-gradient kernel per chunk while it is on.
+ *   "merge_chunk_rays"  0..1048576 (default 4096) knerf_train_batch / knerf_render_batch run m consecutive chunks as one set of launches,
+ *                            m the largest divisor of the chunk count with m * ray_chunks <= this value (0: every chunk its own
+ *                            launches).  `ray_chunks` is the reference's memory knob (nerf.py:100, 332-473): every ray's forward, loss
+ *                            term and gradient contribution is independent of the chunk that holds it (mean over R rays times 1 / C
+ *                            = mean over m R rays times m / C; the fine sampler's random numbers are keyed by the ray's index in the
+ *                            batch), so rendered outputs are bit-identical and accumulated gradients equal up to the order of fp32
+ *                            sums.  4,096 rays need 8 GB of workspace here; if that cannot be allocated the caller's own chunk
+ *                            size is used.  Off while "grad_diagnostics" is on (it counts the LAST chunk's gradient).
  *   "wgrad_group_max"   1..64, "wgrad_group_gb" >= 0: chunks per coarse weight-gradient launch of knerf_train_batch and the memory
  *                            budget of the workspaces that takes (defaults 4 and 40 GB; 1 or 0 = one launch per chunk).
  *   "wgrad_cost0".."wgrad_cost<n_layers>": relative cost per sample tile of the n_layers + 1 weight-gradient jobs (nine for the default shape) (workgroups are dealt out in that

@@ -420,6 +420,20 @@ int wgrad_group_for(knerf_ctx* ctx, int n_rays, int n_chunks) {
     return memo((n_chunks + n_groups - 1) / n_groups);      // the smallest group that needs no more launches
 }
 
+// Chunks per LAUNCH (option "merge_chunk_rays", default 4096 rays).  `ray_chunks` is the reference's memory knob (nerf.py:100,
+// 332-473: a Python loop over chunks, gradients accumulated as g / C): every ray's forward, loss term and gradient contribution is
+// independent of which chunk holds it -- the per-chunk mean over R rays times 1 / C is the per-launch mean over m R rays times
+// m / C, the fine sampler's random numbers are keyed by the ray's index in the batch -- so m consecutive chunks run as ONE set of
+// launches: rendered outputs bit-identical, accumulated gradients equal up to the order of fp32 sums.  On this device a 4,096-ray
+// launch needs 8 GB of workspace; launches of 256 / 512 / 1,024 rays (the reference's train.py defaults to 1,024) fill 256 CUs
+// badly: 23.7 / 18.0 / 14.3 ms per 128 x 128 image against 13.7.  m divides the chunk count (equal-sized launches).
+int merge_factor(const knerf_ctx* ctx, int ray_chunks, int n_chunks) {
+    if (ctx->merge_rays <= 0 || n_chunks <= 1) return 1;
+    for (int m = n_chunks; m > 1; --m)
+        if (n_chunks % m == 0 && (long long)m * ray_chunks <= ctx->merge_rays) return m;
+    return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -681,6 +695,7 @@ int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "render_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
     const size_t Nc = (size_t)ctx->cfg.n_coarse, Nf = (size_t)ctx->cfg.n_fine, Na = Nc + Nf;
+    ray_chunks *= merge_factor(ctx, ray_chunks, n_rays / ray_chunks);        // per-ray work only: bit-identical outputs
     for (int i = 0; i < n_rays / ray_chunks; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
         if (int r = knerf_render_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, u ? u + r0 * Nf : nullptr, seed, (uint64_t)r0,
@@ -713,16 +728,26 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "train_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
     hipStream_t s = (hipStream_t)stream;
-    const int C = n_rays / ray_chunks, Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
+    const int Nc = ctx->cfg.n_coarse, Nf = ctx->cfg.n_fine;
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
     ctx->tile_counter_next = 0;
-    // zero-gradient diagnostics count the LAST chunk's gradient (nerf.py:430-451): that chunk's weight-gradient launches must be its own
-    int G = ctx->grad_diag ? 1 : wgrad_group_for(ctx, ray_chunks, C);
-    if (int r = ensure_ws(ctx, ray_chunks, true, s, G)) {
-        if (G == 1) return r;
-        G = 1;                                                      // the group did not fit: one chunk per wgrad launch
-        ctx->group_cache_rays = ray_chunks; ctx->group_cache_chunks = C; ctx->group_cache = 1;
-        if (int r1 = ensure_ws(ctx, ray_chunks, true, s, 1)) return r1;
+    // zero-gradient diagnostics count the LAST chunk's gradient (nerf.py:430-451): that chunk's launches must be its own
+    int merge = ctx->grad_diag ? 1 : merge_factor(ctx, ray_chunks, n_rays / ray_chunks);
+    const int user_chunks = ray_chunks;
+    int C = 0, G = 1;
+    for (;;) {
+        ray_chunks = user_chunks * merge;
+        C = n_rays / ray_chunks;
+        G = ctx->grad_diag ? 1 : wgrad_group_for(ctx, ray_chunks, C);
+        int r = ensure_ws(ctx, ray_chunks, true, s, G);
+        if (r && G > 1) {                                           // the group did not fit: one chunk per wgrad launch
+            G = 1;
+            ctx->group_cache_rays = ray_chunks; ctx->group_cache_chunks = C; ctx->group_cache = 1;
+            r = ensure_ws(ctx, ray_chunks, true, s, 1);
+        }
+        if (!r) break;
+        if (merge == 1) return r;
+        merge = 1;                                                  // the merged launches did not fit either: the caller's own chunks
     }
     const size_t tc = tiles_for((long long)ray_chunks * Nc);
     const bool skip = skipping(ctx);
@@ -819,6 +844,9 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
         ctx->grad_diag = value != 0;
     } else if (n == "skip_dead_tiles") {
         ctx->skip_dead = value != 0;               // ignored where it does not apply (general-shape path, sample counts not multiples of 32)
+    } else if (n == "merge_chunk_rays") {
+        if (value < 0 || value > 1048576) return fail(ctx, KNERF_ERR_INVALID, "merge_chunk_rays: 0..1048576");
+        ctx->merge_rays = (int)value;
     } else if (n == "wgrad_group_max") {
         if (value < 1 || value > 64) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_max: 1..64");
         ctx->wgrad_group_max = (int)value; ctx->group_cache = 0;
@@ -842,6 +870,7 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     else if (n == "grad_diagnostics") *value = ctx->grad_diag;
     else if (n == "skip_dead_tiles_active") *value = skipping(ctx);
     else if (n == "wgrad_group_max") *value = ctx->wgrad_group_max;
+    else if (n == "merge_chunk_rays") *value = ctx->merge_rays;
     else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
     else if (n == "wgrad_group") *value = ctx->ws_train ? ctx->ws_group : 0;            // chunks per coarse wgrad launch of the current workspaces
     else if (n == "general_shape_path") *value = ctx->generic;

@@ -43,7 +43,7 @@ class KnerfContext:
         for knerf_set_option.  encoded_widths = (xyz_dim, dir_dim): a stand-alone NeRFMLP of those two input widths
         (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
         KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
-        KNERF_SKIP_DEAD_TILES into the config flag / options below (explicit arguments win)."""
+        KNERF_SKIP_DEAD_TILES, KNERF_MERGE_CHUNK_RAYS into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
         if not torch.cuda.is_available():
             raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
@@ -85,8 +85,9 @@ class KnerfContext:
         opts = {}
         env = os.environ
         for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),
-                          ("KNERF_DETERMINISTIC", "deterministic"), ("KNERF_SKIP_DEAD_TILES", "skip_dead_tiles")):
-            if env.get(key):
+                          ("KNERF_DETERMINISTIC", "deterministic"), ("KNERF_SKIP_DEAD_TILES", "skip_dead_tiles"),
+                          ("KNERF_MERGE_CHUNK_RAYS", "merge_chunk_rays")):
+            if env.get(key) not in (None, ""):
                 opts[name] = float(env[key])
         env_costs = {}
         if env.get("KNERF_WGRAD_COSTS"):          # one entry per weight-gradient job (n_layers + 1 of them); surplus entries are ignored

@@ -464,6 +464,30 @@ def _bench(args, env_extra, timeout=420):
                           env=dict(base, **env_extra))
 
 
+def test_bench_line_of_the_references_own_command_line_and_of_small_chunks():
+    """`bench.py --config ref1` = train_single.py:16-17 (--img_wh 128 --ray_chunks 2048, batch 1), the command line the reference's
+    comment quotes 3 s per step for: vs_baseline is filled on such lines only, against that number; the single-process line's
+    metric time is small and positive.  With --ray-chunks 256 the 64 chunks of a step run as four 4,096-ray sets of launches
+    (option merge_chunk_rays): the dominant kernel's launch count over the two profiled steps says so."""
+    import json
+    r = _bench(["--config", "ref1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert "train_single.py:16-17" in line["config"]["workload"] and line["config"]["rays_per_step_per_gpu"] == 128 * 128
+    assert line["vs_baseline"] == pytest.approx(line["value"] / (128 * 128 * 256 / 3.0)) and line["vs_baseline"] > 20
+    assert "3 s/step" in line["baseline"] and "V100" in line["baseline"]
+    assert 0 < line["metrics_ms_per_step"] < 5 and "hip events" in line["metrics_clock"]
+    assert line["roofline"]["launches"] == 2 * 4                      # 8 chunks of 2,048 -> four launches of 4,096 rays per step
+    r = _bench(["--config", "ref1", "--ray-chunks", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    small = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert "ray_chunks overridden: 256" in small["config"]["workload"] and small["roofline"]["launches"] == 2 * 4
+    r = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    head = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert head["vs_baseline"] is None and "baseline" not in head        # nothing is published for the headline configuration
+
+
 def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     """cfg4 (BASELINE configs[3]: one 128 x 128 image per GPU, 8 GPUs) as far as a one-GPU box allows: THREE ranks share this device
     over gloo.  The pool kills a run in which more than six processes of one user have the GPU open: this test process, the launcher
@@ -489,7 +513,9 @@ def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     st = line["allreduce_us_standalone"]
     assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] and st["host_wall_us_median"] > 0 and line["allreduce_busbw_GBps"] > 0
     assert "rccl_version" in line and line["allreduce_selftest_operand_stayed_zero"] is True
-    assert 0 < line["metrics_ms_per_step"] < 5 and "hip events" in line["metrics_clock"]
+    # three processes share ONE card here: other ranks' kernels run between this rank's two events (13.7 ms seen), so only the sign
+    # is a property; the single-process lines assert the size
+    assert 0 < line["metrics_ms_per_step"] and "hip events" in line["metrics_clock"]
     for k in range(3):
         assert f"[bench rank {k}/3] local_rank {k} -> cuda:0" in r.stderr, r.stderr[-3000:]
         assert f"[bench rank {k}/3] device memory free" in r.stderr

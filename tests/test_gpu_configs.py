@@ -106,7 +106,7 @@ def test_grouped_wgrad_path_meets_the_oracle():
     P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
     cfg, N, R = P["cfg"], 256, 128
     o, d, t, u, img = (P[k].reshape(N, -1) for k in ("o", "d", "t", "u", "img"))
-    ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=2))
+    ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=2, merge_chunk_rays=0))     # the caller's own chunks: this test is about their grouped launch
     ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
     loss = torch.zeros(2, device="cuda")
     tf_all = torch.empty((N, 192), device="cuda")
@@ -272,8 +272,11 @@ def test_coarse_only_configuration_trains_both_nets_against_oracle():
     ctx.close()
 
 
-def test_cfg1_as_written_64x64_in_four_chunks_of_1024_against_oracle():
-    """BASELINE configs[0] AS WRITTEN on the GPU: lego-shaped 64 x 64 image, batch 1, ray_chunks 1024 -> 4 chunks,
+@pytest.mark.parametrize("merge", [0, 4096])
+def test_cfg1_as_written_64x64_in_four_chunks_of_1024_against_oracle(merge):
+    """merge = 0: the four chunks as four sets of launches; merge = 4096 (the library's default, option merge_chunk_rays): the same
+    call runs them as ONE 4,096-ray set of launches -- the same oracle comparison must hold.
+    BASELINE configs[0] AS WRITTEN on the GPU: lego-shaped 64 x 64 image, batch 1, ray_chunks 1024 -> 4 chunks,
     coarse-only (n_fine = 0: the second network runs on the coarse t-values, nerf.py:182-191), through knerf_train_batch -- full-size
     launches, the coarse weight gradients of the four chunks in one grouped launch.  The NumPy oracle cannot do 4,096 rays in
     seconds, so the comparison uses an EXACT property instead of a smaller problem: a ray whose target equals the rendered pixel has
@@ -297,7 +300,8 @@ def test_cfg1_as_written_64x64_in_four_chunks_of_1024_against_oracle():
     rnd = torch.rand((N, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
     so, sd, st, sg = (x[ti].cpu().numpy() for x in (o, d, t, rnd))
     for net, params, skip in ((0, cp, 1), (1, fp, 0)):
-        ctx = KnerfContext(n_coarse=64, n_fine=0, white_background=False, options=dict(skip_dead_tiles=skip))
+        ctx = KnerfContext(n_coarse=64, n_fine=0, white_background=False, options=dict(skip_dead_tiles=skip, merge_chunk_rays=merge))
+        assert ctx.get_option("merge_chunk_rays") == merge
         ctx.set_weights(0, O.flatten_params(cp)); ctx.set_weights(1, O.flatten_params(fp))
         ren = ctx.render_batch(o, d, t, None, ray_chunks=R)
         tgt = ren["c_image" if net == 0 else "f_image"].clone()
@@ -307,10 +311,10 @@ def test_cfg1_as_written_64x64_in_four_chunks_of_1024_against_oracle():
         ctx.train_batch(o, d, t, tgt, None, ray_chunks=R, loss=loss, c_image=ci, f_image=fi)
         torch.cuda.synchronize()
         assert torch.equal(ci, ren["c_image"]) and torch.equal(fi, ren["f_image"])      # training and rendering share the kernels' arithmetic
-        assert ctx.get_option("wgrad_group") == 4.0                                     # the four coarse passes left in ONE weight-gradient launch
+        assert ctx.get_option("wgrad_group") == (4.0 if merge == 0 else 1.0)            # merge = 0: the four coarse passes left in ONE weight-gradient launch
         live, total = ctx.tile_stats(reset=True)
         if skip:                                                                        # 2 passes x 4 chunks x 2,048 tiles; the net under test keeps its 256 rays' tiles
-            assert total == 2 * C * R * 64 // 32 and 0 < live <= 256 * 2 + total // 2, (live, total)
+            assert total == 2 * C * R * 64 // 32 and 0 < live <= 256 * 2 + total // 2, (live, total)     # the same tiles either way
         n = ctx.param_count
         g = ctx.grads_view().cpu().numpy()[net * n:(net + 1) * n] * (N / 256.0)
         got_loss = float(loss[net]) * (N / 256.0)

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 def _ctx(P, **options):
     from keras_nerf_amd.runtime import KnerfContext
+    options.setdefault("merge_chunk_rays", 0)       # these tests are about the caller's chunks as launches (grouping, odd sizes); merging: test_gpu_merge.py
     ctx = KnerfContext(white_background=True, options=options)
     ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
     return ctx

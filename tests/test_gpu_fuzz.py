@@ -27,7 +27,7 @@ def test_grouped_train_batch_equals_chunk_by_chunk(rays_per_chunk, chunks, group
     u = torch.as_tensor(P["u"].reshape(P["N"], -1)[:R].copy(), device="cuda")
     gs, ls = [], []
     for mode in ("batch", "chunks"):
-        ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=group_max))
+        ctx = KnerfContext(white_background=True, options=dict(wgrad_group_max=group_max, merge_chunk_rays=0))
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         ctx.zero_grads()
         loss = torch.zeros(2, device="cuda")
@@ -125,7 +125,7 @@ def test_more_chunks_per_batch_than_the_counter_ring_held():
     o, d, t, img, u = (torch.as_tensor(P[k].reshape(P["N"], -1), device="cuda")[idx].contiguous() for k in ("o", "d", "t", "img", "u"))
     res = {}
     for skip in (1, 0):
-        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip))
+        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip, merge_chunk_rays=0))      # 2,200 chunks of 32 rays AS chunks (the counter ring)
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         loss = torch.zeros(2, device="cuda")
         ctx.train_batch(o, d, t, img, u, ray_chunks=rc, loss=loss)
