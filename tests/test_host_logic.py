@@ -137,6 +137,49 @@ def test_image_loader_composites_and_resizes(tmp_path):
     assert ImageLoader(4, 4)(p).shape == (4, 4, 4)
 
 
+def test_antialiased_resize_follows_the_scale_and_translate_algorithm(tmp_path):
+    """image.py:22-23 `tf.image.resize(image, size, antialias=True)`: triangle kernel widened by the reduction factor, taps on pixel
+    centres, weights normalised per output pixel, float32 throughout (data/image.py).  Known answers of that algorithm."""
+    from PIL import Image
+    from keras_nerf_amd.data.image import ImageLoader, resize_antialiased, triangle_resize_weights
+    rng = np.random.default_rng(0)
+    np.testing.assert_array_equal(triangle_resize_weights(7, 7), np.eye(7, dtype=np.float32))             # equal size: identity
+    W = triangle_resize_weights(16, 8)                                                                      # 2:1 -> taps (1, 3, 3, 1) / 8
+    np.testing.assert_allclose(W[3, 5:9], [0.125, 0.375, 0.375, 0.125], atol=1e-7)
+    assert np.count_nonzero(W[3]) == 4
+    np.testing.assert_allclose(W[0, :3], np.array([3, 3, 1]) / 7.0, atol=1e-7)                             # border: the taps inside, renormalised
+    W = triangle_resize_weights(800, 128)                                                                   # the lego images at --img_wh 128
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=2e-6)
+    assert (W >= 0).all() and np.count_nonzero(W[64]) in (12, 13)                                            # radius 6.25 input pixels
+    np.testing.assert_allclose(W[10], W[117][::-1], atol=1e-7)                                              # mirror symmetry
+    W = triangle_resize_weights(4, 8)                                                                       # enlarging: plain bilinear, half-pixel centres
+    np.testing.assert_allclose(W[3, 1:3], [0.75, 0.25], atol=1e-7)
+    np.testing.assert_allclose(W[0, :2], [1.0, 0.0], atol=1e-7)
+    const = resize_antialiased(np.full((50, 37, 4), 0.3, np.float32), 11, 13)
+    np.testing.assert_allclose(const, 0.3, atol=1e-6)                                                       # partition of unity
+    img8 = rng.integers(0, 256, (100, 100, 4), dtype=np.uint8)
+    img8[..., 3] = 255                                   # opaque: PIL resizes RGBA with PREMULTIPLIED alpha, the reference channel by channel (below)
+    ours = resize_antialiased(img8.astype(np.float32) / 255, 16, 16)
+    pil = np.asarray(Image.fromarray(img8, "RGBA").resize((16, 16), resample=Image.BILINEAR), np.float32) / 255
+    assert np.abs(ours - pil).max() <= 1.01 / 255        # the same kernel; PIL rounds every output to 8 bits (rounds 1-4 used it)
+    assert np.abs(ours - pil).mean() < 0.3 / 255
+    # the reference resizes the FOUR channels independently and blends afterwards (image.py:22-31): at a silhouette the colour is mixed
+    # with the transparent pixels' black AND weighted by the resized alpha.  2 x 2 -> 1 x 1, left column opaque red, right column empty:
+    # rgb = (0.5, 0, 0), alpha = 0.5 -> over white (0.75, 0.5, 0.5), over black (0.25, 0, 0).  (A premultiplied-alpha resize, as PIL's,
+    # would give (1, 0.5, 0.5) / (0.5, 0, 0): rounds 1-4 differed from the reference along every silhouette.)
+    edge = np.zeros((2, 2, 4), np.uint8); edge[:, 0] = (255, 0, 0, 255)
+    p = str(tmp_path / "edge.png"); Image.fromarray(edge, "RGBA").save(p)
+    np.testing.assert_allclose(ImageLoader(1, 1, white_background=True)(p)[0, 0], [0.75, 0.5, 0.5, 0.5], atol=1e-6)
+    np.testing.assert_allclose(ImageLoader(1, 1, white_background=False)(p)[0, 0], [0.25, 0.0, 0.0, 0.5], atol=1e-6)
+    img8 = rng.integers(0, 256, (100, 100, 4), dtype=np.uint8)
+    ours = resize_antialiased(img8.astype(np.float32) / 255, 16, 16)
+    p = str(tmp_path / "r.png"); Image.fromarray(img8, "RGBA").save(p)
+    out = ImageLoader(16, 16, white_background=True)(p)
+    want = ours[..., 3:4] * ours[..., :3] + (1 - ours[..., 3:4])
+    np.testing.assert_allclose(out[..., :3], np.clip(want, 0, 1), atol=1e-6)
+    assert len(np.unique(np.round(out[..., 3] * 255, 3) % 1)) > 4                                           # not quantised to 1/255 any more
+
+
 def test_dataset_loader_json_and_shuffle_semantics(tmp_path):
     from keras_nerf_amd.data.loader import DatasetLoader
     from tests.synthetic_scene import write
