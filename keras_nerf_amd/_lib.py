@@ -73,19 +73,32 @@ class KnerfError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Load the HIP library; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise KnerfError(f"{LIB_PATH} is missing: run `python keras_nerf_amd/build.py` (hipcc, gfx950). "
+_by_path = {}
+
+
+def load_path(path: str) -> C.CDLL:
+    """A library of this ABI by path (bound once per path): the product library, or a build with further fused shapes
+    (build.py --add-shape / KNERF_AUTO_BUILD in runtime.py).  Raises (never falls back) when the file is missing."""
+    path = os.path.abspath(path)
+    lib = _by_path.get(path)
+    if lib is None:
+        if not os.path.exists(path):
+            raise KnerfError(f"{path} is missing: run `python keras_nerf_amd/build.py` (hipcc, gfx950). "
                              "keras_nerf_amd has no CPU path.")
         # torch first: its bundled HIP runtime must be the one already mapped when libknerf_hip.so resolves
         # libamdhip64, otherwise two runtimes coexist and the second one sees no device / foreign pointers
         import torch  # noqa: F401
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        _lib = lib
+        _by_path[path] = lib
+    return lib
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = load_path(LIB_PATH)
     return _lib

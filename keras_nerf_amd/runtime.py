@@ -2,6 +2,8 @@
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import os
 from typing import Optional
 
 import numpy as np
@@ -38,10 +40,12 @@ class KnerfContext:
 
     def __init__(self, n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4,
                  white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None,
-                 force_generic=None, options=None, encoded_widths=None):
+                 force_generic=None, options=None, encoded_widths=None, auto_build=None):
         """force_generic: run the default MLP shape through the general-shape kernels as well (tests).  options: {name: value}
         for knerf_set_option.  encoded_widths = (xyz_dim, dir_dim): a stand-alone NeRFMLP of those two input widths
-        (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
+        (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  auto_build (default: $KNERF_AUTO_BUILD): a
+        shape the fused kernels COULD cover but the loaded library does not hold is compiled for them on first use (hipcc, a few
+        minutes once per shape; the build is kept in keras_nerf_amd/build_auto_*/) instead of running on the general-shape kernels.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
         KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
         KNERF_SKIP_DEAD_TILES, KNERF_MERGE_CHUNK_RAYS into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
@@ -52,7 +56,6 @@ class KnerfContext:
         torch.cuda.set_device(self.device)
         if oob not in ("zero", "clamp"):
             raise ValueError("oob must be 'zero' or 'clamp'")
-        import os
         if force_generic is None:
             force_generic = bool(os.environ.get("KNERF_FORCE_GENERIC"))
         flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
@@ -69,19 +72,23 @@ class KnerfContext:
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
         self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
         if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
-            # a shape outside the library's list: say what it costs and, where the fused kernels could cover it, how to get them
-            import logging
+            # a shape outside the library's list: where the fused kernels could cover it, build them (opt-in) or say how; else say what it costs
             coverable = (dense_units in (64, 128, 256) and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
-                         and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8)
+                         and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8 and not (dense_units == 256 and pos_emb_xyz == 16 and pos_emb_dir >= 5))
             spec = f"{n_layers},{skip_layer},{dense_units}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
+            if auto_build is None:
+                auto_build = os.environ.get("KNERF_AUTO_BUILD", "") not in ("", "0")
+            if coverable and auto_build:
+                self._rebuild_for(spec)
+        if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
             # visible at the default log level when there is something the user can do about it, once per shape
             say = logging.info
             if coverable and spec not in _GENERIC_SHAPES_WARNED:
                 _GENERIC_SHAPES_WARNED.add(spec)
                 say = logging.warning
-            say("NeRFMLP(n_layers=%d, dense_units=%d, skip_layer=%d), pos_emb %d/%d runs on the general-shape kernels (about 3x slower per "
-                "FLOP than the fused chain)%s", n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir,
-                f"; `python keras_nerf_amd/build.py --add-shape={spec}` builds the fused kernels for it" if coverable else "")
+            say("NeRFMLP(n_layers=%d, dense_units=%d, skip_layer=%d), pos_emb %d/%d runs on the general-shape kernels (about 2x slower "
+                "than the fused chain)%s", n_layers, dense_units, skip_layer, pos_emb_xyz, pos_emb_dir,
+                f"; `python keras_nerf_amd/build.py --add-shape={spec}` builds the fused kernels for it (KNERF_AUTO_BUILD=1 does that on first use)" if coverable else "")
         opts = {}
         env = os.environ
         for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),
@@ -102,6 +109,32 @@ class KnerfContext:
                     self.set_option(k, v)
                 except ValueError:           # the context has fewer jobs than n_layers + 1 (general-shape path)
                     break
+
+    def _rebuild_for(self, spec: str):
+        """KNERF_AUTO_BUILD: compile the fused kernels for this shape into their own library (build.py --variant=auto_<shape>
+        --add-shape=<shape>; kept on disk, so the next process finds it built), load it beside the product library and re-create
+        the context on it.  One process builds at a time (several ranks start together): a file lock around the build."""
+        import fcntl
+        from . import build as B
+        variant = "auto_" + spec.replace(",", "_")
+        lock_path = os.path.join(os.path.dirname(os.path.abspath(B.__file__)), f".build_{variant}.lock")
+        logging.warning("KNERF_AUTO_BUILD: building the fused kernels for shape %s (hipcc, a few minutes the first time)", spec)
+        with open(lock_path, "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                path = B.build(verbose=False, variant=variant, add_shapes=[spec])
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+        self.lib.knerf_destroy(self._ctx)
+        self._ctx = C.c_void_p()
+        self.lib = _lib.load_path(path)
+        rc = self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
+        if rc != 0:
+            msg = self.lib.knerf_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise KnerfError(f"KNERF_AUTO_BUILD: {path} refused the context: {msg}")
+        if self.get_option("general_shape_path"):
+            raise KnerfError(f"KNERF_AUTO_BUILD: {path} does not hold shape {spec}")
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -142,3 +142,13 @@ def test_general_shape_layer_program_matches_the_keras_layer_list():
                 cat = li % sk == 0 and li > 0
                 assert out_ld == r32(u) + (r32(xyz) if cat else 0) + (r32(dr) if li == nl - 1 else 0), name
         assert off == lib.knerf_param_count_for(C.byref(cfg))
+
+
+def test_load_path_binds_one_library_per_path_and_refuses_a_missing_one(tmp_path):
+    """_lib.load_path: the product library and builds with further fused shapes (runtime.py KNERF_AUTO_BUILD) live side by side in one
+    process, each bound once; a missing file is an error, never a detour"""
+    from keras_nerf_amd import _lib
+    a, b = _lib.load_path(_lib.LIB_PATH), _lib.load_path(_lib.LIB_PATH)
+    assert a is b and a is _lib.load()
+    with pytest.raises(_lib.KnerfError, match="is missing"):
+        _lib.load_path(str(tmp_path / "libknerf_hip_nowhere.so"))

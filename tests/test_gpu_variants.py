@@ -67,3 +67,61 @@ def test_build_time_extra_shapes_run_on_the_fused_kernels():
         ctx = KnerfContext(white_background=True, **kw)
         assert ctx.get_option("general_shape_path") == 1.0
         ctx.close()
+
+
+AUTO_SHAPE = (6, 2, 128)      # coverable by the fused kernels, not in the built-in list; prebuilt as libknerf_hip_auto_6_2_128.so (build() of __graft_entry__)
+
+
+def test_auto_build_puts_a_coverable_shape_on_the_fused_kernels_beside_the_product_library():
+    """KNERF_AUTO_BUILD / KnerfContext(auto_build=True) (runtime.py): a shape the fused kernels could cover but the loaded library
+    does not hold is compiled for them on first use (here: found built -- the variant travels with the tree, as the two above) and
+    the context is re-created on THAT library, next to the product library in the same process: the shape leaves the general-shape
+    kernels, its gradients meet the oracle at the built-in shapes' tolerance and the general-shape kernels' at theirs, and a
+    default-shape context on the product library gives the same bits before and after."""
+    import numpy as np
+    import torch
+    from oracle import nerf_oracle as O
+    from keras_nerf_amd import _lib
+    from keras_nerf_amd.runtime import KnerfContext
+    from tests.problem import make_problem
+    from tests.test_gpu_train import flat, per_tensor_err
+    nl, sk, units = AUTO_SHAPE
+    cfg = O.NerfConfig(n_layers=nl, dense_units=units, skip_layer=sk)
+    P = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05, cfg=cfg)
+    o, d, t, u, img = flat(P)
+    Pd = make_problem(n_images=1, wh=16, weight_scale=1.5, bias_std=0.05)
+
+    def default_shape_grads():
+        ctx = KnerfContext(white_background=True, options=dict(deterministic=1))
+        assert ctx.lib is _lib.load()
+        ctx.set_weights(0, O.flatten_params(Pd["cp"])); ctx.set_weights(1, O.flatten_params(Pd["fp"]))
+        loss = torch.zeros(2, device="cuda")
+        ctx.train_chunk(*flat(Pd)[:3], flat(Pd)[4], flat(Pd)[3], inv_chunks=1.0, loss=loss)
+        torch.cuda.synchronize()
+        g = ctx.grads_view().clone(); ctx.close()
+        return g
+
+    before = default_shape_grads()
+    res = {}
+    for auto in (False, True):
+        ctx = KnerfContext(n_layers=nl, dense_units=units, skip_layer=sk, white_background=True, auto_build=auto)
+        assert ctx.get_option("general_shape_path") == (0.0 if auto else 1.0)
+        assert (ctx.lib is _lib.load()) == (not auto)
+        ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
+        loss = torch.zeros(2, device="cuda")
+        ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss)
+        torch.cuda.synchronize()
+        res[auto] = (ctx.grads_view().cpu().numpy().copy(), loss.cpu().numpy().copy())
+        if auto:
+            ctx.apply_adam(); ctx.poll_nonfinite(wait=True)                  # the optimizer and the weight repack of that library too
+            assert np.isfinite(ctx.get_weights(0)).all()
+        ctx.close()
+    n = res[True][0].size // 2
+    rc, lc, gc = O.chunk_loss_and_grads(P["cp"], o, d, t, img, cfg, True, emulate_bf16=O.FUSED)
+    assert per_tensor_err(res[True][0][:n], O.flatten_params(gc), cfg)[0] < 2e-2
+    assert abs(float(res[True][1][0]) - float(lc)) < 2e-3
+    # (coarse net only: the fine net's sample positions follow each implementation's own coarse weights)
+    assert per_tensor_err(res[True][0][:n], res[False][0][:n], cfg)[0] < 4e-2
+    assert np.abs(res[True][1] - res[False][1]).max() < 2e-3
+    after = default_shape_grads()
+    assert torch.equal(before.view(torch.int32), after.view(torch.int32))
