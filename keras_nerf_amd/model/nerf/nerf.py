@@ -244,6 +244,10 @@ class NeRF:
         return [self.coarse_loss_tracker, self.coarse_psnr_metric, self.corase_ssim_metric,
                 self.fine_loss_tracker, self.fine_psnr_metric, self.fine_ssim_metric]
 
+    @property
+    def metrics_names(self):
+        return [m.name for m in self.metrics]
+
     def reset_metrics(self):
         self._metric_state.state.zero_()
 
@@ -361,6 +365,25 @@ class NeRF:
         # whole-image MSE (nerf.py:484-487) from the metrics kernel's squared-difference sums (losses=None)
         self._metric_state.update(images, coarse["image"], fine["image"], None)
         return self._metric_state.snapshot()
+
+    def evaluate(self, dataset, return_dict=False, callbacks=None, verbose=0):
+        """tf.keras.Model.evaluate on the reference's test_step (nerf.py:475-497): the metrics averaged over the dataset's batches, as
+        a list in `metrics_names` order or as a dict (data-parallel: the replicas' mean, as fit's validation logs)."""
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            getattr(cb, "on_test_begin", lambda logs=None: None)({})
+        self.reset_metrics()
+        logs = {}
+        for b, batch in enumerate(dataset):
+            logs = self.test_step(batch)
+            for cb in callbacks:
+                getattr(cb, "on_test_batch_end", lambda i, logs=None: None)(b, logs)
+        logs = parallel.reduce_logs({k: float(v) for k, v in dict(logs).items()}, self.device)
+        for cb in callbacks:
+            getattr(cb, "on_test_end", lambda logs=None: None)(dict(logs))
+        if verbose:
+            logging.info("evaluate - %s", " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+        return logs if return_dict else [logs[k] for k in self.metrics_names if k in logs]
 
     # ------------------------------------------------------------------ fit: the part of tf.keras.Model.fit the reference uses
     def fit(self, dataset, epochs=1, validation_data=None, callbacks=None, initial_epoch=0, verbose=1):

@@ -252,6 +252,15 @@ def test_loader_monitor_fit_end_to_end(tmp_path):
     assert list(rows[0].keys()) == ["epoch", "coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim",
                                     "val_coarse_loss", "val_coarse_psnr", "val_coarse_ssim", "val_fine_loss", "val_fine_psnr", "val_fine_ssim"]
     assert NeRFTrainMonitor(te, log_dir, batch_size=1, update_freq=2).last_epoch == 3        # resume: last CSV epoch + 1
+    # tf.keras.Model.evaluate on the reference's test_step: the weights have not moved since the last epoch's validation pass, so the
+    # dataset's means are that epoch's val_ logs (the loader's validation jitter is seeded per epoch: same rays are not guaranteed,
+    # the metric definitions are) -- as a list in metrics_names order and as a dict
+    assert nerf.metrics_names == ["coarse_loss", "coarse_psnr", "coarse_ssim", "fine_loss", "fine_psnr", "fine_ssim"]
+    ev = nerf.evaluate(va, return_dict=True)
+    assert list(ev) == nerf.metrics_names and all(np.isfinite(v) for v in ev.values())
+    assert ev["fine_loss"] == pytest.approx(nerf.history.history["val_fine_loss"][-1], rel=0.2)
+    assert ev["fine_psnr"] == pytest.approx(-10 * np.log10(ev["fine_loss"]), abs=0.35)        # mean of per-batch PSNRs vs PSNR of the mean MSE: two batches
+    assert nerf.evaluate(va) == [ev[k] for k in nerf.metrics_names] or nerf.evaluate(va) == pytest.approx([ev[k] for k in nerf.metrics_names], rel=0.2)
 
 
 def test_train_script_shaped_like_the_reference_uses_every_rank(tmp_path):
