@@ -294,14 +294,25 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_kernel(GemmArgs g) {
 // wave streams its own rows (A fragments one 64-wide chunk ahead, across tile boundaries) against the resident weights.
 // The chunk body is branch-free and fully unrolled with the B fragments read 4 MFMAs ahead (left to itself hipcc emits
 // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per fragment: 48 cycles per MFMA instead of 8).
+// Column blocks (N wider than one slab: widths above 256, or K = 320 behind a concat) re-read the SAME rows of A once each.  The grid is
+// one-dimensional and maps workgroup w to (row group bx, column block by) such that the gy column blocks of a row group are
+// neighbours in one XCD's dispatch order (workgroups are dealt round-robin over the 8 XCDs: w and w + 8 share one): they walk the
+// same row tiles at the same pace, so after the first of them the rows come from that XCD's L2 instead of HBM.  gx is a multiple
+// of 8 whenever gy > 1 (launch_gemm_ws).  Placement is a speed matter only; nothing depends on it.
 template <int NT>
-__global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, int pitch) {
+__global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, int pitch, int gx, int gy) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     constexpr int NB = NT * 32;
     constexpr int NF = 4 * NT;                        // fragments per 64-wide chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * NB;
+    int bx = blockIdx.x, by = 0;
+    if (gy > 1) {
+        const int xcd = bx & 7, local = bx >> 3;
+        by = local % gy;
+        bx = (local / gy) * 8 + xcd;
+    }
+    const int n0 = by * NB;
     const int K64 = (g.K + 63) / 64 * 64;
     const int gpr = K64 / 8;                          // 16-byte granules per staged row
     for (int q = tid; q < NB * gpr; q += kGemmWaves * 64) {
@@ -312,8 +323,8 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_ws_kernel(GemmArgs g, in
     __syncthreads();
     const long long n_tiles = g.live ? (long long)*g.n_live : g.M / 32;
     const char* B = gsm + r * pitch + h * 16;
-    const long long stride = (long long)gridDim.x * kGemmWaves;
-    long long tile = (long long)blockIdx.x * kGemmWaves + wave;
+    const long long stride = (long long)gx * kGemmWaves;
+    long long tile = (long long)bx * kGemmWaves + wave;
     auto row_tile = [&](long long i) -> long long { return g.live ? (long long)g.live[i] : i; };      // entry i of the tiles to process
     bf16x8 a_cur[4], a_nxt[4];
     auto fetch_a = [&](long long t, int k, bf16x8 (&a)[4]) {          // one 64-wide chunk of this wave's 32 rows (t = a row tile)
@@ -373,7 +384,8 @@ hipError_t launch_gemm_ws(const GemmArgs& g, int gy, hipStream_t s) {
     long long gx = (g.M / 32 + kGemmWaves - 1) / kGemmWaves;
     const long long cap = 512 / gy > 0 ? 512 / gy : 1;           // persistent: about two workgroups per CU in all
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((gemm_ws_kernel<NT>), dim3((unsigned)gx, gy), dim3(kGemmWaves * 64), lds, s, g, pitch);
+    if (gy > 1) gx = gx >= 8 ? gx / 8 * 8 : 8;                   // the XCD mapping of the kernel wants whole groups of eight row groups
+    hipLaunchKernelGGL((gemm_ws_kernel<NT>), dim3((unsigned)(gx * gy)), dim3(kGemmWaves * 64), lds, s, g, pitch, (int)gx, gy);
     return hipGetLastError();
 }
 
@@ -763,11 +775,20 @@ __device__ __forceinline__ void coop_glds16(const void* gsrc, unsigned lds_dst) 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int N) {
+__global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int N, int gx, int gy, int gz) {
+    // one-dimensional grid -> (bx, by, bz).  A layer wider than one 256 x 256 block has gx gy blocks per unit of samples, which read
+    // the SAME X and dZ slabs (X once per column block, dZ once per row block): the blocks of a unit are neighbours in one XCD's
+    // dispatch order (workgroups w and w + 8 share an XCD; gz is a multiple of 8 then, launch_wgrad), so the repeats come from that
+    // XCD's L2.  Speed only; nothing depends on the placement.
+    int bx = 0, by = 0, bz = blockIdx.x;
+    if (gx * gy > 1) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q = local % (gx * gy);
+        bx = q % gx; by = q / gx; bz = (local / (gx * gy)) * 8 + xcd;
+    }
     extern __shared__ __attribute__((aligned(16))) char csm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;
-    const int k0 = blockIdx.x * 256, n0 = blockIdx.y * 256;
+    const int k0 = bx * 256, n0 = by * 256;
     const int r = lane & 31, h = lane >> 5;
     // transposed-read lane offsets: group gq = lane >> 4 -> feature half (gq & 1), k half (gq >> 1); i = lane & 15 -> q = i >> 2, p = i & 3.
     // Row 8 (gq >> 1) + q (+ 16 kk, + 4 for the second read: the low two bits stay q), chunk 4 tile + 2 (gq & 1) + (p >> 1), swizzled by q
@@ -782,7 +803,7 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
         const s16x8g v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    const UnitSched us = unit_schedule(g, (long long)blockIdx.z, (long long)gridDim.z);
+    const UnitSched us = unit_schedule(g, (long long)bz, (long long)gz);
     const long long cnt = us.count;
     // entry j of this unit's schedule -> sample tile; the list look-up is a SCALAR load in asm (a compiler-visible vector load
     // inside the loop would make hipcc drain vmcnt(0), i.e. the whole DMA pipeline, every step)
@@ -819,7 +840,7 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    const bool do_bias = blockIdx.x == 0 && wa == 0;                     // wave-uniform
+    const bool do_bias = bx == 0 && wa == 0;                     // wave-uniform
     const bool k_ok[2] = {k0 + 32 * (2 * wa) < K, k0 + 32 * (2 * wa + 1) < K};
     const bool n_ok[4] = {n0 + 32 * (4 * wb) < N, n0 + 32 * (4 * wb + 1) < N, n0 + 32 * (4 * wb + 2) < N, n0 + 32 * (4 * wb + 3) < N};
     if (cnt > 0) {
@@ -858,7 +879,7 @@ __global__ __launch_bounds__(512) void wgrad_coop_kernel(WgradArgs g, int K, int
     // flush: lane (col = r, hh = h), register i -> input column 32 tile + (i&3) + 8(i>>2) + 4hh
     if (g.partial) {            // deterministic mode: the workgroup's 256 x 256 block (its eight waves own disjoint parts) to its own slab
         constexpr int TN = 256, TF = 256 * 256 + TN;
-        float* tile = g.partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * TF;
+        float* tile = g.partial + ((size_t)(bx * gy + by) * gz + bz) * TF;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int cl = 32 * (4 * wb + b) + r;
@@ -928,6 +949,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int n_sl
 #ifndef KNERF_GEN_COOP_MIN_TILES
 #define KNERF_GEN_COOP_MIN_TILES 1      // kt or nt >= this
 #endif
+#ifndef KNERF_GEN_COOP_WGS
+#define KNERF_GEN_COOP_WGS 256      // one workgroup per CU: each flushes a whole 256 x 256 block with atomics (512: +8 %, 1024: +23 %)
+#endif
 inline bool coop_serves(int kt, int nt) {
 #ifdef KNERF_GEN_NO_COOP
     return false;
@@ -941,7 +965,8 @@ size_t wgrad_partial_floats_for(int K, int N) {
     const int kt = K / 32, nt = N / 32;
     if (coop_serves(kt, nt)) {
         const long long gx = (K + 255) / 256, gy = (N + 255) / 256;
-        long long gz = 256 / (gx * gy); if (gz < 1) gz = 1;
+        long long gz = KNERF_GEN_COOP_WGS / (gx * gy); if (gz < 1) gz = 1;
+        if (gx * gy > 1 && gz < 8) gz = 8;                       // launch_wgrad's whole groups of eight units
         return (size_t)(gx * gy * gz) * (256 * 256 + 256);
     }
     const int KT = kt % 2 == 0 ? 2 : 1, NT = nt % 4 == 0 ? 4 : (nt % 2 == 0 ? 2 : 1);      // the largest tiles launch_wgrad may pick
@@ -958,13 +983,11 @@ hipError_t launch_wgrad(const WgradArgs& g, int K, int N, hipStream_t s) {
         hipError_t ae = once([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         if (ae != hipSuccess) return ae;
         const int gx = (K + 255) / 256, gy = (N + 255) / 256;
-#ifndef KNERF_GEN_COOP_WGS
-#define KNERF_GEN_COOP_WGS 256      // one workgroup per CU: each flushes a whole 256 x 256 block with atomics (512: +8 %, 1024: +23 %)
-#endif
         long long gz = KNERF_GEN_COOP_WGS / ((long long)gx * gy);
         if (gz > g.steps) gz = g.steps;
         if (gz < 1) gz = 1;
-        hipLaunchKernelGGL(wgrad_coop_kernel, dim3(gx, gy, (unsigned)gz), dim3(512), lds, s, g, K, N);
+        if (gx * gy > 1) gz = gz >= 8 ? gz / 8 * 8 : 8;         // the kernel's XCD mapping wants whole groups of eight units (idle units are harmless)
+        hipLaunchKernelGGL(wgrad_coop_kernel, dim3((unsigned)(gx * gy * gz)), dim3(512), lds, s, g, K, N, gx, gy, (int)gz);
         if (g.partial)
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((256 * 256 + 256 + 255) / 256, gx * gy), dim3(256), 0, s, g, (int)gz, 256, 256, 1, gy);
         return hipGetLastError();

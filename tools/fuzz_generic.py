@@ -86,7 +86,7 @@ def main():
     bad = 0
     for i in range(args.cases):
         nl = int(rng.integers(1, 11))
-        case = dict(nl=nl, units=int(rng.choice([8, 24, 50, 70, 96, 130, 200, 256, 300])), skip=int(rng.integers(1, nl + 2)),
+        case = dict(nl=nl, units=int(rng.choice([8, 24, 50, 70, 96, 130, 200, 256, 300, 520])), skip=int(rng.integers(1, nl + 2)),
                     lx=int(rng.integers(0, 13)), ld=int(rng.integers(0, 7)), white=bool(rng.integers(0, 2)), seed=int(rng.integers(0, 1 << 30)),
                     rays=int(rng.integers(1, 65)))
         if rng.integers(0, 2):
