@@ -132,9 +132,16 @@ def cpu_baseline(budget_s=70.0):
                                "(64 samples), forward + backward + Adam"}}
 
 
+def dist_on(world):
+    """N > 1 -- or the one-rank rehearsal of the N > 1 path (KNERF_DIST_SINGLE=1, keras_nerf_amd/parallel.py): every branch below
+    that holds a collective, times it or reports it is taken, over the real backend, on a one-GPU box"""
+    from keras_nerf_amd import parallel
+    return world > 1 or parallel.single_rank_rehearsal()
+
+
 def sync(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +151,7 @@ RANK_ELAPSED = []      # every rank's elapsed time of the last timed region, in 
 
 def max_over_ranks(elapsed, world):
     RANK_ELAPSED[:] = [elapsed]
-    if world > 1:          # all_reduce is the one collective both RCCL and gloo run on device tensors: rank r fills slot r, SUM
+    if dist_on(world):          # all_reduce is the one collective both RCCL and gloo run on device tensors: rank r fills slot r, SUM
         every = torch.zeros(world, device="cuda", dtype=torch.float64)
         every[torch.distributed.get_rank()] = elapsed
         torch.distributed.all_reduce(every)
@@ -155,8 +162,8 @@ def max_over_ranks(elapsed, world):
 
 def dist_fields(world, backend, steps):
     per = [e / steps * 1e3 for e in RANK_ELAPSED]
-    return {"rccl_ranks": torch.distributed.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
-            "dist_backend": backend if world > 1 else None,
+    return {"rccl_ranks": torch.distributed.get_world_size() if dist_on(world) and backend == "nccl" else (1 if world == 1 else 0),
+            "dist_backend": backend if dist_on(world) else None,
             "ms_per_step_rank_min": min(per), "ms_per_step_rank_max": max(per), "ms_per_step_by_rank": [round(v, 4) for v in per]}
 
 
@@ -308,20 +315,20 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     # ONE directory for all ranks (rank 0 makes it and writes the dataset, the others learn its name: every rank reads the same
     # transforms_*.json and derives the same shuffled order, data/loader.py)
     box = [tempfile.mkdtemp(prefix="knerf_fit_") if rank == 0 else None]
-    if world > 1:
+    if dist_on(world):
         torch.distributed.broadcast_object_list(box, src=0)
     root = box[0]
     if rank == 0:
         write_synthetic_dataset(os.path.join(root, "data"), wh)
-    if world > 1:
+    if dist_on(world):
         torch.distributed.barrier()
     # the GLOBAL batch, as train.py:84-93 passes it: every rank yields its slice of `batch` images
     train, val, test = DatasetLoader(os.path.join(root, "data"), white_background=True).load_dataset(batch * world, wh, wh, 2.0, 6.0, 64)
-    nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: own initial weights per rank; compile() mirrors rank 0's
+    nerf = NeRF(seed=100 + rank if dist_on(world) else 0)     # N > 1: own initial weights per rank; compile() mirrors rank 0's
     try:
         nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks, white_background=True)
     except Exception as e:                     # noqa: BLE001
-        if world > 1:
+        if dist_on(world):
             rank_fail("NeRF.compile (weight broadcast)", e)
         raise
     monitor = NeRFTrainMonitor(test, os.path.join(root, "log"), batch, update_freq=1, plots=False)
@@ -398,7 +405,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
                           "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
-    if world > 1:
+    if dist_on(world):
         torch.distributed.barrier()            # nobody is still reading when rank 0 removes the directory
     if rank == 0:
         import shutil
@@ -427,7 +434,7 @@ def replica_drift(nerf, world):
     bits = w.view(torch.int32).to(torch.int64)
     chk = (bits * (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 8191 + 1)).sum().reshape(1)
     hi, lo = chk.clone(), chk.clone()
-    if world > 1:
+    if dist_on(world):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
     return float(int(hi[0]) - int(lo[0])), int(chk[0])
@@ -487,9 +494,9 @@ def main():
                     "with MAX and MIN; `replica_drift` (must be 0.0) goes on the line.  Default: on for N > 1 (two one-word collectives, "
                     "outside every timed region), off for N = 1")
     args = ap.parse_args()
-    if args.check_replicas is None:
-        args.check_replicas = int(args.gpus > 1)
     from keras_nerf_amd import parallel
+    if args.check_replicas is None:
+        args.check_replicas = int(args.gpus > 1 or parallel.single_rank_rehearsal())
     # the same environment for self-spawned ranks and for ranks of an external launcher (MASTER_ADDR, dmabuf IPC; N > 1: RCCL's
     # warnings to one file per rank, printed by a rank that fails)
     parallel.dist_env(args.gpus)
@@ -511,10 +518,10 @@ def main():
     try:
         run(args, world, rank, device_index, backend)
     except Exception as e:                     # noqa: BLE001 -- N > 1: ANY rank that raises says who it is and ends the job (exit 3);
-        if world > 1:                          # its peers would otherwise meet it as "connection closed by peer" in their next collective
+        if dist_on(world):                          # its peers would otherwise meet it as "connection closed by peer" in their next collective
             rank_fail("the benchmark body", e)
         raise
-    if world > 1:
+    if dist_on(world):
         torch.distributed.destroy_process_group()
 
 
@@ -529,13 +536,13 @@ def run(args, world, rank, device_index, backend):
     if args.mode == "fit":
         RANK_ELAPSED[:] = [0.0]
         return bench_fit(args, world, rank, wh, batch, chunks, desc, backend)
-    nerf = NeRF(seed=100 + rank if world > 1 else 0)     # N > 1: every rank draws its OWN initial weights; compile() must mirror rank 0's
+    nerf = NeRF(seed=100 + rank if dist_on(world) else 0)     # N > 1: every rank draws its OWN initial weights; compile() must mirror rank 0's
     try:
         inject("compile")
         nerf.compile(optimizer="adam", loss="mse", batch_size=batch, image_height=wh, image_width=wh, ray_chunks=chunks,
                      white_background=True)
     except Exception as e:                     # noqa: BLE001 -- N > 1: the weight broadcast of compile() is the second collective
-        if world > 1:
+        if dist_on(world):
             rank_fail("NeRF.compile (weight broadcast)", e)
         raise
     if args.ignore_nonfinite:
@@ -554,11 +561,11 @@ def run(args, world, rank, device_index, backend):
             nerf.train_step(data, with_metrics=False)
         sync(world)
     except Exception as e:                     # noqa: BLE001 -- N > 1: the first gradient all-reduce (4.77 MB) runs in here
-        if world > 1:
+        if dist_on(world):
             rank_fail("the warm-up steps (first gradient all-reduce)", e)
         raise
     selftest = {}
-    if world > 1:
+    if dist_on(world):
         selftest = allreduce_selftest(nerf, world, backend)
         sync(world)
         nerf._allreduce_events = []            # HIP events on the compute stream around the gradient all-reduce of every timed step
@@ -572,14 +579,14 @@ def run(args, world, rank, device_index, backend):
     comm = {}
     if args.check_replicas:
         comm["replica_drift"], comm["weight_checksum"] = replica_drift(nerf, world)
-    if world > 1:
+    if dist_on(world):
         ev, nerf._allreduce_events = nerf._allreduce_events, None
         ms = [a.elapsed_time(b_) for a, b_ in ev]
         # from the moment this rank's last chunk has finished to the moment the reduced gradients are usable: the collective
         # itself plus the wait for the slowest rank
         comm.update({"allreduce_ms_per_step": sum(ms) / max(len(ms), 1), "allreduce_ms_per_step_max": max(ms) if ms else None,
                      "grad_bytes": int(nerf._ctx.grads_view().numel()) * 4})
-    if world > 1:          # every rank: its share of the device (ranks sharing a GPU in a rehearsal must all fit; wgrad_group follows free memory)
+    if dist_on(world):          # every rank: its share of the device (ranks sharing a GPU in a rehearsal must all fit; wgrad_group follows free memory)
         free_b, total_b = torch.cuda.mem_get_info()
         print(f"[bench rank {rank}/{world}] device memory free {free_b / 2**30:.1f} GiB of {total_b / 2**30:.1f} GiB; "
               f"wgrad_group {int(nerf._ctx.get_option('wgrad_group'))} (budget {nerf._ctx.get_option('wgrad_group_gb'):g} GB)", file=sys.stderr, flush=True)

@@ -16,8 +16,15 @@ import torch
 import torch.distributed as dist
 
 
+def single_rank_rehearsal() -> bool:
+    """KNERF_DIST_SINGLE=1: a ONE-rank process group counts as distributed -- every collective of the N > 1 path (weight broadcast,
+    gradient all-reduce, log means, barriers) really runs, over the real backend, on a box with one GPU.  RCCL refuses two ranks on
+    one device, so this is the only way its code path executes before an 8-GPU node does it for the first time (bench.py, tests)."""
+    return os.environ.get("KNERF_DIST_SINGLE", "") not in ("", "0")
+
+
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_rehearsal())
 
 
 def rank() -> int:
@@ -89,7 +96,7 @@ def dist_env(world: int = 1) -> None:
     world > 1: RCCL's warnings go to one file per rank (NCCL_DEBUG=WARN, NCCL_DEBUG_FILE), whose tail `rank_fail` prints."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
+    if world > 1 or single_rank_rehearsal():
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "knerf_rccl_%h_%p.log"))
 
@@ -151,8 +158,14 @@ def init_rank(backend: str = None, timeout_s: float = 300.0, tag: str = "knerf")
         torch.cuda.set_device(dev)
     elif backend == "nccl" and world > 1:
         raise SystemExit("no GPU visible: the nccl (RCCL) backend needs one per rank")
-    if world == 1 or (dist.is_available() and dist.is_initialized()):
+    if (world == 1 and not single_rank_rehearsal()) or (dist.is_available() and dist.is_initialized()):
         return rank_, world, dev
+    if world == 1 and "MASTER_PORT" not in os.environ:      # the one-rank rehearsal has no launcher that picked a port
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
     if dev is not None:      # which device every rank really sits on (a job that silently shares devices would still train)
         pr = torch.cuda.get_device_properties(dev)
         pci = ":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, k)) or "n/a"

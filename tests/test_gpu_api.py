@@ -497,6 +497,38 @@ def test_bench_line_of_the_references_own_command_line_and_of_small_chunks():
     assert head["vs_baseline"] is None and "baseline" not in head        # nothing is published for the headline configuration
 
 
+def test_one_rank_rccl_rehearsal_of_the_multi_gpu_bench_path():
+    """RCCL refuses two ranks on one device, so on a one-GPU box the N > 1 path can only meet the REAL backend with one rank:
+    KNERF_DIST_SINGLE=1 makes a one-rank process group count as distributed (keras_nerf_amd/parallel.py) -- init_process_group("nccl")
+    with a device id, the proving all-reduce, the weight broadcast of NeRF.compile, the 4.77 MB gradient all-reduce of every step on
+    the library-owned buffer, the stand-alone all-reduce self-test with HIP events, barriers, the per-rank time exchange, the
+    replica-drift check, RCCL's version and its per-rank warning file: everything the driver's first 8-GPU run will execute, minus
+    the peers.  Both bench bodies (step and fit)."""
+    import json
+    env = {"KNERF_DIST_SINGLE": "1", "KNERF_DIST_BACKEND": "nccl"}
+    r = _bench(["--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["dist_backend"] == "nccl" and line["rccl_ranks"] == 1
+    assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
+    assert line["grad_bytes"] == 2 * 595844 * 4 and 0 < line["allreduce_ms_per_step"] < 5
+    st = line["allreduce_us_standalone"]
+    assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] < 5000 and "hip events" in st["clock"]
+    assert line["rccl_version"] and line["allreduce_selftest_operand_stayed_zero"] is True and line["allreduce_busbw_GBps"] == 0.0
+    assert line["ms_per_step_by_rank"] == [pytest.approx(line["ms_per_step"], rel=1e-3)]
+    assert 0 < line["metrics_ms_per_step"] < 5
+    assert "[bench rank 0/1] local_rank 0 -> cuda:0" in r.stderr and "backend nccl" in r.stderr
+    # the same step without the group: the collectives of one rank change nothing in the arithmetic
+    plain = _bench(["--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline", "--check-replicas", "1"], {})
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    pl = json.loads([x for x in plain.stdout.splitlines() if x.startswith("{")][-1])
+    assert pl["dist_backend"] is None and pl["weight_checksum"] != 0
+    r = _bench(["--mode", "fit", "--config", "cfg4", "--epochs", "1"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    fit = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert fit["dist_backend"] == "nccl" and fit["value"] > 0
+
+
 def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     """cfg4 (BASELINE configs[3]: one 128 x 128 image per GPU, 8 GPUs) as far as a one-GPU box allows: THREE ranks share this device
     over gloo.  The pool kills a run in which more than six processes of one user have the GPU open: this test process, the launcher
