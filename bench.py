@@ -132,6 +132,28 @@ def cpu_baseline(budget_s=70.0):
                                "(64 samples), forward + backward + Adam"}}
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a five-line version banner with plain
+    printf when NCCL_DEBUG is set (found by the one-rank rehearsal, round 5), gloo its "[Gloo] Rank r is connected" lines -- so the
+    process's file descriptor 1 is pointed at stderr for the whole run and the line goes to a private copy of the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def dist_on(world):
     """N > 1 -- or the one-rank rehearsal of the N > 1 path (KNERF_DIST_SINGLE=1, keras_nerf_amd/parallel.py): every branch below
     that holds a collective, times it or reports it is taken, over the real backend, on a one-GPU box"""
@@ -230,12 +252,12 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                     "launches": cnt, "kernel_ms_per_frame": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
                     "frame_tflops": rs * FWD_FLOP / 1e12, "frame_frac_of_mfma_peak": rs * FWD_FLOP / 1e12 / MFMA_PEAK_TFLOPS,
                     "frame_executed_tflops": rs * FWD_FLOP_EXEC / 1e12}
-        print(json.dumps({"metric": "frames/sec (360-degree render 256^2, coarse64+fine128, forward only)", "value": fps,
+        emit(json.dumps({"metric": "frames/sec (360-degree render 256^2, coarse64+fine128, forward only)", "value": fps,
                           "unit": "frames/s", "n_gpus": world, "steps": n_frames, "warmup": args.warmup,
                           "ms_per_step": elapsed / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
                           "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}", "readback": "pinned double buffers on a side stream (tools/cfg5_readback_probe.py: A/B against blocking copies)"},
-                          "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}), flush=True)
+                          "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}))
 
 
 # per 32-sample tile, KiB (csrc/layout.h): saved activations (h0 is recomputed, not saved), dZ WRITTEN (the run has 130 blocks;
@@ -392,7 +414,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
     if args.check_replicas:
         drift["replica_drift"], drift["weight_checksum"] = replica_drift(nerf, world)
     if rank == 0:
-        print(json.dumps({**drift, "metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
+        emit(json.dumps({**drift, "metric": f"rays*samples/sec (NeRF.fit train loop with metrics, loader and monitor), {args.config}", "value": value,
                           "unit": "rays*samples/s", "n_gpus": world, "steps": steps * args.epochs, "warmup": steps, "ms_per_step": loop / (steps * args.epochs) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": f"{args.config} through NeRF.fit: {desc}; 100 procedural training views in nerf_synthetic layout, "
@@ -404,7 +426,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                           "fit_ms_per_step_with_skip_dead_tiles": skip_ms, "dead_tile_frac_that_epoch": dead_fit,
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
-                          "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}), flush=True)
+                          "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}))
     if dist_on(world):
         torch.distributed.barrier()            # nobody is still reading when rank 0 removes the directory
     if rank == 0:
@@ -509,6 +531,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: keras_nerf_amd.parallel.launch re-runs this script as N rank processes
         # (children started before this process touches the GPU, never an exec), waits, and exits with their code
         parallel.launch(None, args.gpus, backend=backend)
+    own_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py either plainly (it spawns its own ranks) or "
@@ -703,7 +726,7 @@ def run(args, world, rank, device_index, backend):
             "metrics_ms_per_step": metrics_ms, "metrics_clock": "hip events around the 3 metric launches, mean of 5 steps",
             "options": opts, "dead_tile_frac": dead_frac, **comm, **selftest,
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -510,10 +510,13 @@ def test_one_rank_rccl_rehearsal_of_the_multi_gpu_bench_path():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["dist_backend"] == "nccl" and line["rccl_ranks"] == 1
+    # the contract's ONE JSON line: RCCL prints a version banner on file descriptor 1 when NCCL_DEBUG is set (this rehearsal found it);
+    # bench.py keeps the real stdout for its line and points fd 1 at stderr
+    assert r.stdout.strip() == [x for x in r.stdout.splitlines() if x.startswith("{")][-1] and "RCCL version" in r.stderr
     assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
     assert line["grad_bytes"] == 2 * 595844 * 4 and 0 < line["allreduce_ms_per_step"] < 5
     st = line["allreduce_us_standalone"]
-    assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] < 5000 and "hip events" in st["clock"]
+    assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] and st["median"] < 5000 and "hip events" in st["clock"]      # (the max has been 40 ms once: a one-off, which is why the line carries min / median / max)
     assert line["rccl_version"] and line["allreduce_selftest_operand_stayed_zero"] is True and line["allreduce_busbw_GBps"] == 0.0
     assert line["ms_per_step_by_rank"] == [pytest.approx(line["ms_per_step"], rel=1e-3)]
     assert 0 < line["metrics_ms_per_step"] < 5
@@ -542,6 +545,7 @@ def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["dist_backend"] == "gloo" and line["config"]["parallelism"] == "dp3" and line["config"]["global_batch_images"] == 3
+    assert r.stdout.strip().count("\n") == 0                 # one line on stdout: gloo's "[Gloo] Rank ..." chatter went to stderr
     assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
     assert line["grad_bytes"] == 2 * 595844 * 4 and line["allreduce_ms_per_step"] > 0
     assert line["value"] > 0 and line["scaling"] == "weak" and line["rccl_ranks"] == 0
