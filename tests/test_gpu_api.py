@@ -530,6 +530,20 @@ def test_one_rank_rccl_rehearsal_of_the_multi_gpu_bench_path():
     assert r.returncode == 0, r.stderr[-3000:]
     fit = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert fit["dist_backend"] == "nccl" and fit["value"] > 0
+    # ... and under the launcher the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    # 127.0.0.1 --master-port P bench.py --gpus N ...`), with N = 1: the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)
+    # instead of the script's own, its stdout passed through: still exactly one line
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "cfg4",
+                        "--no-cpu-baseline", "--no-profile"], capture_output=True, text=True, timeout=300, env=dict(base, **env))
+    assert t.returncode == 0, t.stderr[-3000:]
+    assert t.stdout.strip().count("\n") == 0, t.stdout[:2000]
+    tl = json.loads(t.stdout)
+    assert tl["dist_backend"] == "nccl" and tl["rccl_ranks"] == 1 and tl["replica_drift"] == 0.0 and tl["allreduce_ms_per_step"] > 0
 
 
 def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
