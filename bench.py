@@ -199,6 +199,9 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
     nerf = NeRF(seed=0)
     nerf.compile(optimizer="adam", loss="mse", batch_size=1, image_height=wh, image_width=wh, ray_chunks=chunks,
                  white_background=True, is_training=False)
+    # rays per set of launches: the largest whole number of chunks of a frame within the library's limit (knerf.h "merge_render_rays")
+    lim, n_chunks = int(nerf._ctx.get_option("merge_render_rays")), wh * wh // chunks
+    launch_rays = chunks * max([m for m in range(1, n_chunks + 1) if n_chunks % m == 0 and m * chunks <= lim] or [1])
     rg = RaysGenerator(get_focal_from_fov(0.6911112070083618, wh), wh, wh, 2.0, 6.0, nerf.n_coarse, seed=rank)
     n_frames = args.steps
     poses = [pose_spherical(360.0 * i / max(n_frames, 1), -30.0, 4.0) for i in range(n_frames + args.warmup)]
@@ -256,7 +259,8 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                           "unit": "frames/s", "n_gpus": world, "steps": n_frames, "warmup": args.warmup,
                           "ms_per_step": elapsed / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
-                          "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}", "readback": "pinned double buffers on a side stream (tools/cfg5_readback_probe.py: A/B against blocking copies)"},
+                          "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}",
+                                     "launch_rays": launch_rays, "launch_note": "consecutive chunks of a frame share launches (option merge_render_rays; per-ray work only: outputs bit-identical for every value)", "readback": "pinned double buffers on a side stream (tools/cfg5_readback_probe.py: A/B against blocking copies)"},
                           "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}))
 
 

@@ -140,7 +140,10 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *   "grad_diagnostics"  0/1  (default 0) knerf_train_batch counts the non-zero entries of the last chunk's gradient of each net
  *                            (knerf_grad_diagnostics; the reference does this when run_eagerly, nerf.py:430-451); one launch of the
  *                            coarse weight-gradient kernel per chunk while it is on.
- *   "merge_chunk_rays"  0..1048576 (default 4096) knerf_train_batch / knerf_render_batch run m consecutive chunks as one set of launches,
+ *   "merge_render_rays" 0..1048576 (default 65536) the same for knerf_render_batch on the fused kernels (rendering keeps no saved
+ *                            tensors: 5 KB of workspace per ray; outputs bit-identical for every value); the general-shape kernels
+ *                            render under "merge_chunk_rays".
+ *   "merge_chunk_rays"  0..1048576 (default 4096) knerf_train_batch runs m consecutive chunks as one set of launches,
  *                            m the largest divisor of the chunk count with m * ray_chunks <= this value (0: every chunk its own
  *                            launches).  `ray_chunks` is the reference's memory knob (nerf.py:100, 332-473): every ray's forward, loss
  *                            term and gradient contribution is independent of the chunk that holds it (mean over R rays times 1 / C

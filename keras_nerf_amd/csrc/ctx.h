@@ -91,7 +91,8 @@ struct knerf_ctx {
     bool skip_dead = true;              // dgrad / wgrad skip 32-sample tiles whose dL/d(rgb, sigma) is exactly zero (exact; +0.3 % when nothing is dead)
     int wgrad_group_max = 4;            // chunks per coarse weight-gradient launch of knerf_train_batch (1 = one launch per chunk)
     double wgrad_group_gb = 40.0;       // memory budget of those grouped workspaces
-    int merge_rays = 4096;              // knerf_train_batch / knerf_render_batch: consecutive chunks share launches of up to this many rays (0: off)
+    int merge_rays = 4096;              // knerf_train_batch: consecutive chunks share launches of up to this many rays (0: off)
+    int merge_render_rays = 65536;      // knerf_render_batch on the fused path (no saved tensors: 5 KB of workspace per ray); general-shape path: merge_rays
     int wgrad_cost[17] = {};            // workgroups per job ~ cost (build_wgrad_plan); filled from the job kinds at creation
     bool grad_diag = false;             // zero-gradient diagnostics of the last chunk (nerf.py:430-451; NeRF.compile(run_eagerly=True))
     float* diag_tmp = nullptr;          // the earlier chunks' accumulated gradient while the last chunk runs alone

@@ -427,10 +427,10 @@ int wgrad_group_for(knerf_ctx* ctx, int n_rays, int n_chunks) {
 // launches: rendered outputs bit-identical, accumulated gradients equal up to the order of fp32 sums.  On this device a 4,096-ray
 // launch needs 8 GB of workspace; launches of 256 / 512 / 1,024 rays (the reference's train.py defaults to 1,024) fill 256 CUs
 // badly: 23.7 / 18.0 / 14.3 ms per 128 x 128 image against 13.7.  m divides the chunk count (equal-sized launches).
-int merge_factor(const knerf_ctx* ctx, int ray_chunks, int n_chunks) {
-    if (ctx->merge_rays <= 0 || n_chunks <= 1) return 1;
+int merge_factor(int limit_rays, int ray_chunks, int n_chunks) {
+    if (limit_rays <= 0 || n_chunks <= 1) return 1;
     for (int m = n_chunks; m > 1; --m)
-        if (n_chunks % m == 0 && (long long)m * ray_chunks <= ctx->merge_rays) return m;
+        if (n_chunks % m == 0 && (long long)m * ray_chunks <= limit_rays) return m;
     return 1;
 }
 
@@ -695,7 +695,10 @@ int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "render_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
     const size_t Nc = (size_t)ctx->cfg.n_coarse, Nf = (size_t)ctx->cfg.n_fine, Na = Nc + Nf;
-    ray_chunks *= merge_factor(ctx, ray_chunks, n_rays / ray_chunks);        // per-ray work only: bit-identical outputs
+    // per-ray work only: bit-identical outputs.  Rendering keeps no saved tensors (5 KB of workspace per ray on the fused path), so its
+    // launches may be far larger than a training step's: 65,536 rays by default ("merge_render_rays"; a 256 x 256 frame in ONE set
+    // of launches is 4 % faster than in sixteen); the general-shape path's activations stay in memory, it keeps the training limit
+    ray_chunks *= merge_factor(ctx->generic ? ctx->merge_rays : ctx->merge_render_rays, ray_chunks, n_rays / ray_chunks);
     for (int i = 0; i < n_rays / ray_chunks; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
         if (int r = knerf_render_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, u ? u + r0 * Nf : nullptr, seed, (uint64_t)r0,
@@ -732,7 +735,7 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     if (ctx->plan_dirty) { if (int r = upload_plan(ctx)) return r; }
     ctx->tile_counter_next = 0;
     // zero-gradient diagnostics count the LAST chunk's gradient (nerf.py:430-451): that chunk's launches must be its own
-    int merge = ctx->grad_diag ? 1 : merge_factor(ctx, ray_chunks, n_rays / ray_chunks);
+    int merge = ctx->grad_diag ? 1 : merge_factor(ctx->merge_rays, ray_chunks, n_rays / ray_chunks);
     const int user_chunks = ray_chunks;
     int C = 0, G = 1;
     for (;;) {
@@ -847,6 +850,9 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
     } else if (n == "merge_chunk_rays") {
         if (value < 0 || value > 1048576) return fail(ctx, KNERF_ERR_INVALID, "merge_chunk_rays: 0..1048576");
         ctx->merge_rays = (int)value;
+    } else if (n == "merge_render_rays") {
+        if (value < 0 || value > 1048576) return fail(ctx, KNERF_ERR_INVALID, "merge_render_rays: 0..1048576");
+        ctx->merge_render_rays = (int)value;
     } else if (n == "wgrad_group_max") {
         if (value < 1 || value > 64) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_max: 1..64");
         ctx->wgrad_group_max = (int)value; ctx->group_cache = 0;
@@ -871,6 +877,7 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     else if (n == "skip_dead_tiles_active") *value = skipping(ctx);
     else if (n == "wgrad_group_max") *value = ctx->wgrad_group_max;
     else if (n == "merge_chunk_rays") *value = ctx->merge_rays;
+    else if (n == "merge_render_rays") *value = ctx->merge_render_rays;
     else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
     else if (n == "wgrad_group") *value = ctx->ws_train ? ctx->ws_group : 0;            // chunks per coarse wgrad launch of the current workspaces
     else if (n == "general_shape_path") *value = ctx->generic;

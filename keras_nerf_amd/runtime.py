@@ -47,7 +47,7 @@ class KnerfContext:
         shape the fused kernels COULD cover but the loaded library does not hold is compiled for them on first use (hipcc, a few
         minutes once per shape; the build is kept in keras_nerf_amd/build_auto_*/) instead of running on the general-shape kernels.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
         KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
-        KNERF_SKIP_DEAD_TILES, KNERF_MERGE_CHUNK_RAYS into the config flag / options below (explicit arguments win)."""
+        KNERF_SKIP_DEAD_TILES, KNERF_MERGE_CHUNK_RAYS, KNERF_MERGE_RENDER_RAYS into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
         if not torch.cuda.is_available():
             raise KnerfError("keras_nerf_amd needs an MI355X (gfx950) GPU; there is no CPU path")
@@ -93,7 +93,7 @@ class KnerfContext:
         env = os.environ
         for key, name in (("KNERF_WGRAD_GROUP_MAX", "wgrad_group_max"), ("KNERF_WGRAD_GROUP_GB", "wgrad_group_gb"),
                           ("KNERF_DETERMINISTIC", "deterministic"), ("KNERF_SKIP_DEAD_TILES", "skip_dead_tiles"),
-                          ("KNERF_MERGE_CHUNK_RAYS", "merge_chunk_rays")):
+                          ("KNERF_MERGE_CHUNK_RAYS", "merge_chunk_rays"), ("KNERF_MERGE_RENDER_RAYS", "merge_render_rays")):
             if env.get(key) not in (None, ""):
                 opts[name] = float(env[key])
         env_costs = {}

@@ -27,7 +27,7 @@ def _data(P, n):
 def test_default_is_4096_rays_and_the_option_round_trips():
     P = make_problem(n_images=1, wh=16)
     ctx = _ctx(P)
-    assert ctx.get_option("merge_chunk_rays") == 4096.0
+    assert ctx.get_option("merge_chunk_rays") == 4096.0 and ctx.get_option("merge_render_rays") == 65536.0
     ctx.set_option("merge_chunk_rays", 0)
     assert ctx.get_option("merge_chunk_rays") == 0.0
     with pytest.raises(ValueError):
@@ -41,8 +41,9 @@ def test_rendered_outputs_do_not_depend_on_the_merge(given_u):
     P = make_problem(n_images=3, wh=16, weight_scale=1.5, bias_std=0.05)
     o, d, t, _, u = _data(P, 768)
     outs = []
-    for merge in (0, 4096, 256):
-        ctx = _ctx(P, merge_chunk_rays=merge)
+    for merge in (0, 65536, 256):                   # every chunk its own launches / the default (here: all twelve chunks at once) / four chunks per launch
+        ctx = _ctx(P, merge_render_rays=merge)
+        assert ctx.get_option("merge_render_rays") == merge
         outs.append(ctx.render_batch(o, d, t, u if given_u else None, seed=11, ray_chunks=64))
         torch.cuda.synchronize()
         ctx.close()
