@@ -286,6 +286,8 @@ def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
         raise ValueError("nprocs must be >= 1")
     if n == 1:
         dist_env(1)
+        if single_rank_rehearsal():                # KNERF_DIST_SINGLE: this process IS the one rank of a real process group
+            init_rank(backend)
         if fn is not None:
             fn(*args)
         return 0

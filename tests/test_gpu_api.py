@@ -292,6 +292,28 @@ def test_train_script_shaped_like_the_reference_uses_every_rank(tmp_path):
     assert "test_0_1.png" in os.listdir(tmp_path / "logs" / "scene")
 
 
+def test_train_script_as_the_one_rank_of_a_real_rccl_group(tmp_path):
+    """the same script with KNERF_DIST_SINGLE=1 over the nccl backend: `parallel.MirroredStrategy(devices=1)` joins a one-rank RCCL
+    group in-process, so NeRF.compile's broadcast, every step's gradient all-reduce, the log means, the monitor's barriers around
+    rank 0's writing and the final barrier all run on RCCL (what a one-GPU box can show of train.py:75-157 on the real backend)"""
+    import csv
+    import json
+    import subprocess
+    import sys
+    from tests.synthetic_scene import write
+    root = write(str(tmp_path / "scene"), n=(4, 2, 2), wh=20)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_like_reference.py"), "--data_dir", root,
+                        "--log_dir", str(tmp_path / "logs"), "--model_dirs", str(tmp_path / "model"), "--devices", "1", "--num_epochs", "2"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, KNERF_DIST_BACKEND="nccl", KNERF_DIST_SINGLE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "backend nccl" in r.stderr and r.stdout.count("Number of devices: 1") == 1
+    a = json.load(open(tmp_path / "logs" / "rank0.json"))
+    assert a["world"] == 1 and a["weight_checksum"] != 0 and a["steps_per_epoch"] == 4 and len(a["history"]["fine_loss"]) == 2
+    assert [x["epoch"] for x in csv.DictReader(open(tmp_path / "logs" / "scene" / "log.csv"))] == ["0", "1"]
+    assert sorted(os.listdir(tmp_path / "model" / "scene")) == ["coarse.h5", "fine.h5", "model_config.json"]
+
+
 def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     """train.py:75-157 semantics with two processes on this GPU (gloo; tests/dp_gpu_worker.py): both ranks start from rank
     0's weights, SUM their accumulated gradients and end with identical weights that equal a single-process step on the
