@@ -580,6 +580,8 @@ def run(args, world, rank, device_index, backend):
         nerf._ctx.set_option("deterministic", args.deterministic)
     data = make_batch(nerf, wh, batch, rank)
     n_rays = batch * wh * wh
+    lim, n_chunks = int(nerf._ctx.get_option("merge_chunk_rays")), n_rays // chunks
+    launch_rays = chunks * max([m for m in range(1, n_chunks + 1) if n_chunks % m == 0 and m * chunks <= lim] or [1])
     samples_per_ray = nerf.n_coarse + (nerf.n_coarse + nerf.n_fine)          # 64 + 192 = 256 MLP evaluations per ray
 
     try:
@@ -725,6 +727,7 @@ def run(args, world, rank, device_index, backend):
             **({"baseline": baseline_note} if baseline_note else {}),
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {desc}", "rays_per_step_per_gpu": n_rays, "samples_per_ray": samples_per_ray,
+                       "ray_chunks": chunks, "launch_rays": launch_rays,      # consecutive chunks share launches up to merge_chunk_rays (knerf.h)
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
             "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
             "metrics_ms_per_step": metrics_ms, "metrics_clock": "hip events around the 3 metric launches, mean of 5 steps",

@@ -513,6 +513,7 @@ def test_bench_line_of_the_references_own_command_line_and_of_small_chunks():
     assert r.returncode == 0, r.stderr[-3000:]
     small = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert "ray_chunks overridden: 256" in small["config"]["workload"] and small["roofline"]["launches"] == 2 * 4
+    assert small["config"]["ray_chunks"] == 256 and small["config"]["launch_rays"] == 4096 and line["config"]["launch_rays"] == 4096
     r = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile"], {})
     assert r.returncode == 0, r.stderr[-3000:]
     head = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
