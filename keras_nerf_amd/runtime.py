@@ -29,6 +29,36 @@ def _f32(x, device) -> torch.Tensor:
 
 _GENERIC_SHAPES_WARNED = set()      # shapes already reported as "coverable by build.py --add-shape" (one warning each per process)
 
+FUSED_WIDTHS = (64, 128, 256)       # csrc/layout.h: the trunk widths the fused kernels are written for
+
+
+def padded_width(dense_units: int):
+    """the fused width a narrower (even) dense_units is run at, or None: 50 -> 64, 96 -> 128, 192 -> 256"""
+    if dense_units in FUSED_WIDTHS or dense_units > FUSED_WIDTHS[-1] or dense_units < 2 or dense_units % 2:
+        return None
+    return next(w for w in FUSED_WIDTHS if w >= dense_units)
+
+
+def width_pad_index(n_layers: int, units: int, padded: int, skip_layer: int, xyz_dim: int, dir_dim: int) -> np.ndarray:
+    """int64 [n_params(units)]: where parameter i of the REAL network (flat Keras order, mlp.py:11-27) sits in the flat parameters
+    of the same network at width `padded`.  A kernel's h rows / h columns keep their index; the rows behind them ([h ; xyz_enc] of a
+    concat layer, [features ; dir_enc] of rgb_features) move behind the padded h block."""
+    from .model.nerf.mlp import layer_shapes
+    real = layer_shapes(n_layers, units, skip_layer, xyz_dim, dir_dim)
+    pad = layer_shapes(n_layers, padded, skip_layer, xyz_dim, dir_dim)
+    idx, off = [], 0
+    for (name, fi, fo), (_, fip, fop) in zip(real, pad):
+        h_rows = {"layer_0": 0, "rgb": units // 2}.get(name, units)                 # leading rows that are h features of width `units`
+        h_rows_p = {"layer_0": 0, "rgb": padded // 2}.get(name, padded)
+        rows = np.arange(fi)
+        rows_p = np.where(rows < h_rows, rows, rows - h_rows + h_rows_p)
+        idx.append((off + rows_p[:, None] * fop + np.arange(fo)[None, :]).reshape(-1))
+        off += fip * fop
+        idx.append(off + np.arange(fo))
+        off += fop
+    return np.concatenate(idx).astype(np.int64)
+
+
 
 class _CudaView:
     def __init__(self, ptr: int, n: int, typestr: str):
@@ -40,12 +70,17 @@ class KnerfContext:
 
     def __init__(self, n_coarse=64, n_fine=128, pos_emb_xyz=10, pos_emb_dir=4, n_layers=8, dense_units=256, skip_layer=4,
                  white_background=False, oob="zero", lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, device=None,
-                 force_generic=None, options=None, encoded_widths=None, auto_build=None):
+                 force_generic=None, options=None, encoded_widths=None, auto_build=None, pad_width=None):
         """force_generic: run the default MLP shape through the general-shape kernels as well (tests).  options: {name: value}
         for knerf_set_option.  encoded_widths = (xyz_dim, dir_dim): a stand-alone NeRFMLP of those two input widths
         (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  auto_build (default: $KNERF_AUTO_BUILD): a
         shape the fused kernels COULD cover but the loaded library does not hold is compiled for them on first use (hipcc, a few
-        minutes once per shape; the build is kept in keras_nerf_amd/build_auto_*/) instead of running on the general-shape kernels.  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
+        minutes once per shape; the build is kept in keras_nerf_amd/build_auto_*/) instead of running on the general-shape kernels.
+        pad_width (default on; $KNERF_NO_WIDTH_PAD=1 turns it off): an even dense_units below 256 that is not 64 / 128 / 256 runs on the
+        FUSED kernels of the next of those widths with zero-padded weights -- an exact identity (padded neurons have zero kernel and
+        bias: their activations, every gradient that touches them and hence their Adam updates are exactly zero; `_set_up_padding`) --
+        whenever the library holds (or auto_build builds) that shape; set_weights / get_weights / grads() speak the REAL layout,
+        weights_view / grads_view expose the padded buffers (what a data-parallel broadcast / all-reduce needs).  The LIBRARY reads no environment variables; for tools and sweeps this wrapper translates
         KNERF_FORCE_GENERIC, KNERF_WGRAD_GROUP_MAX, KNERF_WGRAD_GROUP_GB, KNERF_WGRAD_COSTS ("c0,...,c<n_layers>": one per weight-gradient job), KNERF_DETERMINISTIC and
         KNERF_SKIP_DEAD_TILES, KNERF_MERGE_CHUNK_RAYS, KNERF_MERGE_RENDER_RAYS into the config flag / options below (explicit arguments win)."""
         self._ctx = C.c_void_p()
@@ -65,20 +100,28 @@ class KnerfContext:
         self.cfg = KnerfConfig(n_coarse, n_fine, pos_emb_xyz, pos_emb_dir, n_layers, dense_units, skip_layer,
                                int(bool(white_background)), int(oob == "clamp"), lr, beta1, beta2, epsilon, flags)
         self.n_coarse, self.n_fine = n_coarse, n_fine
-        rc = self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
+        self._pad_index = None          # torch int64 [real params] -> position in the padded flat parameters (width padding), or None
+        if pad_width is None:
+            pad_width = os.environ.get("KNERF_NO_WIDTH_PAD", "") in ("", "0")
+        wide = padded_width(dense_units) if (pad_width and not force_generic and encoded_widths is None) else None
+        if wide is not None and self._set_up_padding(wide, auto_build):
+            real_units, dense_units = dense_units, wide                 # from here on the context IS the padded shape
+        rc = 0 if self._ctx.value else self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
         if rc != 0:
             msg = self.lib.knerf_last_error(None).decode()
             self._ctx = C.c_void_p()
             raise (ValueError if rc == _lib.KNERF_ERR_INVALID else KnerfError)(msg)
-        self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
+        if self._pad_index is None:
+            self.param_count = int(self.lib.knerf_param_count_for(C.byref(self.cfg)))
         if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
             # a shape outside the library's list: where the fused kernels could cover it, build them (opt-in) or say how; else say what it costs
-            coverable = (dense_units in (64, 128, 256) and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
-                         and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8 and not (dense_units == 256 and pos_emb_xyz == 16 and pos_emb_dir >= 5))
-            spec = f"{n_layers},{skip_layer},{dense_units}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
+            eff = (padded_width(dense_units) if pad_width else None) or dense_units       # the width the fused kernels would run it at
+            coverable = (eff in FUSED_WIDTHS and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
+                         and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8 and not (eff == 256 and pos_emb_xyz == 16 and pos_emb_dir >= 5))
+            spec = f"{n_layers},{skip_layer},{eff}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
             if auto_build is None:
                 auto_build = os.environ.get("KNERF_AUTO_BUILD", "") not in ("", "0")
-            if coverable and auto_build:
+            if coverable and auto_build and eff == dense_units:          # (a padded width was tried, and built if allowed, in _set_up_padding)
                 self._rebuild_for(spec)
         if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
             # visible at the default log level when there is something the user can do about it, once per shape
@@ -109,6 +152,47 @@ class KnerfContext:
                     self.set_option(k, v)
                 except ValueError:           # the context has fewer jobs than n_layers + 1 (general-shape path)
                     break
+
+    def _set_up_padding(self, wide: int, auto_build) -> bool:
+        """Try the network at width `wide` (zero-padded) on the fused kernels.  True: self._ctx is a fused context of the padded shape,
+        self.cfg describes it, self.param_count / self._pad_index the real one.  False: nothing changed (the real shape then runs on
+        the general-shape kernels as before).
+
+        Why the padding is exact: a padded neuron j has a zero kernel column and zero bias, so z_j = 0 and h_j = relu(0) = 0 (a
+        linear head layer: 0); the next layer's kernel rows for j are zero, so nothing reads it.  Backward: dz_j = [h_j > 0] (...) = 0
+        at a relu, and W_next[j, :] . dz_next = 0 at a linear layer, so dW[:, j] = x^T dz_j = 0, db_j = 0 and dW_next[j, :] = h_j^T
+        dz_next = 0: Adam's m and v stay 0 and its update 0 / (0 + eps) = 0 -- the zeros stay zeros, bit for bit, and the sums over the
+        real neurons only ever gain exact zeros."""
+        c = self.cfg
+        cfg_p = KnerfConfig(c.n_coarse, c.n_fine, c.pos_emb_xyz, c.pos_emb_dir, c.n_layers, wide, c.skip_layer, c.white_background,
+                            c.oob_clamp, c.lr, c.beta1, c.beta2, c.epsilon, c.flags)
+        ctx = C.c_void_p()
+        if self.lib.knerf_create(C.byref(cfg_p), C.byref(ctx)) != 0:
+            return False
+        real_cfg, real_ctx = self.cfg, self._ctx
+        self.cfg, self._ctx = cfg_p, ctx
+        generic = bool(self.get_option("general_shape_path"))
+        if generic:                                        # the padded shape is not in the library either: build it when allowed
+            if auto_build is None:
+                auto_build = os.environ.get("KNERF_AUTO_BUILD", "") not in ("", "0")
+            coverable = (3 <= c.n_layers <= 16 and c.skip_layer >= 1 and (c.n_layers - 1) % c.skip_layer != 0 and 1 <= c.pos_emb_xyz <= 16
+                         and 1 <= c.pos_emb_dir <= 8 and not (wide == 256 and c.pos_emb_xyz == 16 and c.pos_emb_dir >= 5))
+            if coverable and auto_build:
+                self._rebuild_for(f"{c.n_layers},{c.skip_layer},{wide}" + ("" if (c.pos_emb_xyz, c.pos_emb_dir) == (10, 4) else f",{c.pos_emb_xyz},{c.pos_emb_dir}"))
+                generic = bool(self.get_option("general_shape_path"))
+        if generic:
+            self.lib.knerf_destroy(self._ctx)
+            self.cfg, self._ctx = real_cfg, real_ctx
+            return False
+        self.param_count = int(self.lib.knerf_param_count_for(C.byref(real_cfg)))
+        self.padded_param_count = int(self.lib.knerf_param_count_for(C.byref(cfg_p)))
+        self.real_dense_units = int(real_cfg.dense_units)
+        idx = width_pad_index(c.n_layers, int(real_cfg.dense_units), wide, c.skip_layer, 3 + 6 * c.pos_emb_xyz, 3 + 6 * c.pos_emb_dir)
+        assert idx.size == self.param_count and int(idx.max()) < self.padded_param_count
+        self._pad_index_host = idx
+        self._pad_index = torch.as_tensor(idx, device=self.device)
+        logging.info("dense_units=%d runs on the fused kernels at width %d with zero-padded weights (exact)", real_cfg.dense_units, wide)
+        return True
 
     def _rebuild_for(self, spec: str):
         """KNERF_AUTO_BUILD: compile the fused kernels for this shape into their own library (build.py --variant=auto_<shape>
@@ -195,12 +279,26 @@ class KnerfContext:
     # ---- weights
     def set_weights(self, net: int, flat):
         flat = np.ascontiguousarray(np.asarray(flat, dtype=np.float32).reshape(-1))
+        if self._pad_index is not None:                # width padding: the real parameters into a zero vector of the padded layout
+            if flat.size != self.param_count:
+                raise ValueError(f"set_weights: {flat.size} values for a network of {self.param_count} parameters")
+            wide = np.zeros(self.padded_param_count, np.float32)
+            wide[self._pad_index_host] = flat
+            flat = wide
         self._check(self.lib.knerf_set_weights(self._ctx, net, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size))
 
     def get_weights(self, net: int) -> np.ndarray:
-        out = np.empty(self.param_count, np.float32)
+        n = self.param_count if self._pad_index is None else self.padded_param_count
+        out = np.empty(n, np.float32)
         self._check(self.lib.knerf_get_weights(self._ctx, net, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
-        return out
+        return out if self._pad_index is None else out[self._pad_index_host]
+
+    def grads(self, net: int) -> torch.Tensor:
+        """the accumulated gradient of one net in the REAL flat layout (a copy): grads_view()'s half, un-padded where the width is padded"""
+        g = self.grads_view()
+        n = g.numel() // 2
+        half = g[net * n:(net + 1) * n]
+        return half.clone() if self._pad_index is None else half[self._pad_index]
 
     def weights_view(self, net: int) -> torch.Tensor:
         """torch view (no copy) of the library-owned fp32 master weights of one net"""

@@ -183,7 +183,7 @@ def test_skipping_changes_nothing_when_nothing_is_dead_and_handles_all_dead():
 
 
 @pytest.mark.parametrize("shape", [dict(force_generic=True),                                              # the default shape on the general-shape kernels
-                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2)])     # a shape only they cover
+                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2, pad_width=False)])     # a shape only they cover
 def test_dead_tile_skipping_on_the_general_shape_path_is_exact(shape):
     """Round 5: the general-shape kernels (csrc/generic.hip) walk the same list of live 32-sample tiles in every dgrad GEMM and every
     weight-gradient product.  A problem with a substantial dead fraction (sigma's bias lowered so that the ReLU on sigma is closed in

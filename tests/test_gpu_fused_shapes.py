@@ -123,11 +123,15 @@ def test_fused_shape_deterministic_and_skipping_exact(nl, sk, units):
 
 def test_shapes_outside_the_fused_set_use_the_general_path():
     from keras_nerf_amd.runtime import KnerfContext
-    for kw in (dict(n_layers=8, dense_units=96, skip_layer=4), dict(n_layers=6, dense_units=64, skip_layer=3), dict(n_layers=6, dense_units=128, skip_layer=3), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
+    for kw in (dict(n_layers=8, dense_units=96, skip_layer=4, pad_width=False), dict(n_layers=8, dense_units=320, skip_layer=4), dict(n_layers=6, dense_units=64, skip_layer=3), dict(n_layers=6, dense_units=128, skip_layer=3), dict(n_layers=5, dense_units=256, skip_layer=2),      # concat behind the last layer
                dict(n_layers=8, dense_units=256, skip_layer=4, pos_emb_xyz=6), dict(n_layers=7, dense_units=256, skip_layer=3)):
         ctx = KnerfContext(white_background=True, **kw)
         assert ctx.get_option("general_shape_path") == 1.0, kw
         ctx.close()
+    # ... and a width BETWEEN the fused ones runs on them, zero-padded (tests/test_width_padding.py), when the padded shape is in the library
+    ctx = KnerfContext(white_background=True, n_layers=8, dense_units=96, skip_layer=4)
+    assert ctx.get_option("general_shape_path") == 0.0 and ctx.real_dense_units == 96
+    ctx.close()
     ctx = KnerfContext(white_background=True)
     assert ctx.get_option("general_shape_path") == 0.0
     ctx.close()

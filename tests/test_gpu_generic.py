@@ -36,7 +36,8 @@ def ctx_for(P, **kw):
     from keras_nerf_amd.runtime import KnerfContext
     c = P["cfg"]
     ctx = KnerfContext(n_coarse=c.n_coarse, n_fine=c.n_fine, pos_emb_xyz=c.pos_emb_xyz, pos_emb_dir=c.pos_emb_dir,
-                       n_layers=c.n_layers, dense_units=c.dense_units, skip_layer=c.skip_layer, white_background=True, **kw)
+                       n_layers=c.n_layers, dense_units=c.dense_units, skip_layer=c.skip_layer, white_background=True,
+                       pad_width=False, **kw)        # these tests are about the general-shape kernels: no detour over a padded fused width
     assert ctx.param_count == O.param_count(c)
     ctx.set_weights(0, O.flatten_params(P["cp"]))
     ctx.set_weights(1, O.flatten_params(P["fp"]))

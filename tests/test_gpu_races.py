@@ -74,7 +74,7 @@ def test_chain_kernels_are_bit_reproducible_at_bench_size():
 
 
 @pytest.mark.parametrize("shape", [dict(n_layers=8, dense_units=256, skip_layer=4, force_generic=True),          # the default shape on the general-shape kernels
-                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2)])   # cooperative and per-wave weight-gradient kernels, a width the chain does not cover
+                                   dict(n_layers=5, dense_units=192, skip_layer=2, pos_emb_xyz=6, pos_emb_dir=2, pad_width=False)])   # cooperative and per-wave weight-gradient kernels, a width the chain does not cover
 def test_general_shape_kernels_are_bit_reproducible_at_bench_size(shape):
     """csrc/generic.hip at the bench's chunk size (4,096 rays x 192 samples through every GEMM): outputs, every activation buffer,
     every dZ buffer identical from launch to launch; the gradient equal up to the order of its fp32 atomics by default and
