@@ -33,8 +33,9 @@ FUSED_WIDTHS = (64, 128, 256)       # csrc/layout.h: the trunk widths the fused 
 
 
 def padded_width(dense_units: int):
-    """the fused width a narrower (even) dense_units is run at, or None: 50 -> 64, 96 -> 128, 192 -> 256"""
-    if dense_units in FUSED_WIDTHS or dense_units > FUSED_WIDTHS[-1] or dense_units < 2 or dense_units % 2:
+    """the fused width a narrower dense_units is run at, or None: 50 -> 64, 96 -> 128, 191 -> 256 (odd widths too: the reference's
+    rgb_features layer has dense_units // 2 outputs, mlp.py:25, and so has the map)"""
+    if dense_units in FUSED_WIDTHS or dense_units > FUSED_WIDTHS[-1] or dense_units < 2:
         return None
     return next(w for w in FUSED_WIDTHS if w >= dense_units)
 
@@ -76,7 +77,7 @@ class KnerfContext:
         (KNERF_FLAG_ENCODED_WIDTHS: weights and mlp_call only; pos_emb_* are ignored).  auto_build (default: $KNERF_AUTO_BUILD): a
         shape the fused kernels COULD cover but the loaded library does not hold is compiled for them on first use (hipcc, a few
         minutes once per shape; the build is kept in keras_nerf_amd/build_auto_*/) instead of running on the general-shape kernels.
-        pad_width (default on; $KNERF_NO_WIDTH_PAD=1 turns it off): an even dense_units below 256 that is not 64 / 128 / 256 runs on the
+        pad_width (default on; $KNERF_NO_WIDTH_PAD=1 turns it off): a dense_units below 256 that is not 64 / 128 / 256 runs on the
         FUSED kernels of the next of those widths with zero-padded weights -- an exact identity (padded neurons have zero kernel and
         bias: their activations, every gradient that touches them and hence their Adam updates are exactly zero; `_set_up_padding`) --
         whenever the library holds (or auto_build builds) that shape; set_weights / get_weights / grads() speak the REAL layout,

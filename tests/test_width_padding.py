@@ -9,7 +9,7 @@ import pytest
 from oracle import nerf_oracle as O
 from tests.problem import make_problem
 
-SHAPES = [(8, 4, 192), (8, 4, 96), (4, 2, 50), (6, 3, 200)]
+SHAPES = [(8, 4, 192), (8, 4, 96), (4, 2, 50), (6, 3, 200), (4, 2, 51)]       # the last: odd (rgb_features has 51 // 2 = 25 outputs)
 
 
 def _pad_params(params, cfg, wide):
@@ -47,12 +47,12 @@ def test_zero_padded_network_is_the_real_one_on_the_oracle(nl, sk, units):
 
 def test_widths_that_are_not_padded():
     from keras_nerf_amd.runtime import padded_width
-    assert [padded_width(u) for u in (64, 128, 256, 300, 512, 63, 1)] == [None] * 7           # fused already / wider than 256 / odd (units // 2)
-    assert [padded_width(u) for u in (2, 50, 66, 130, 254)] == [64, 64, 128, 256, 256]
+    assert [padded_width(u) for u in (64, 128, 256, 300, 512, 1)] == [None] * 6               # fused already / wider than 256 / no rgb_features outputs
+    assert [padded_width(u) for u in (2, 50, 63, 66, 130, 255)] == [64, 64, 64, 128, 256, 256]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nl,sk,units", SHAPES[:3])
+@pytest.mark.parametrize("nl,sk,units", SHAPES[:3] + SHAPES[4:])
 def test_padded_context_runs_fused_and_meets_the_oracle_of_the_real_shape(nl, sk, units):
     import torch
     from keras_nerf_amd.runtime import KnerfContext
