@@ -106,7 +106,7 @@ class KnerfContext:
             pad_width = os.environ.get("KNERF_NO_WIDTH_PAD", "") in ("", "0")
         wide = padded_width(dense_units) if (pad_width and not force_generic and encoded_widths is None) else None
         if wide is not None and self._set_up_padding(wide, auto_build):
-            real_units, dense_units = dense_units, wide                 # from here on the context IS the padded shape
+            dense_units = wide                                          # from here on the context IS the padded shape
         rc = 0 if self._ctx.value else self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
         if rc != 0:
             msg = self.lib.knerf_last_error(None).decode()
