@@ -33,11 +33,17 @@ FUSED_WIDTHS = (64, 128, 256)       # csrc/layout.h: the trunk widths the fused 
 
 
 def padded_width(dense_units: int):
-    """the fused width a narrower dense_units is run at, or None: 50 -> 64, 96 -> 128, 191 -> 256 (odd widths too: the reference's
-    rgb_features layer has dense_units // 2 outputs, mlp.py:25, and so has the map)"""
-    if dense_units in FUSED_WIDTHS or dense_units > FUSED_WIDTHS[-1] or dense_units < 2:
+    """the width a dense_units is run at, or None (as it is).  Below 256: the next FUSED width -- 50 -> 64, 96 -> 128, 191 -> 256 (odd
+    widths too: the reference's rgb_features layer has dense_units // 2 outputs, mlp.py:25, and so has the map).  Above 256 (general-shape
+    kernels): the next multiple of 128 -- their GEMMs tile the output in blocks of 8, 4, 2 or 1 thirty-two-column tiles, whichever
+    divides it, and every block re-reads the layer's input: 352 (11 tiles: eleven blocks) costs 24.9 ms per train chunk, 384 (three
+    blocks of four) 13.1; 416 29.8 against 512's 18.0."""
+    if dense_units < 2 or dense_units in FUSED_WIDTHS:
         return None
-    return next(w for w in FUSED_WIDTHS if w >= dense_units)
+    if dense_units < FUSED_WIDTHS[-1]:
+        return next(w for w in FUSED_WIDTHS if w >= dense_units)
+    wide = -(-dense_units // 128) * 128
+    return None if wide == dense_units else wide
 
 
 def width_pad_index(n_layers: int, units: int, padded: int, skip_layer: int, xyz_dim: int, dir_dim: int) -> np.ndarray:
@@ -172,7 +178,7 @@ class KnerfContext:
             return False
         real_cfg, real_ctx = self.cfg, self._ctx
         self.cfg, self._ctx = cfg_p, ctx
-        generic = bool(self.get_option("general_shape_path"))
+        generic = bool(self.get_option("general_shape_path")) and wide <= FUSED_WIDTHS[-1]      # (above 256 the general-shape kernels ARE the target)
         if generic:                                        # the padded shape is not in the library either: build it when allowed
             if auto_build is None:
                 auto_build = os.environ.get("KNERF_AUTO_BUILD", "") not in ("", "0")
@@ -192,7 +198,8 @@ class KnerfContext:
         assert idx.size == self.param_count and int(idx.max()) < self.padded_param_count
         self._pad_index_host = idx
         self._pad_index = torch.as_tensor(idx, device=self.device)
-        logging.info("dense_units=%d runs on the fused kernels at width %d with zero-padded weights (exact)", real_cfg.dense_units, wide)
+        logging.info("dense_units=%d runs at width %d with zero-padded weights (exact) on the %s kernels", real_cfg.dense_units, wide,
+                     "fused" if wide <= FUSED_WIDTHS[-1] else "general-shape")
         return True
 
     def _rebuild_for(self, spec: str):

@@ -9,7 +9,8 @@ import pytest
 from oracle import nerf_oracle as O
 from tests.problem import make_problem
 
-SHAPES = [(8, 4, 192), (8, 4, 96), (4, 2, 50), (6, 3, 200), (4, 2, 51)]       # the last: odd (rgb_features has 51 // 2 = 25 outputs)
+SHAPES = [(8, 4, 192), (8, 4, 96), (4, 2, 50), (6, 3, 200), (4, 2, 51),      # (4, 2, 51): odd (rgb_features has 51 // 2 = 25 outputs)
+          (3, 2, 288)]                                                       # above 256: the general-shape kernels at the next multiple of 128
 
 
 def _pad_params(params, cfg, wide):
@@ -26,7 +27,7 @@ def test_zero_padded_network_is_the_real_one_on_the_oracle(nl, sk, units):
     from keras_nerf_amd.runtime import padded_width
     cfg = O.NerfConfig(n_layers=nl, dense_units=units, skip_layer=sk)
     wide = padded_width(units)
-    assert wide in (64, 128, 256) and wide > units
+    assert wide in (64, 128, 256, 384) and wide > units
     P = make_problem(n_images=1, wh=6, weight_scale=1.5, bias_std=0.05, cfg=cfg)
     N = P["N"]
     o, d, t, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["img"].reshape(N, 3)
@@ -47,12 +48,13 @@ def test_zero_padded_network_is_the_real_one_on_the_oracle(nl, sk, units):
 
 def test_widths_that_are_not_padded():
     from keras_nerf_amd.runtime import padded_width
-    assert [padded_width(u) for u in (64, 128, 256, 300, 512, 1)] == [None] * 6               # fused already / wider than 256 / no rgb_features outputs
+    assert [padded_width(u) for u in (64, 128, 256, 384, 512, 1024, 1)] == [None] * 7         # a fused width / a multiple of 128 / no rgb_features outputs
     assert [padded_width(u) for u in (2, 50, 63, 66, 130, 255)] == [64, 64, 64, 128, 256, 256]
+    assert [padded_width(u) for u in (257, 288, 352, 385, 416, 520)] == [384, 384, 384, 512, 512, 640]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nl,sk,units", SHAPES[:3] + SHAPES[4:])
+@pytest.mark.parametrize("nl,sk,units", SHAPES[:3] + SHAPES[4:])      # incl. 288 -> 384 on the general-shape kernels
 def test_padded_context_runs_fused_and_meets_the_oracle_of_the_real_shape(nl, sk, units):
     import torch
     from keras_nerf_amd.runtime import KnerfContext
@@ -63,7 +65,7 @@ def test_padded_context_runs_fused_and_meets_the_oracle_of_the_real_shape(nl, sk
     res = {}
     for pad in (True, False):
         ctx = KnerfContext(n_layers=nl, dense_units=units, skip_layer=sk, white_background=True, pad_width=pad)
-        assert ctx.get_option("general_shape_path") == (0.0 if pad else 1.0)
+        assert ctx.get_option("general_shape_path") == (0.0 if pad and units < 256 else 1.0)      # below 256 the padded shape is a fused one
         assert ctx.param_count == O.param_count(cfg)
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         np.testing.assert_array_equal(ctx.get_weights(0), O.flatten_params(P["cp"]))          # the real layout, round trip
