@@ -37,8 +37,7 @@ def test_compiler_tracked_fragment_loads_give_identical_bits():
     assert len(a) >= 10
 
 
-XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3",
-           "6,3,64", "8,4,64,6,2", "8,4,256,10,8", "8,4,128,10,6"]    # round 4: width 64 (8/4 and 4/2 are built in), pos_emb_dir 5..8 (four head k-steps)
+from tests.variant_shapes import XSHAPES      # noqa: E402  (also read by __graft_entry__.build)
 
 
 def test_build_time_extra_shapes_run_on_the_fused_kernels():
