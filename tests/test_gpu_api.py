@@ -567,6 +567,11 @@ def test_one_rank_rccl_rehearsal_of_the_multi_gpu_bench_path():
     assert t.stdout.strip().count("\n") == 0, t.stdout[:2000]
     tl = json.loads(t.stdout)
     assert tl["dist_backend"] == "nccl" and tl["rccl_ranks"] == 1 and tl["replica_drift"] == 0.0 and tl["allreduce_ms_per_step"] > 0
+    # a rank that fails prints the tail of ITS RCCL log (parallel.rank_fail; NCCL_DEBUG_FILE with %h / %p): with a real RCCL behind it
+    # (INFO here, so that the file has lines) the file is found under the name this code derives, the job ends with code 3, stdout stays empty
+    f = _bench(["--steps", "3", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline"], dict(env, NCCL_DEBUG="INFO", KNERF_BENCH_INJECT_FAILURE="0:warmup"))
+    assert f.returncode == 3 and f.stdout.strip() == "", (f.returncode, f.stdout[:500])
+    assert "[bench rank 0/1] FAILED in the warm-up steps" in f.stderr and "RCCL log tail (INFO)" in f.stderr and "NCCL INFO" in f.stderr
 
 
 def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
