@@ -111,8 +111,12 @@ class KnerfContext:
         if pad_width is None:
             pad_width = os.environ.get("KNERF_NO_WIDTH_PAD", "") in ("", "0")
         wide = padded_width(dense_units) if (pad_width and not force_generic and encoded_widths is None) else None
-        if wide is not None and self._set_up_padding(wide, auto_build):
-            dense_units = wide                                          # from here on the context IS the padded shape
+        # ... and where the library lacks this (n_layers, skip_layer) pair at that fused width but holds it one width up, that one: the
+        # fused chain at 256 (3.4 ms per 8-layer chunk) still beats the general-shape kernels at 128 (3.8); two widths up it does not
+        for cand in ([wide] + [w for w in FUSED_WIDTHS if wide < w <= 2 * wide][:1] if wide is not None else []):
+            if self._set_up_padding(cand, auto_build if cand == wide else False):
+                dense_units = cand                                      # from here on the context IS the padded shape
+                break
         rc = 0 if self._ctx.value else self.lib.knerf_create(C.byref(self.cfg), C.byref(self._ctx))
         if rc != 0:
             msg = self.lib.knerf_last_error(None).decode()

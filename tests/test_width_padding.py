@@ -97,6 +97,25 @@ def test_padded_context_runs_fused_and_meets_the_oracle_of_the_real_shape(nl, sk
 
 
 @pytest.mark.gpu
+def test_a_pair_the_library_lacks_at_the_next_width_is_taken_one_width_up():
+    """6 layers / skip 3 is built in at width 256 only: dense_units = 100 (next fused width 128: not in the library) runs zero-padded on
+    the 256-wide fused kernels -- still faster than the general-shape kernels at 128 --; dense_units = 40 (next: 64, one up: 128, both
+    missing) stays on the general-shape kernels: two widths up would cost more than it saves"""
+    from keras_nerf_amd.runtime import KnerfContext
+    ctx = KnerfContext(n_layers=6, dense_units=100, skip_layer=3, white_background=True)
+    assert ctx.get_option("general_shape_path") == 0.0 and ctx.real_dense_units == 100 and ctx.cfg.dense_units == 256
+    cfg = O.NerfConfig(n_layers=6, dense_units=100, skip_layer=3)
+    assert ctx.param_count == O.param_count(cfg)
+    w = O.flatten_params(O.init_params(cfg, 0))
+    ctx.set_weights(0, w)
+    np.testing.assert_array_equal(ctx.get_weights(0), w)
+    ctx.close()
+    ctx = KnerfContext(n_layers=6, dense_units=40, skip_layer=3, white_background=True)
+    assert ctx.get_option("general_shape_path") == 1.0 and ctx.cfg.dense_units == 40
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_nerf_with_a_padded_width_trains_and_checkpoints_in_the_real_layout(tmp_path):
     import torch
     from keras_nerf_amd.model.nerf.nerf import NeRF
