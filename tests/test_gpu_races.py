@@ -177,4 +177,11 @@ def test_creating_and_destroying_contexts_returns_their_memory():
         torch.cuda.synchronize()
         free, total = torch.cuda.mem_get_info()
         used.append(total - free)
-    assert max(used[3:]) - min(used[3:]) <= 64 << 20, [u >> 20 for u in used]      # torch's own caching allocator settles within the first cycles
+    # A leak raises the FLOOR cycle after cycle; a transient reading does not (one run in a dozen has shown +112 MiB for a few cycles:
+    # the driver's view of memory that hipFree has just returned).  So: the floor of the last dozen cycles against the floor of the first
+    # settled dozen (torch's own caching allocator settles within the first cycles), and no lasting growth over the second half.
+    mib = [u >> 20 for u in used]
+    print("device MiB in use after each cycle:", mib)
+    assert min(used[-12:]) - min(used[3:15]) <= 16 << 20, mib
+    assert min(used[30:]) - min(used[3:30]) <= 16 << 20, mib
+    assert max(used[3:]) - min(used[3:]) <= 1 << 30, mib                          # (and nothing like a whole workspace left behind at any time)
