@@ -183,8 +183,11 @@ def max_over_ranks(elapsed, world):
 
 
 def dist_fields(world, backend, steps):
+    from keras_nerf_amd import parallel
     per = [e / steps * 1e3 for e in RANK_ELAPSED]
-    return {"rccl_ranks": torch.distributed.get_world_size() if dist_on(world) and backend == "nccl" else (1 if world == 1 else 0),
+    # launch_attempts 2 = the launcher's first set of ranks never got a working process group and a second, fresh set under the
+    # other HSA_ENABLE_IPC_MODE_LEGACY setting produced this line (keras_nerf_amd/parallel.py _launch_attempts)
+    return {**parallel.launch_fields(), "rccl_ranks": torch.distributed.get_world_size() if dist_on(world) and backend == "nccl" else (1 if world == 1 else 0),
             "dist_backend": backend if dist_on(world) else None,
             "ms_per_step_rank_min": min(per), "ms_per_step_rank_max": max(per), "ms_per_step_by_rank": [round(v, 4) for v in per]}
 

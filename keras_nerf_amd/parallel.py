@@ -87,6 +87,9 @@ def reduce_logs(logs: dict, device=None) -> dict:
 # launcher stops the others by their own PIDs (no pattern kills, no collective time-outs).
 # ---------------------------------------------------------------------------------------------------------------------
 RANK_FAILED = 3          # exit code of a rank that raised (and of the launcher that saw it)
+RANK_FAILED_SETUP = 4    # ... of a rank whose process group never worked (init_process_group / the first all_reduce): the one
+                         # failure the launcher answers with a second set of ranks under the other IPC setting (launch)
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
 
 
 def dist_env(world: int = 1) -> None:
@@ -95,19 +98,40 @@ def dist_env(world: int = 1) -> None:
     without it RCCL fails with `hipIpcGetMemHandle: invalid argument`).  Called before anything touches HIP; existing values win.
     world > 1: RCCL's warnings go to one file per rank (NCCL_DEBUG=WARN, NCCL_DEBUG_FILE), whose tail `rank_fail` prints."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("KNERF_LAUNCH_IPC") != "unset":          # the launcher's second attempt runs WITHOUT the variable (launch)
+        os.environ.setdefault(IPC_VAR, "0")
     if world > 1 or single_rank_rehearsal():
         os.environ.setdefault("NCCL_DEBUG", "WARN")
-        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "knerf_rccl_%h_%p.log"))
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            # one file per rank: in the launcher's job directory when there is one (removed with it after a clean job), else under
+            # TMPDIR and removed by this process when it leaves normally (rank_fail leaves through os._exit: the file stays)
+            os.environ["NCCL_DEBUG_FILE"] = os.path.join(os.environ.get("KNERF_LAUNCH_DIR") or os.environ.get("TMPDIR", "/tmp"), "knerf_rccl_%h_%p.log")
+            if not os.environ.get("KNERF_LAUNCH_DIR"):
+                import atexit
+                atexit.register(_remove_own_rccl_log, os.getpid())
 
 
-def rccl_log_tail(max_bytes: int = 4000) -> str:
-    """the tail of THIS process's RCCL debug file (dist_env), or '' -- NCCL_DEBUG_FILE's %h / %p are host name and pid"""
+def _own_rccl_log() -> str:
     pat = os.environ.get("NCCL_DEBUG_FILE", "")
     if not pat:
         return ""
     import socket
-    path = pat.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))
+    return pat.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))
+
+
+def _remove_own_rccl_log(pid: int) -> None:
+    if pid == os.getpid():                 # not in a forked child that inherited the handler
+        try:
+            os.remove(_own_rccl_log())
+        except OSError:
+            pass
+
+
+def rccl_log_tail(max_bytes: int = 4000) -> str:
+    """the tail of THIS process's RCCL debug file (dist_env), or '' -- NCCL_DEBUG_FILE's %h / %p are host name and pid"""
+    path = _own_rccl_log()
+    if not path:
+        return ""
     try:
         with open(path, "rb") as f:
             f.seek(0, 2); n = f.tell(); f.seek(max(0, n - max_bytes))
@@ -116,10 +140,11 @@ def rccl_log_tail(max_bytes: int = 4000) -> str:
         return ""
 
 
-def rank_fail(what: str, exc: BaseException, tag: str = "knerf") -> None:
-    """A rank that cannot join or use the process group says who and where it is and leaves with exit code 3 -- the launcher then
-    stops the other ranks -- instead of letting them sit in a collective until its time-out.  Never re-execs (the process may
-    have initialised the GPU).  Prints the tail of this rank's RCCL warnings when there are any."""
+def rank_fail(what: str, exc: BaseException, tag: str = "knerf", code: int = RANK_FAILED) -> None:
+    """A rank that cannot join or use the process group says who and where it is and leaves with exit code 3 (4 = the group never
+    worked, RANK_FAILED_SETUP) -- the launcher then stops the other ranks -- instead of letting them sit in a collective until its
+    time-out.  Never re-execs (the process may have initialised the GPU).  Prints the tail of this rank's RCCL warnings when there
+    are any; under `launch` the same text is left in the job directory, for the line of a second attempt to quote."""
     import traceback
     r, w = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
     n_dev = torch.cuda.device_count()          # no GPU initialisation: the device this rank was (or would have been) given
@@ -127,17 +152,29 @@ def rank_fail(what: str, exc: BaseException, tag: str = "knerf") -> None:
     backend = dist.get_backend() if dist.is_available() and dist.is_initialized() else os.environ.get("KNERF_DIST_BACKEND", "nccl")
     tb = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
     tail = rccl_log_tail()
-    print(f"[{tag} rank {r}/{w}] FAILED in {what} on {dev} (backend {backend}): {type(exc).__name__}: {exc}\n{tb}"
-          + (f"[{tag} rank {r}/{w}] RCCL log tail ({os.environ.get('NCCL_DEBUG', '')}):\n{tail}\n" if tail else ""), file=sys.stderr, flush=True)
+    text = (f"[{tag} rank {r}/{w}] FAILED in {what} on {dev} (backend {backend}, {IPC_VAR}={os.environ.get(IPC_VAR, '<unset>')}): "
+            f"{type(exc).__name__}: {exc}\n{tb}" + (f"[{tag} rank {r}/{w}] RCCL log tail ({os.environ.get('NCCL_DEBUG', '')}):\n{tail}\n" if tail else ""))
+    print(text, file=sys.stderr, flush=True)
+    job = os.environ.get("KNERF_LAUNCH_DIR")
+    if job:
+        try:
+            with open(os.path.join(job, f"fail_attempt{os.environ.get('KNERF_LAUNCH_ATTEMPT', '1')}_rank{r}.txt"), "w") as f:
+                f.write(text)
+        except OSError:
+            pass
     sys.stderr.flush(); sys.stdout.flush()
-    os._exit(RANK_FAILED)
+    os._exit(code)
 
 
 def inject(stage: str) -> None:
     """fault injection for the fail-fast tests: KNERF_INJECT_FAILURE (or KNERF_BENCH_INJECT_FAILURE) = "<rank>:<stage>" makes that
-    rank raise at that stage (init | first_all_reduce | compile | warmup | body)"""
+    rank raise at that stage (init | first_all_reduce | compile | warmup | body); "<rank>:<stage>@<k>" only in the launcher's k-th
+    attempt, "*" = every rank"""
     spec = os.environ.get("KNERF_INJECT_FAILURE") or os.environ.get("KNERF_BENCH_INJECT_FAILURE", "")
-    if spec and spec == f"{os.environ.get('RANK', '0')}:{stage}":
+    spec, _, attempt = spec.partition("@")
+    if attempt and attempt != os.environ.get("KNERF_LAUNCH_ATTEMPT", "1"):
+        return
+    if spec and spec in (f"{os.environ.get('RANK', '0')}:{stage}", f"*:{stage}"):
         raise RuntimeError(f"injected failure at stage '{stage}'")
 
 
@@ -177,7 +214,7 @@ def init_rank(backend: str = None, timeout_s: float = 300.0, tag: str = "knerf")
         kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     except Exception as e:                         # noqa: BLE001 -- whatever the backend raises: say which rank and leave
-        rank_fail("init_process_group", e, tag)
+        rank_fail("init_process_group", e, tag, RANK_FAILED_SETUP)
     try:
         inject("first_all_reduce")
         probe = torch.ones(1, device="cuda" if dev is not None else "cpu")
@@ -187,7 +224,7 @@ def init_rank(backend: str = None, timeout_s: float = 300.0, tag: str = "knerf")
         if int(probe[0]) != world:
             raise RuntimeError(f"all_reduce(1) over {world} ranks returned {float(probe[0])}")
     except Exception as e:                         # noqa: BLE001
-        rank_fail("the first all_reduce", e, tag)
+        rank_fail("the first all_reduce", e, tag, RANK_FAILED_SETUP)
     return rank_, world, dev
 
 
@@ -280,6 +317,7 @@ def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
                 raise
         return 0
     backend = backend or os.environ.get("KNERF_DIST_BACKEND", "nccl")
+    dist_env(1)                                    # rendezvous address and IPC mode BEFORE the first call into torch.cuda, whatever it initialises
     n_dev = torch.cuda.device_count()
     n = int(nprocs) if nprocs is not None else max(n_dev, 1)
     if n < 1:
@@ -296,8 +334,17 @@ def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
                          f"(KNERF_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)")
     if torch.cuda.is_available() and torch.cuda.is_initialized():
         raise RuntimeError("launch must be called before this process touches the GPU (rank processes are started first)")
-    dist_env(n)
-    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    what = os.path.basename(sys.argv[0]) if fn is None else getattr(fn, "__name__", "fn")
+    code = _launch_attempts(fn, tuple(args), n, backend, what)
+    if fn is None:
+        raise SystemExit(code)                     # the parent was only the launcher: the script's body ran in the ranks
+    if code:
+        raise SystemExit(code)
+    return 0
+
+
+def _start_ranks(fn, args, n: int, backend: str, port: int):
+    """one fresh process per rank, environment taken from os.environ as it is NOW; returns (procs, poll, kill, hard_kill)"""
     if fn is None:
         import subprocess
         procs = []
@@ -305,18 +352,91 @@ def launch(fn=None, nprocs: int = None, args=(), backend: str = None) -> int:
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_PORT=str(port),
                        KNERF_DIST_BACKEND=backend)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0]), *sys.argv[1:]], env=env))
-        code = _wait_ranks(procs, lambda p: p.poll(), lambda p: p.terminate(), os.path.basename(sys.argv[0]), hard_kill=lambda p: p.kill())
-        raise SystemExit(code)                     # the parent was only the launcher: the script's body ran in the ranks
+        return procs, (lambda p: p.poll()), (lambda p: p.terminate()), (lambda p: p.kill())
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rank_entry, args=(fn, tuple(args), r, n, port, backend), daemon=False) for r in range(n)]
+    procs = [ctx.Process(target=_rank_entry, args=(fn, args, r, n, port, backend), daemon=False) for r in range(n)]
     for p in procs:
         p.start()
-    code = _wait_ranks(procs, lambda p: p.exitcode if not p.is_alive() else None, lambda p: p.terminate(), getattr(fn, "__name__", "fn"),
-                       hard_kill=lambda p: p.kill())
-    if code:
-        raise SystemExit(code)
-    return 0
+    return procs, (lambda p: p.exitcode if not p.is_alive() else None), (lambda p: p.terminate()), (lambda p: p.kill())
+
+
+def first_attempt_failure(max_chars: int = 1500):
+    """inside a rank of the launcher's SECOND attempt: what the first attempt's failing rank printed (its exception and the tail
+    of its RCCL log), shortened -- bench.py puts it on its line.  None in a first attempt or outside `launch`."""
+    path = os.environ.get("KNERF_LAUNCH_FIRST_FAILURE")
+    if not path:
+        return None
+    try:
+        with open(path) as f:
+            text = f.read()
+    except OSError:
+        return "(the first attempt left no report)"
+    return text if len(text) <= max_chars else text[:max_chars // 3] + "\n[...]\n" + text[-2 * max_chars // 3:]
+
+
+def launch_fields() -> dict:
+    """for a benchmark line: which attempt of the launcher this job is and the IPC setting it runs under"""
+    return {"launch_attempts": int(os.environ.get("KNERF_LAUNCH_ATTEMPT", "1")), "ipc_mode_legacy_env": os.environ.get(IPC_VAR),
+            "first_attempt_failure": first_attempt_failure()}
+
+
+def _launch_attempts(fn, args, n: int, backend: str, what: str) -> int:
+    """Start the ranks; when the job ends because its process group never worked (the first rank to fail left with
+    RANK_FAILED_SETUP: init_process_group or the first all_reduce), start ONE more, entirely fresh, set of ranks under the other
+    IPC setting.  dist_env defaults HSA_ENABLE_IPC_MODE_LEGACY=0 because this pool's host driver supports dmabuf IPC only; a node
+    with another driver may need the variable absent, and the first N > 1 run there has nobody to try that by hand.  This
+    process never touches the GPU, nothing execs, the first set has been stopped by handle before the second starts.  The ranks
+    learn the attempt number and the first failure's text from the environment (launch_fields) -- a job that needed two attempts
+    says so on its line.  Any other failure, and a second set-up failure, end the job as before."""
+    import shutil
+    import signal
+    import tempfile
+    job = tempfile.mkdtemp(prefix="knerf_job_")
+    saved = {k: os.environ.get(k) for k in (IPC_VAR, "KNERF_LAUNCH_DIR", "KNERF_LAUNCH_ATTEMPT", "KNERF_LAUNCH_IPC", "KNERF_LAUNCH_FIRST_FAILURE",
+                                            "NCCL_DEBUG", "NCCL_DEBUG_FILE")}
+
+    def on_term(signum, frame):                    # a plain SIGTERM must not orphan the ranks: _wait_ranks stops them on its way out
+        raise SystemExit(128 + signum)
+    try:
+        old_term = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                             # not the main thread: the caller keeps its own handling
+        old_term = None
+    code = 0
+    try:
+        os.environ["KNERF_LAUNCH_DIR"] = job
+        if os.environ.get("NCCL_DEBUG_FILE", "").endswith("knerf_rccl_%h_%p.log"):     # dist_env's own default, set before the job had a directory
+            del os.environ["NCCL_DEBUG_FILE"]
+        for attempt in (1, 2):
+            os.environ["KNERF_LAUNCH_ATTEMPT"] = str(attempt)
+            if attempt == 2:                       # the other setting: absent where it was "0", "0" where it was something else
+                if os.environ.get(IPC_VAR) == "0":
+                    del os.environ[IPC_VAR]; os.environ["KNERF_LAUNCH_IPC"] = "unset"
+                else:
+                    os.environ[IPC_VAR] = "0"
+                reports = sorted(f for f in os.listdir(job) if f.startswith("fail_attempt1_"))
+                os.environ["KNERF_LAUNCH_FIRST_FAILURE"] = os.path.join(job, reports[0]) if reports else os.path.join(job, "none")
+                print(f"[knerf launch] the process group of {what} never came up (exit code {code}): ONE more attempt with fresh ranks "
+                      f"and {IPC_VAR}={os.environ.get(IPC_VAR, '<unset>')}", file=sys.stderr, flush=True)
+            dist_env(n)
+            port = (int(os.environ.get("MASTER_PORT", 0)) if attempt == 1 else 0) or _free_port()
+            procs, poll, kill, hard_kill = _start_ranks(fn, args, n, backend, port)
+            code = _wait_ranks(procs, poll, kill, what, hard_kill=hard_kill)
+            if code != RANK_FAILED_SETUP:
+                break
+    finally:
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        if code == 0:
+            shutil.rmtree(job, ignore_errors=True)
+        else:
+            print(f"[knerf launch] reports and RCCL logs of the failed job: {job}", file=sys.stderr, flush=True)
+    return code
 
 
 class MirroredStrategy:

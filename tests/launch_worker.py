@@ -28,7 +28,9 @@ def body(out_dir, fail_rank=-1):
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump({"rank": rank, "world": world, "w": float(w[0][0]), "g1": float(g[1]), "loss": logs["loss"], "pid": os.getpid(),
                    "master": os.environ["MASTER_ADDR"], "ipc": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
-                   "nccl_debug": os.environ.get("NCCL_DEBUG"), "is_main": parallel.is_main()}, f)
+                   "nccl_debug": os.environ.get("NCCL_DEBUG"), "is_main": parallel.is_main(), **parallel.launch_fields()}, f)
+    if rank == 0:                # a benchmark's one line: a job that needed the launcher's second attempt says so
+        print(json.dumps({"n_ranks": world, **parallel.launch_fields()}), flush=True)
 
 
 def hang_unless_zero(out_dir):

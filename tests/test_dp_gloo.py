@@ -179,6 +179,55 @@ def test_launch_rerun_script_form_like_mirrored_strategy(tmp_path):
     _check_ranks(str(tmp_path), 4)
 
 
+@pytest.mark.parametrize("form", ["function", "script"])
+def test_launch_retries_once_with_the_other_ipc_setting_when_the_group_never_comes_up(tmp_path, form):
+    """The first unattended N > 1 run (train.py:75-93 on the driver's 8-GPU node) most likely dies where RCCL builds its rings:
+    dist_env defaults HSA_ENABLE_IPC_MODE_LEGACY=0 because THIS pool's driver needs it, and nobody knows what that node needs.
+    A job whose first failing rank leaves from init_process_group / the first all_reduce (exit code 4) gets ONE more set of FRESH
+    ranks from the launcher (which never touched a GPU) with the variable absent; the line of the job says launch_attempts 2, the
+    setting that worked and what the first attempt's rank reported.  Here: every rank of attempt 1 fails by injection, over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_launch_env(), KNERF_INJECT_FAILURE="*:first_all_reduce@1")
+    if form == "function":
+        code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import body; "
+                "rc = parallel.launch(body, 2, args=(%r,), backend='gloo'); print('launch returned', rc)") % (root, str(tmp_path))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    else:
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "launch_worker.py"), str(tmp_path), "2"],
+                           capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout                                     # ONE line: the first attempt printed none
+    line = lines[0]
+    assert line["launch_attempts"] == 2 and line["ipc_mode_legacy_env"] is None and line["n_ranks"] == 2
+    assert "injected failure at stage 'first_all_reduce'" in line["first_attempt_failure"] and "HSA_ENABLE_IPC_MODE_LEGACY=0" in line["first_attempt_failure"]
+    assert "ONE more attempt with fresh ranks and HSA_ENABLE_IPC_MODE_LEGACY=<unset>" in r.stderr
+    rs = [json.load(open(os.path.join(str(tmp_path), f"rank{k}.json"))) for k in range(2)]
+    assert all(z["ipc"] is None and z["launch_attempts"] == 2 and z["world"] == 2 for z in rs)
+    # the launcher's own environment is as it found it, and a clean job leaves no job directory behind
+    assert "reports and RCCL logs of the failed job" not in r.stderr
+
+
+def test_launch_does_not_retry_other_failures_and_gives_up_after_the_second_set_up_failure(tmp_path):
+    """a rank that fails in the BODY ends the job at once (exit 3, one attempt); a group that does not come up under either setting
+    ends it with exit 4 after exactly two attempts; a caller who chose a value other than "0" gets "0" as the second attempt"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import body; "
+            "parallel.launch(body, 2, args=(%r,), backend='gloo')") % (root, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(_launch_env(), KNERF_INJECT_FAILURE="1:body"))
+    assert r.returncode == 3 and "ONE more attempt" not in r.stderr, (r.returncode, r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(_launch_env(), KNERF_INJECT_FAILURE="0:init", HSA_ENABLE_IPC_MODE_LEGACY="1"))
+    assert r.returncode == 4 and r.stderr.count("ONE more attempt") == 1, (r.returncode, r.stderr[-2000:])
+    assert "fresh ranks and HSA_ENABLE_IPC_MODE_LEGACY=0" in r.stderr and "reports and RCCL logs of the failed job" in r.stderr
+    assert r.stderr.count("[knerf rank 0/2] FAILED in init_process_group") == 2
+
+
 def test_launch_stops_everything_when_one_rank_fails(tmp_path):
     """a rank that raises names itself, leaves with code 3, and the launcher terminates its peers (which are blocked in a collective
     with it) by their handles within seconds -- no collective time-out, no orphan processes"""

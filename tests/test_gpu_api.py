@@ -613,6 +613,21 @@ def test_cfg4_rehearsal_three_ranks_on_one_gpu_replicas_stay_identical():
     assert line["n_gpus"] == 3 and line["replica_drift"] == 0.0 and line["steps"] == 33 and line["value"] > 0      # 100 views = 33 global batches of 3
 
 
+def test_bench_line_after_the_launchers_second_attempt():
+    """`bench.py --gpus 2` spawns its own ranks; both ranks of the FIRST set fail in the first all-reduce (injected, attempt 1 only):
+    the launcher -- which never touched the GPU -- starts one fresh set with HSA_ENABLE_IPC_MODE_LEGACY absent, and the ONE JSON
+    line of the run says so (train.py:75-93: the N > 1 job nobody will be there to restart; tests/test_dp_gloo.py has the CPU half)"""
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "cfg4", "--no-cpu-baseline", "--no-profile"],
+               {"KNERF_DIST_BACKEND": "gloo", "KNERF_BENCH_INJECT_FAILURE": "*:first_all_reduce@1"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["launch_attempts"] == 2 and line["ipc_mode_legacy_env"] is None and line["replica_drift"] == 0.0
+    assert "injected failure at stage 'first_all_reduce'" in line["first_attempt_failure"]
+    assert "ONE more attempt with fresh ranks" in r.stderr
+
+
 def test_a_failing_rank_ends_the_run_at_once_with_its_name():
     """The first RCCL run with N > 1 happens on the driver's box with nobody to debug it: a rank that cannot join (or whose first
     collective fails) must say which rank / device / stage and end the whole job with a non-zero code within seconds, not leave
