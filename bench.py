@@ -89,11 +89,11 @@ def _cpu_problem(wh, n_images, n_rays=None):
     return o, d, t, img, u
 
 
-def _time_cpu_steps(step, want, budget_s):
-    """1 warm-up, then up to `want` timed steps while the wall-clock budget lasts (at least 2)"""
+def _time_cpu_steps(step, want, budget_s, at_least=3):
+    """1 warm-up, then up to `want` timed steps while the wall-clock budget lasts -- and `at_least` of them whatever they cost"""
     t0 = time.perf_counter(); step(); first = time.perf_counter() - t0
     times, spent = [], first
-    while len(times) < want and (len(times) < 2 or spent + (times[-1] if times else first) <= budget_s):
+    while len(times) < want and (len(times) < at_least or spent + (times[-1] if times else first) <= budget_s):
         t0 = time.perf_counter(); step(); times.append(time.perf_counter() - t0); spent += times[-1]
     return times
 
@@ -102,8 +102,9 @@ def cpu_baseline(budget_s=70.0):
     """The reference's TF-CPU path cannot run here (no TensorFlow): its op-for-op torch-CPU restatement
     (oracle/torch_ref.py, autograd backward, Keras-form Adam; kind "port") is timed on this box's host cores, as SURVEY.md
     section 8d prescribes: (1) BASELINE configs[0] exactly -- 64x64 image, 4 chunks of 1024 rays, coarse net only, 64 samples;
-    (2) a bounded sample of the benched workload's shape (cfg2: coarse64 + fine128, one chunk).  Median of up to 5 steps
-    after 1 warm-up inside a wall-clock budget; `cores` = torch threads actually used."""
+    (2) a bounded sample of the benched workload's shape (cfg2: coarse64 + fine128, one chunk).  Median of 3 to 5 steps
+    after 1 warm-up (5 while the wall-clock budget lasts, never fewer than 3: cfg1 costs ~13 s per step on the GPU box's host, so
+    its leg is ~50 s); `cores` = torch threads actually used."""
     from oracle import nerf_oracle as O
     from oracle import torch_ref as T
     cfg = O.NerfConfig()
@@ -129,7 +130,7 @@ def cpu_baseline(budget_s=70.0):
             "s_per_step": med2, "steps_timed": len(t2),
             "cfg1": {"value": 4096 * 64 / med1, "unit": "rays*samples/s", "s_per_step": med1, "steps_timed": len(t1),
                      "sample": "BASELINE configs[0] exactly: 64x64 image, batch 1, ray_chunks 1024 (4 chunks), coarse net only "
-                               "(64 samples), forward + backward + Adam"}}
+                               f"(64 samples), forward + backward + Adam; median of {len(t1)} steps after 1 warm-up"}}
 
 
 _REAL_STDOUT = None
@@ -264,7 +265,7 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
                           "dtype": "bf16", "data": "synthetic", "rays_samples_per_s": rs,
                           "config": {"workload": f"cfg5: {desc}", "frames": n_frames, "parallelism": f"dp{world}",
                                      "launch_rays": launch_rays, "launch_note": "consecutive chunks of a frame share launches (option merge_render_rays; per-ray work only: outputs bit-identical for every value)", "readback": "pinned double buffers on a side stream (tools/cfg5_readback_probe.py: A/B against blocking copies)"},
-                          "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames)}))
+                          "roofline": roofline, "cpu_baseline": None, **dist_fields(world, backend, n_frames), **provenance()}))
 
 
 # per 32-sample tile, KiB (csrc/layout.h): saved activations (h0 is recomputed, not saved), dZ WRITTEN (the run has 130 blocks;
@@ -279,8 +280,11 @@ WGRAD_KIB_PER_TILE = ACT_KIB + DZ_KIB + WGRAD_REREAD_KIB
 STEP_KIB_PER_TILE = 2 * (ACT_KIB + DZ_KIB + MASK_KIB) + WGRAD_REREAD_KIB + 2.5
 
 
-def pmc_traffic(kernel, skip_dead_tiles):
-    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary of THIS data layout that profiled the
+def pmc_traffic(kernel, skip_dead_tiles, kernel_digest="unchecked", profiles_dir=None):
+    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary of THE KERNELS THIS PROCESS LOADED
+    (`_kernel_digest` of the summary == kernel_digest of the loaded library, keras_nerf_amd/_lib.py build_info: the digest of the three
+    big kernels' sources and flags, tied to the binary by the library's own hash; a summary without a digest, one of other kernels,
+    or a library without a valid record gives (None, None) -- no counters are better than stale ones), of this data layout, that profiled the
     INSTANTIATION the bench ran (profiles/*pmc_traffic*.json, produced by tools/pmc.sh + tools/pmc_report.py on the GPU box: separate
     rocprofv3 --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is,
     both in KiB).  Counters cannot be read from inside the benched process, so the line names its source.  The weight-gradient kernel
@@ -295,9 +299,13 @@ def pmc_traffic(kernel, skip_dead_tiles):
             "mlp_bwd": ("mlp_bwd_kernel<", f", {net}>")}.get(kernel.rsplit("_", 1)[0])
     if not want:
         return None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+    if kernel_digest is None:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*pmc_traffic*.json")), reverse=True):
         rep = json.load(open(f))
         if rep.get("_layout", "act158_dz156") != LAYOUT_TAG:
+            continue
+        if kernel_digest != "unchecked" and rep.get("_kernel_digest") != kernel_digest:
             continue
         opt = rep.get("_options", {}).get("skip_dead_tiles")          # absent in summaries older than round 4: they profiled skipping off
         if kernel.startswith("mlp_bwd") and bool(opt) != bool(skip_dead_tiles):
@@ -306,8 +314,18 @@ def pmc_traffic(kernel, skip_dead_tiles):
                 and "hbm_bytes_per_launch" in v]
         if not rows:
             continue
-        return max(r["hbm_bytes_per_launch"] for r in rows), os.path.relpath(f, ROOT)
+        return max(r["hbm_bytes_per_launch"] for r in rows), os.path.relpath(f, ROOT) if f.startswith(ROOT) else f
     return None, None
+
+
+def provenance():
+    """what produced this line: the library that was loaded (path, hash of the file, digest of its three big kernels' sources, the
+    commit it was built at), this script's hash and -- where the tree is a repository -- its commit"""
+    from keras_nerf_amd import _lib
+    from keras_nerf_amd.build import file_sha16, git_head
+    info = _lib.build_info()
+    return {"lib_sha16": info["lib_sha16"], "lib_path": info["lib_path"], "kernel_digest": info["kernel_digest"],
+            "git_head": git_head(), "git_head_at_build": info["git_head_at_build"], "bench_py_sha16": file_sha16(os.path.abspath(__file__))}
 
 
 def write_synthetic_dataset(root, wh, n=(100, 4, 4)):
@@ -433,7 +451,7 @@ def bench_fit(args, world, rank, wh, batch, chunks, desc, backend):
                           "fit_ms_per_step_with_skip_dead_tiles": skip_ms, "dead_tile_frac_that_epoch": dead_fit,
                           "fit_wall_s": wall, "fit_wall_rays_samples_per_s": world * per_step * steps * args.epochs / wall,
                           "epoch_end_s": [t["end"][e] - t["train_end"][e] for e in range(1, epochs)],
-                          "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1)}))
+                          "roofline": None, "cpu_baseline": None, **dist_fields(world, backend, 1), **provenance()}))
     if dist_on(world):
         torch.distributed.barrier()            # nobody is still reading when rank 0 removes the directory
     if rank == 0:
@@ -663,7 +681,7 @@ def run(args, world, rank, device_index, backend):
         else:
             roofline = {"bound": "mfma", "kernel": dom, "achieved": flop / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flop / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None}
-        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, bool(nerf._ctx.get_option("skip_dead_tiles_active")))
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, bool(nerf._ctx.get_option("skip_dead_tiles_active")), provenance()["kernel_digest"])
         if roofline["traffic"] is not None and per_launch_samples != chunk_samples:
             # the committed PMC summary profiles one-chunk launches (tools/kbench.py); this launch covers several chunks of the same tiles
             roofline["traffic"] *= per_launch_samples / chunk_samples
@@ -686,6 +704,12 @@ def run(args, world, rank, device_index, backend):
         roofline["step_frac_of_mfma_peak"] = roofline["step_train_tflops"] / MFMA_PEAK_TFLOPS
         roofline["step_executed_tflops"] = n_rays * samples_per_ray * TRAIN_FLOP_EXEC / (elapsed / args.steps) / 1e12
         roofline["step_executed_frac_of_mfma_peak"] = roofline["step_executed_tflops"] / MFMA_PEAK_TFLOPS
+        # the GOVERNING roofline of the path is MFMA on the algorithmic 3x-forward FLOP count of the whole step; the
+        # object around it describes the dominant KERNEL, which in this dataflow (saved bf16 activations) is bound by HBM
+        roofline = {"governing": {"bound": "mfma", "achieved": roofline["step_train_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": roofline["step_frac_of_mfma_peak"], "executed_frac": roofline["step_executed_frac_of_mfma_peak"],
+                                  "scope": "whole train step, algorithmic FLOPs (3 x forward of the 12 Dense layers as written) / step time"},
+                    **roofline}
         roofline["executed_note"] = ("all 12 Dense layers of both MLPs are trained (24 gradient tensors each); the three activation-free "
                                      "layers behind the trunk are evaluated as one composed 283x4 stage, an exact identity of the "
                                      "reference network (DESIGN.md 2.0), hence executed < algorithmic FLOPs")
@@ -734,7 +758,7 @@ def run(args, world, rank, device_index, backend):
                        "parallelism": f"dp{world}", "global_batch_images": batch * world},
             "roofline": roofline, "cpu_baseline": cpu, **dist_fields(world, backend, args.steps),
             "metrics_ms_per_step": metrics_ms, "metrics_clock": "hip events around the 3 metric launches, mean of 5 steps",
-            "options": opts, "dead_tile_frac": dead_frac, **comm, **selftest,
+            "options": opts, "dead_tile_frac": dead_frac, **comm, **selftest, **provenance(),
         }
         emit(json.dumps(out))
 

@@ -150,12 +150,17 @@ int knerf_zero_grads(knerf_ctx* ctx, void* stream);
  *                            = mean over m R rays times m / C; the fine sampler's random numbers are keyed by the ray's index in the
  *                            batch), so rendered outputs are bit-identical and accumulated gradients equal up to the order of fp32
  *                            sums.  4,096 rays need 8 GB of workspace here; if that cannot be allocated the caller's own chunk
- *                            size is used.  Off while "grad_diagnostics" is on (it counts the LAST chunk's gradient).
+ *                            size is used -- by knerf_render_batch too -- and remembered for that (ray_chunks, chunk count), so later
+ *                            calls do not fail the same allocation again ("merge_fallbacks", read-only: how often that happened).
+ *                            Off while "grad_diagnostics" is on (it counts the LAST chunk's gradient).
+ *   "workspace_limit_gb" >= 0 (default 0 = off; tests) a workspace request above it is answered like an exhausted device -- by a real
+ *                            failing hipMalloc -- so that the two fall-backs above can be exercised without filling the memory.
  *   "wgrad_group_max"   1..64, "wgrad_group_gb" >= 0: chunks per coarse weight-gradient launch of knerf_train_batch and the memory
  *                            budget of the workspaces that takes (defaults 4 and 40 GB; 1 or 0 = one launch per chunk).
  *   "wgrad_cost0".."wgrad_cost<n_layers>": relative cost per sample tile of the n_layers + 1 weight-gradient jobs (nine for the default shape) (workgroups are dealt out in that
  *                            proportion; tuning sweeps).
- * knerf_get_option also answers "skip_dead_tiles_active", "wgrad_group" (of the current workspaces) and "general_shape_path". */
+ * knerf_get_option also answers "skip_dead_tiles_active", "wgrad_group" (of the current workspaces), "general_shape_path" and
+ * "merge_fallbacks". */
 int knerf_set_option(knerf_ctx* ctx, const char* name, double value);
 int knerf_get_option(knerf_ctx* ctx, const char* name, double* value);
 /* running totals since the last reset: 32-sample tiles the dgrad launches found live / all tiles they covered (skip_dead_tiles

@@ -96,9 +96,32 @@ def load_path(path: str) -> C.CDLL:
     return lib
 
 
+def build_info(path: str = None) -> dict:
+    """What is inside the library at `path` (default: the one load() binds): {"lib_path", "lib_sha16", "kernel_digest",
+    "git_head_at_build"}.  kernel_digest (build.py: the source of the three big kernels + flags) comes from the record build.py
+    writes beside the library and is None when that record is missing or describes ANOTHER file (its lib_sha16 differs from the
+    file's): a digest is only as good as its tie to the binary."""
+    import json
+    from .build import file_sha16
+    path = os.path.abspath(path or LIB_PATH)
+    out = {"lib_path": os.path.relpath(path, os.path.dirname(_HERE)), "lib_sha16": file_sha16(path) if os.path.exists(path) else None,
+           "kernel_digest": None, "git_head_at_build": None}
+    try:
+        info = json.load(open(path + ".info.json"))
+    except (OSError, ValueError):
+        return out
+    if info.get("lib_sha16") == out["lib_sha16"]:
+        out["kernel_digest"] = info.get("kernel_digest"); out["git_head_at_build"] = info.get("git_head_at_build")
+    return out
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
+        if os.environ.get("KNERF_LIB"):          # an A/B build takes the product library's place: never silently
+            import logging
+            logging.warning("KNERF_LIB is set: keras_nerf_amd runs on %s instead of the product library %s", LIB_PATH,
+                            os.path.join(_HERE, "libknerf_hip.so"))
         _lib = load_path(LIB_PATH)
     return _lib

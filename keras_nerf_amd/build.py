@@ -29,11 +29,61 @@ SLICED = {"mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip"}
 N_BUILTIN_SHAPES = 14   # = kNumBuiltinShapes (csrc/layout.h static_asserts it); knerf_api.hip checks the total against KNERF_N_SHAPE_SLICES
 MAX_EXTRA_SHAPES = 36   # a build-time budget, not a limit of csrc/layout.h (one more instantiation of the three big kernels each)
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
+# the extra trunk shapes of the `xshape` build variant (tests/test_gpu_variants.py builds and checks it; __graft_entry__.build() keeps an
+# existing one up to date): round 4 added width 64 (8/4 and 4/2 are built in) and pos_emb_dir 5..8 (four head k-steps)
+XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3",
+           "6,3,64", "8,4,64,6,2", "8,4,256,10,8", "8,4,128,10,6"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]
 # -ffp-contract=off: the parity-critical fp32 arithmetic (ray points, sampler, compositing) must round like the
 # reference's separate mul/add ops; fused multiply-adds are written explicitly (__builtin_fmaf) where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+
+
+# what the three big kernels are compiled from (hipcc's own dependency files of mlp_fwd_s0.o / mlp_bwd_s0.o / wgrad_s0.o say so):
+# the digest of these files and of the compiler flags names the kernels' ISA -- a host-side edit (knerf_api.hip) does not change it
+KERNEL_FILES = ["mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "chain.h", "bwd_body.h", "wgrad_body.h", "kernels.h", "layout.h"]
+
+
+def kernel_digest(flags=None) -> str:
+    """16 hex digits naming the source of the three big kernels + the flags they are built with; recorded beside every library
+    (`<lib>.info.json`) and in every PMC summary (tools/pmc_report.py), so that bench.py quotes hardware counters only for the
+    kernels it actually ran"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_FILES:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(FLAGS if flags is None else flags).encode())
+    return h.hexdigest()[:16]
+
+
+def file_sha16(path: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    """the commit of the tree, or None where there is no repository (the GPU boxes get a snapshot without .git)"""
+    try:
+        r = subprocess.run(["git", "-C", os.path.dirname(HERE), "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10)
+        dirty = subprocess.run(["git", "-C", os.path.dirname(HERE), "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10)
+        return (r.stdout.strip() + ("+dirty" if dirty.stdout.strip() else "")) if r.returncode == 0 and r.stdout.strip() else None
+    except Exception:           # noqa: BLE001 -- no git here
+        return None
+
+
+def _write_info(lib: str, flags) -> None:
+    """<lib>.info.json: which kernels (kernel_digest of the sources it was built from) are inside WHICH file (sha of the library)"""
+    import json
+    import time
+    info = {"lib_sha16": file_sha16(lib), "kernel_digest": kernel_digest(flags), "git_head_at_build": git_head(),
+            "built_unix": int(time.time()), "flags": list(flags)}
+    with open(lib + ".info.json", "w") as f:
+        json.dump(info, f, indent=1)
 
 
 def _newer(a: str, b: str) -> bool:
@@ -184,6 +234,10 @@ def build(force: bool = False, verbose: bool = True, defines=(), variant: str = 
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         pchanged = True
+    if changed or not os.path.exists(lib + ".info.json"):
+        # (an up-to-date library without a record: every object is newer than its sources, so the sources as they are now are
+        # what it was built from)
+        _write_info(lib, flags)
     if pchanged or not os.path.exists(probe):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", probe, *pobjs, "-L" + HERE, "-l:" + os.path.basename(lib),
                "-Wl,-rpath,$ORIGIN"]

@@ -100,6 +100,10 @@ struct knerf_ctx {
     long long* h_diag = nullptr;        // pinned: [0] coarse, [1] fine non-zero count of the last chunk's gradient, [2] steps published
     bool plan_dirty = false;
     int group_cache_rays = 0, group_cache_chunks = 0, group_cache = 0;   // wgrad_group_for memo (hipMemGetInfo is a driver call)
+    // (ray_chunks, chunk count) whose MERGED launches did not fit in memory: later calls start from the caller's own chunks instead
+    // of failing the same allocation again (train / render); how often a merge was given up (option "merge_fallbacks", read-only)
+    int merge_fail_rays = 0, merge_fail_chunks = 0, rmerge_fail_rays = 0, rmerge_fail_chunks = 0, merge_fallbacks = 0;
+    double ws_limit_gb = 0.0;           // option "workspace_limit_gb" (tests): a workspace request above it meets a REAL failing hipMalloc
     // workspaces (grow-only).  Inference buffers (raw, w_c, t_f, img_tmp) follow the largest chunk seen by any call; the training
     // buffers (draw, act, mask, dz, tile lists) follow the largest TRAINING chunk and group only, so that rendering with a larger
     // ray_chunks does not re-size them.

@@ -116,12 +116,27 @@ template <class T> void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr
 // (draw, act / mask / dz, tile flags and lists) follow the largest TRAINING chunk and group: `group` coarse-pass regions followed
 // by one fine-pass region, so that one weight-gradient launch covers the coarse passes of a group of chunks
 // (launch_wgrad_tiles below).  A render with a larger ray_chunks therefore never re-sizes the training regions.
-int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group = 1) {
+// option "workspace_limit_gb": the out-of-memory paths of the callers (a merged launch or a wgrad group that does not fit) are taken
+// by a REAL failed hipMalloc -- same error code, same state of the runtime's last-error word -- without filling 288 GB first
+int over_limit(knerf_ctx* ctx, double bytes) {
+    if (ctx->ws_limit_gb <= 0 || bytes <= ctx->ws_limit_gb * 1e9) return KNERF_OK;
+    void* never = nullptr;
+    HIPCHK(hipMalloc(&never, (size_t)1 << 50));
+    (void)hipFree(never);
+    return KNERF_OK;
+}
+
+int ensure_ws_impl(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group) {
     const int Na = ctx->cfg.n_coarse + ctx->cfg.n_fine;
     if (ctx->generic) {          // general-shape path: one size for everything (its activations are forward buffers too)
         if (n_rays <= ctx->ws_rays && (!train || ctx->ws_train)) return KNERF_OK;
         const int R = n_rays > ctx->ws_rays ? n_rays : ctx->ws_rays;
         train = train || ctx->ws_train;
+        {
+            const double mp = (double)gen::padded_rows((long long)R * Na);
+            if (int r = over_limit(ctx, (double)R * Na * 20 + mp * 256 + 2.0 * ctx->gplan.act_elems_per_row * mp +
+                                            (train ? 2.0 * ctx->gplan.dz_elems_per_row * mp + (double)R * Na * 16 : 0.0))) return r;
+        }
         HIPCHK(hipStreamSynchronize(s));           // nothing enqueued earlier may still use the buffers that are freed below
         free_dev(ctx->raw); free_dev(ctx->draw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
         ctx->ws_rays = 0;
@@ -161,6 +176,14 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
     const bool grow_base = n_rays > ctx->ws_rays;
     const bool grow_train = train && (!ctx->ws_train || n_rays > ctx->ws_train_rays || group > ctx->ws_group);
     if (!grow_base && !grow_train) return KNERF_OK;
+    if (ctx->ws_limit_gb > 0) {
+        const int Rt = n_rays > ctx->ws_train_rays ? n_rays : ctx->ws_train_rays;
+        const size_t tl = group == 1 ? tiles_for((long long)Rt * Na) : (size_t)group * tiles_for((long long)Rt * ctx->cfg.n_coarse) + tiles_for((long long)Rt * Na);
+        const double base_b = grow_base ? (double)n_rays * Na * 20 + (double)n_rays * (ctx->cfg.n_coarse * 4 + 32) : 0.0;
+        const double train_b = grow_train ? (double)Rt * Na * 16 + (double)saved_region_bytes(tl, ctx->si.act_blocks) +
+                                                (double)saved_region_bytes(tl, ctx->si.mask_blocks) + (double)saved_region_bytes(tl, ctx->si.dz_blocks) : 0.0;
+        if (int r = over_limit(ctx, base_b + train_b)) return r;
+    }
     HIPCHK(hipStreamSynchronize(s));               // nothing enqueued earlier may still use the buffers that are freed below
     if (grow_base) {
         free_dev(ctx->raw); free_dev(ctx->w_c); free_dev(ctx->t_f); free_dev(ctx->img_tmp);
@@ -200,6 +223,15 @@ int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group =
         ctx->ws_train = true; ctx->ws_train_rays = R; ctx->ws_group = group;
     }
     return KNERF_OK;
+}
+
+// A failed hipMalloc stays behind as the runtime's LAST ERROR: every launch helper ends in `return hipGetLastError()`, so the first
+// kernel after a failed allocation would report hipErrorOutOfMemory although the caller's retry at a smaller size succeeded
+// (ADVICE r05).  The word is read -- which clears it -- here, where the failure is already on its way to the caller as a status.
+int ensure_ws(knerf_ctx* ctx, int n_rays, bool train, hipStream_t s, int group = 1) {
+    const int r = ensure_ws_impl(ctx, n_rays, train, s, group);
+    if (r) (void)hipGetLastError();
+    return r;
 }
 
 // kernel classes reported by knerf_profile_read
@@ -698,7 +730,16 @@ int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float
     // per-ray work only: bit-identical outputs.  Rendering keeps no saved tensors (5 KB of workspace per ray on the fused path), so its
     // launches may be far larger than a training step's: 65,536 rays by default ("merge_render_rays"; a 256 x 256 frame in ONE set
     // of launches is 4 % faster than in sixteen); the general-shape path's activations stay in memory, it keeps the training limit
-    ray_chunks *= merge_factor(ctx->generic ? ctx->merge_rays : ctx->merge_render_rays, ray_chunks, n_rays / ray_chunks);
+    // ... and `ray_chunks` stays the reference's memory knob: merged launches that do not fit fall back to the caller's own chunks
+    // (remembered per (ray_chunks, chunk count), so that later frames do not fail the same allocation again)
+    const int user_chunks = ray_chunks, user_n = n_rays / ray_chunks;
+    int m = merge_factor(ctx->generic ? ctx->merge_rays : ctx->merge_render_rays, ray_chunks, user_n);
+    if (m > 1 && ctx->rmerge_fail_rays == user_chunks && ctx->rmerge_fail_chunks == user_n) m = 1;
+    if (m > 1 && ensure_ws(ctx, user_chunks * m, false, (hipStream_t)stream)) {
+        ctx->rmerge_fail_rays = user_chunks; ctx->rmerge_fail_chunks = user_n; ++ctx->merge_fallbacks;
+        m = 1;
+    }
+    ray_chunks = user_chunks * m;
     for (int i = 0; i < n_rays / ray_chunks; ++i) {
         const size_t r0 = (size_t)i * ray_chunks;
         if (int r = knerf_render_chunk(ctx, stream, o + r0 * 3, d + r0 * 3, t + r0 * Nc, u ? u + r0 * Nf : nullptr, seed, (uint64_t)r0,
@@ -737,6 +778,7 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
     // zero-gradient diagnostics count the LAST chunk's gradient (nerf.py:430-451): that chunk's launches must be its own
     int merge = ctx->grad_diag ? 1 : merge_factor(ctx->merge_rays, ray_chunks, n_rays / ray_chunks);
     const int user_chunks = ray_chunks;
+    if (merge > 1 && ctx->merge_fail_rays == user_chunks && ctx->merge_fail_chunks == n_rays / user_chunks) merge = 1;   // did not fit last time
     int C = 0, G = 1;
     for (;;) {
         ray_chunks = user_chunks * merge;
@@ -751,6 +793,7 @@ int knerf_train_batch(knerf_ctx* ctx, void* stream, const float* o, const float*
         if (!r) break;
         if (merge == 1) return r;
         merge = 1;                                                  // the merged launches did not fit either: the caller's own chunks
+        ctx->merge_fail_rays = user_chunks; ctx->merge_fail_chunks = n_rays / user_chunks; ++ctx->merge_fallbacks;
     }
     const size_t tc = tiles_for((long long)ray_chunks * Nc);
     const bool skip = skipping(ctx);
@@ -849,10 +892,13 @@ int knerf_set_option(knerf_ctx* ctx, const char* name, double value) {
         ctx->skip_dead = value != 0;               // ignored where it does not apply (general-shape path, sample counts not multiples of 32)
     } else if (n == "merge_chunk_rays") {
         if (value < 0 || value > 1048576) return fail(ctx, KNERF_ERR_INVALID, "merge_chunk_rays: 0..1048576");
-        ctx->merge_rays = (int)value;
+        ctx->merge_rays = (int)value; ctx->merge_fail_rays = 0; if (ctx->generic) ctx->rmerge_fail_rays = 0;
     } else if (n == "merge_render_rays") {
         if (value < 0 || value > 1048576) return fail(ctx, KNERF_ERR_INVALID, "merge_render_rays: 0..1048576");
-        ctx->merge_render_rays = (int)value;
+        ctx->merge_render_rays = (int)value; ctx->rmerge_fail_rays = 0;
+    } else if (n == "workspace_limit_gb") {      // tests: workspace requests above it fail like an exhausted device (0 = off)
+        if (value < 0) return fail(ctx, KNERF_ERR_INVALID, "workspace_limit_gb: >= 0");
+        ctx->ws_limit_gb = value; ctx->merge_fail_rays = ctx->rmerge_fail_rays = 0; ctx->group_cache = 0;
     } else if (n == "wgrad_group_max") {
         if (value < 1 || value > 64) return fail(ctx, KNERF_ERR_INVALID, "wgrad_group_max: 1..64");
         ctx->wgrad_group_max = (int)value; ctx->group_cache = 0;
@@ -878,6 +924,8 @@ int knerf_get_option(knerf_ctx* ctx, const char* name, double* value) {
     else if (n == "wgrad_group_max") *value = ctx->wgrad_group_max;
     else if (n == "merge_chunk_rays") *value = ctx->merge_rays;
     else if (n == "merge_render_rays") *value = ctx->merge_render_rays;
+    else if (n == "workspace_limit_gb") *value = ctx->ws_limit_gb;
+    else if (n == "merge_fallbacks") *value = ctx->merge_fallbacks;
     else if (n == "wgrad_group_gb") *value = ctx->wgrad_group_gb;
     else if (n == "wgrad_group") *value = ctx->ws_train ? ctx->ws_group : 0;            // chunks per coarse wgrad launch of the current workspaces
     else if (n == "general_shape_path") *value = ctx->generic;

@@ -214,6 +214,18 @@ class KnerfContext:
         from . import build as B
         variant = "auto_" + spec.replace(",", "_")
         lock_path = os.path.join(os.path.dirname(os.path.abspath(B.__file__)), f".build_{variant}.lock")
+        import torch.distributed as dist
+        built = os.path.join(os.path.dirname(os.path.abspath(B.__file__)), f"libknerf_hip_{variant}.so")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # N ranks behind one file lock, two minutes of hipcc each turn, inside the process group's time-outs: not from a rank of a
+            # running job.  A library built earlier (one process, before the job) is loaded as it is; otherwise the general-shape path.
+            if not os.path.exists(built):
+                logging.warning("KNERF_AUTO_BUILD: not compiling shape %s from rank %d of a %d-rank job (it runs on the general-shape kernels); "
+                                "build it once beforehand: `python keras_nerf_amd/build.py --variant=%s --add-shape=%s`",
+                                spec, dist.get_rank(), dist.get_world_size(), variant, spec)
+                return
+            path = built
+            return self._adopt_library(path, spec)
         logging.warning("KNERF_AUTO_BUILD: building the fused kernels for shape %s (hipcc, a few minutes the first time)", spec)
         try:
             with open(lock_path, "w") as lock:
@@ -225,6 +237,10 @@ class KnerfContext:
         except Exception as e:                     # noqa: BLE001 -- no hipcc on this machine, a read-only tree, a shape that spills ...
             logging.warning("KNERF_AUTO_BUILD: building shape %s failed (%s: %s); it runs on the general-shape kernels", spec, type(e).__name__, e)
             return
+        self._adopt_library(path, spec)
+
+    def _adopt_library(self, path: str, spec: str):
+        """re-create this context on the library at `path` (a build that holds shape `spec` for the fused kernels)"""
         self.lib.knerf_destroy(self._ctx)
         self._ctx = C.c_void_p()
         self.lib = _lib.load_path(path)

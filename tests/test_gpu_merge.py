@@ -103,3 +103,42 @@ def test_eager_diagnostics_keep_the_callers_chunks():
         counts.append(tuple(ctx.grad_diagnostics(wait=True)[:2]))
         ctx.close()
     assert counts[0] == counts[1] and counts[0][0] > 0
+
+
+def test_merged_launches_that_do_not_fit_fall_back_to_the_callers_chunks_and_the_step_succeeds():
+    """`ray_chunks` is the reference's memory knob (nerf.py:95-100).  When the merged workspace cannot be allocated
+    knerf_train_batch retries with the caller's own chunk size -- and the failed hipMalloc must not survive as the runtime's last
+    error (every launch helper ends in hipGetLastError(): the first kernel after it would report out-of-memory although the retry
+    succeeded).  Forced here by option workspace_limit_gb, which answers an over-limit request with a REAL failing hipMalloc: the
+    step succeeds, equals the never-merged step bit for bit (deterministic mode), the failure is remembered (one fall-back for two
+    steps), and the render path does the same."""
+    P = make_problem(n_images=3, wh=16, weight_scale=1.5, bias_std=0.05)
+    o, d, t, img, u = _data(P, 768)
+    res = {}
+    for name, opts in (("plain", dict(merge_chunk_rays=0, merge_render_rays=0)), ("fallback", dict(workspace_limit_gb=0.4))):
+        ctx = _ctx(P, deterministic=1, **opts)
+        outs = []
+        for _ in range(2):
+            loss = torch.zeros(2, device="cuda"); ci = torch.empty((768, 3), device="cuda"); fi = torch.empty((768, 3), device="cuda")
+            ctx.zero_grads()
+            ctx.train_batch(o, d, t, img, u, ray_chunks=64, loss=loss, c_image=ci, f_image=fi)      # 768 rays merged: ~1.5 GB; 64 rays: ~0.13 GB
+            torch.cuda.synchronize()
+            outs.append((ctx.grads_view().cpu().numpy().copy(), loss.cpu().numpy().copy(), ci.clone(), fi.clone()))
+        if name == "fallback":
+            assert ctx.get_option("merge_fallbacks") == 1.0                   # the second step did not try the merged size again
+            assert ctx.get_option("merge_chunk_rays") == 4096.0
+        if name == "fallback":                                                # rendering keeps no saved tensors: 768 rays are 3.2 MB, 64 rays 0.3 MB
+            ctx.set_option("workspace_limit_gb", 0.002)
+        rend = ctx.render_batch(o, d, t, u, seed=11, ray_chunks=64)
+        rend2 = ctx.render_batch(o, d, t, u, seed=11, ray_chunks=64)
+        torch.cuda.synchronize()
+        if name == "fallback":
+            assert ctx.get_option("merge_fallbacks") == 2.0                   # + ONE for the two renders
+        res[name] = (outs, rend, rend2)
+        ctx.close()
+    for k in range(2):
+        a, b = res["plain"][0][k], res["fallback"][0][k]
+        assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for key, v in res["plain"][1].items():
+        assert torch.equal(v, res["fallback"][1][key]) and torch.equal(v, res["fallback"][2][key]), key

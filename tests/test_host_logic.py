@@ -331,6 +331,66 @@ def test_bench_quotes_pmc_traffic_of_the_instantiation_it_ran_only():
     assert b.pmc_traffic("composite", True) == (None, None)
 
 
+def test_bench_refuses_counters_of_other_kernels_and_names_its_binary(tmp_path):
+    """(c) a PMC summary is quoted only when its recorded `_kernel_digest` (source of the three big kernels +
+    flags, keras_nerf_amd/build.py) equals that of the library the process loaded -- a summary without a digest, one of an edited
+    kernel, or a library whose record describes another file gives `traffic: null`; (b) the line's provenance names the binary."""
+    import importlib.util
+    import json
+    import os
+    import shutil
+    from keras_nerf_amd import _lib, build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("knerf_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    row = {"wgrad_kernel<Shape<8, 4, 256>, 1, true> grid=65536": {"hbm_bytes_per_launch": 6.2e9}}
+    good = B.kernel_digest()
+    for name, digest in (("r01_pmc_traffic_old.json", None), ("r02_pmc_traffic_edited.json", "0123456789abcdef")):
+        rep = {"_layout": b.LAYOUT_TAG, "_options": {"skip_dead_tiles": 1}, **row}
+        if digest:
+            rep["_kernel_digest"] = digest
+        json.dump(rep, open(tmp_path / name, "w"))
+    assert b.pmc_traffic("wgrad_fine", True, good, str(tmp_path)) == (None, None)          # nothing of THESE kernels: no number
+    assert b.pmc_traffic("wgrad_fine", True, None, str(tmp_path)) == (None, None)          # a library without a valid record: no number
+    json.dump({"_layout": b.LAYOUT_TAG, "_options": {"skip_dead_tiles": 1}, "_kernel_digest": good,
+               "wgrad_kernel<Shape<8, 4, 256>, 1, true> grid=65536": {"hbm_bytes_per_launch": 6.1e9}}, open(tmp_path / "r00_pmc_traffic_mine.json", "w"))
+    val, src = b.pmc_traffic("wgrad_fine", True, good, str(tmp_path))                      # an OLDER file name, but the right kernels
+    assert val == 6.1e9 and src.endswith("r00_pmc_traffic_mine.json")
+    # the digest follows the kernel sources and the flags, not the host code
+    assert len(good) == 16 and B.kernel_digest(B.FLAGS + ["-DKNERF_MASK_LAYOUT=1"]) != good
+    assert "knerf_api.hip" not in B.KERNEL_FILES and {"wgrad_body.h", "chain.h", "layout.h"} <= set(B.KERNEL_FILES)
+    # build_info: the record beside a library counts only while it describes THAT file
+    lib = tmp_path / "libfake.so"
+    lib.write_bytes(b"\x7fELF one build")
+    B._write_info(str(lib), B.FLAGS)
+    info = _lib.build_info(str(lib))
+    assert info["kernel_digest"] == good and info["lib_sha16"] == B.file_sha16(str(lib))
+    lib.write_bytes(b"\x7fELF another build")                                              # re-linked, record not renewed
+    stale = _lib.build_info(str(lib))
+    assert stale["kernel_digest"] is None and stale["lib_sha16"] != info["lib_sha16"]
+    if os.path.exists(_lib.LIB_PATH):                                                      # the product library of this tree carries its record
+        prov = b.provenance()
+        assert prov["lib_sha16"] == B.file_sha16(_lib.LIB_PATH) and prov["bench_py_sha16"] == B.file_sha16(os.path.join(root, "bench.py"))
+        assert prov["kernel_digest"] == good, "libknerf_hip.so was not built from the kernel sources of this tree: run keras_nerf_amd/build.py"
+
+
+def test_knerf_lib_override_is_announced(monkeypatch, caplog):
+    """KNERF_LIB swaps the product binary for an A/B build (tools/kbench.py): never silently"""
+    import importlib
+    import logging
+    from keras_nerf_amd import _lib
+    monkeypatch.setenv("KNERF_LIB", "/nonexistent/libknerf_hip_variant.so")
+    fresh = importlib.reload(_lib)
+    try:
+        with caplog.at_level(logging.WARNING):
+            with pytest.raises(fresh.KnerfError):
+                fresh.load()
+        assert any("KNERF_LIB is set" in r.getMessage() and "/nonexistent/libknerf_hip_variant.so" in r.getMessage() for r in caplog.records)
+    finally:
+        monkeypatch.delenv("KNERF_LIB")
+        importlib.reload(_lib)
+
+
 def test_zero_gradient_messages_are_the_references(caplog):
     """nerf.py:430-451: the three log lines, their levels, and 'once per published step' -- the host side of the device-side count,
     driven by a stand-in context (the GPU test drives the real one)."""
