@@ -8,7 +8,7 @@ libknerf_probe.so  diagnostics for tests/ and tools/ (include/knerf_debug.h): la
 
 --add-shape (or KNERF_ADD_SHAPES="NL,SK,U;NL,SK,U,LX,LD" in the environment): further NeRF(n_layers, skip_layer, dense_units [, pos_emb_xyz,
 pos_emb_dir]) shapes for the fused kernels beside the built-in list of csrc/layout.h (dense_units 256, 128 or 64; encodings: the reference's
-10 / 4 unless given, pos_emb_dir <= 8); three more hipcc runs and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
+10 / 4 unless given, pos_emb_dir <= 8; since round 6 also trunks that end in a concat, e.g. 9,4,256); three more hipcc runs and about 1 MB of library each.  Shapes not in the list still work: they run on the general-shape kernels.
 """
 from __future__ import annotations
 
@@ -31,8 +31,9 @@ MAX_EXTRA_SHAPES = 36   # a build-time budget, not a limit of csrc/layout.h (one
 PROBE_SOURCES = ["debug_api.hip", "probe.hip"]
 # the extra trunk shapes of the `xshape` build variant (tests/test_gpu_variants.py builds and checks it; __graft_entry__.build() keeps an
 # existing one up to date): round 4 added width 64 (8/4 and 4/2 are built in) and pos_emb_dir 5..8 (four head k-steps)
+# round 6: a concat behind the LAST trunk layer ((n_layers - 1) % skip_layer == 0): the head takes [h ; xyz_enc ; dir_enc]
 XSHAPES = ["6,3,128", "8,2,128", "8,4,256,6,2", "8,4,256,12,4", "8,4,128,5,1", "4,2,256,16,3",
-           "6,3,64", "8,4,64,6,2", "8,4,256,10,8", "8,4,128,10,6"]
+           "6,3,64", "8,4,64,6,2", "8,4,256,10,8", "8,4,128,10,6", "9,4,256", "5,2,128", "5,4,64,6,2"]
 HEADERS = ["chain.h", "ctx.h", "kernels.h", "layout.h", "bwd_body.h", "wgrad_body.h", "generic.h", os.path.join("..", "..", "include", "knerf.h"),
            os.path.join("..", "..", "include", "knerf_debug.h")]
 # -ffp-contract=off: the parity-critical fp32 arithmetic (ray points, sampler, compositing) must round like the
@@ -106,9 +107,9 @@ def parse_shapes(specs) -> list:
                 raise ValueError(f"--add-shape wants n_layers,skip_layer,dense_units[,pos_emb_xyz,pos_emb_dir], got {item!r}")
             nl, sk, u = v[:3]
             lx, ld = v[3:] if len(v) == 5 else (10, 4)
-            if u not in (64, 128, 256) or not 3 <= nl <= 16 or sk < 1 or (nl - 1) % sk == 0 or not 1 <= lx <= 16 or not 1 <= ld <= 8:
+            if u not in (64, 128, 256) or not 3 <= nl <= 16 or sk < 1 or not 1 <= lx <= 16 or not 1 <= ld <= 8:
                 raise ValueError(f"shape {item!r} is not one the fused kernels cover: dense_units 64, 128 or 256, 3 <= n_layers <= 16, "
-                                 f"no concat behind the last layer ((n_layers - 1) % skip_layer != 0), 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 8")
+                                 f"skip_layer >= 1, 1 <= pos_emb_xyz <= 16, 1 <= pos_emb_dir <= 8")
             if u == 256 and lx == 16 and ld >= 5:
                 # measured (round 5 compile sweep): eight encoding k-steps AND four direction k-steps at width 256 need 12 bytes of
                 # scratch per lane in the training forward -- the spill check below would refuse the object after a minute of hipcc

@@ -153,9 +153,10 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // and bias behind the parameters; expand turns the wgrad head job's aux sums into the gradients of features, rgb_features
 // and rgb (added to grad, aux zeroed).
 // trunk_params = layout.h Shape::kTrunkParams: the offset of the sigma kernel in the flat parameter vector; units = the trunk width
-// dir_dim / dir_slots = width of the direction encoding (27) and its slots in the composed head (32): layout.h ShapeInfo
-hipError_t launch_head_compose(float* w0, float* w1 /* may be null */, int trunk_params, int units, int dir_dim, int dir_slots, hipStream_t stream);   // one workgroup per net
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int dir_dim, int dir_slots,
+// dir_dim / dir_slots = width of the direction encoding (27) and its slots in the composed head (32); trunk_x / trunk_x_slots = the same for
+// xyz_enc in the trunk's output (63 / 64 when the reference concatenates behind the last layer, else 0 / 0): layout.h ShapeInfo
+hipError_t launch_head_compose(float* w0, float* w1 /* may be null */, int trunk_params, int units, int trunk_x, int trunk_x_slots, int dir_dim, int dir_slots, hipStream_t stream);   // one workgroup per net
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int trunk_x, int trunk_x_slots, int dir_dim, int dir_slots,
                               hipStream_t stream);
 
 struct RayGenArgs {

@@ -80,7 +80,7 @@ int repack(knerf_ctx* ctx, int n, hipStream_t s, bool compose = true) {
         HIPCHK(gen::pack_weights(ctx->gplan, N.w, ctx->gnet[n], s));
         return KNERF_OK;
     }
-    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
+    if (compose) HIPCHK(launch_head_compose(N.w, nullptr, ctx->si.trunk_params, ctx->si.units, ctx->si.trunk_x, ctx->si.trunk_x_slots, ctx->si.dir_dim, ctx->si.dir_slots, s));   // the composed head behind the parameters (layout.h), then the bf16 streams
     HIPCHK(launch_pack(N.w, ctx->tab.d_fwd, reinterpret_cast<unsigned short*>(N.fwd_stream), (size_t)ctx->si.fwd_blocks * 512, s));
     HIPCHK(launch_pack(N.w, ctx->tab.d_bwd, reinterpret_cast<unsigned short*>(N.bwd_stream), (size_t)ctx->si.bwd_blocks * 512, s));
     HIPCHK(launch_gather_f32(N.w, ctx->tab.d_bias, N.bias, (size_t)ctx->si.fwd_bias_tiles * 32, s));
@@ -400,7 +400,7 @@ int expand_head_grads(knerf_ctx* ctx, hipStream_t s) {
         for (int n = 0; n < 2; ++n) HIPCHK(gen::expand_head(ctx->gplan, ctx->gnet[n], ctx->net[n].w, ctx->net[n].g, s));
         return KNERF_OK;
     }
-    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));
+    HIPCHK(launch_head_expand(ctx->net[0].w, ctx->net[0].aux, ctx->net[0].g, ctx->net[1].w, ctx->net[1].aux, ctx->net[1].g, ctx->si.trunk_params, ctx->si.units, ctx->si.trunk_x, ctx->si.trunk_x_slots, ctx->si.dir_dim, ctx->si.dir_slots, s));
     return KNERF_OK;
 }
 
@@ -853,7 +853,7 @@ int knerf_apply_adam(knerf_ctx* ctx, void* stream) {
         a.lr_t = ctx->d_lr_t; a.b1 = ctx->cfg.beta1; a.b2 = ctx->cfg.beta2; a.eps = ctx->cfg.epsilon; a.nonfinite = ctx->d_flag;
         HIPCHK(launch_adam(a, s));
     }
-    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, ctx->si.trunk_params, ctx->si.units, ctx->si.dir_dim, ctx->si.dir_slots, s));      // both nets' heads in one launch
+    if (!ctx->generic) HIPCHK(launch_head_compose(ctx->net[0].w, ctx->net[1].w, ctx->si.trunk_params, ctx->si.units, ctx->si.trunk_x, ctx->si.trunk_x_slots, ctx->si.dir_dim, ctx->si.dir_slots, s));      // both nets' heads in one launch
     for (int n = 0; n < 2; ++n)
         if (int r = repack(ctx, n, s, false)) return r;
     HIPCHK(launch_step_status(ctx->d_flag, ctx->h_status, ctx->d_step, ctx->d_lr_t, AdamHyper{ctx->cfg.lr, ctx->cfg.beta1, ctx->cfg.beta2}, s));

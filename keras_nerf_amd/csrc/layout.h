@@ -24,13 +24,16 @@ namespace knerf {
 
 constexpr int kLx = 10, kLd = 4;               // the reference's defaults (nerf.py:11-14): 63-d / 27-d encodings
 constexpr int kMaxLd = 8;                      // largest pos_emb_dir of a fused shape: 51-d direction encoding, four head k-steps (kAuxS, optim.hip)
+constexpr int kMaxLx = 16;                     // largest pos_emb_xyz: 99-d position encoding, eight k-steps
 
 // ---- trunk shape ---------------------------------------------------------------------------------------------------------
 // The fused kernels cover NeRFMLP(n_layers = NL, dense_units = 256, skip_layer = SK) with 63-d / 27-d encodings (mlp.py:5-50):
 // layer l (l >= 2) takes [h_{l-1} ; xyz_enc] when the reference concatenated behind layer l-1, i.e. (l-1) % SK == 0 (mlp.py:36-38).
 // Shape<8, 4> is the reference's default and the shape every number in DESIGN.md is quoted for; the other instantiations
 // (knerf_api.hip kFusedShapes) share every line of kernel code with it.  Not covered (-> general-shape path, generic.hip): other
-// widths, fewer than 3 layers, a concat behind the LAST layer (the head would take [h ; xyz_enc ; dir_enc]).
+// widths, fewer than 3 layers.  A concat behind the LAST layer ((NL - 1) % SK == 0: 9 / 4, 5 / 4, 5 / 2, 7 / 3 ...; mlp.py:36-38 has no
+// "not the last layer" condition) makes the trunk output [h ; xyz_enc]: the sigma and features kernels have U + kXyzDim rows and the
+// composed head takes [h ; xyz_enc ; dir_enc] (round 6: kTrunkX / kTrunkXQ below).
 // ShapeImpl carries every constant; Shape<NL, SK, U> = the reference's encodings (the names the built-in kernels are mangled with),
 // ShapeL<NL, SK, U, LX, LD> = other positional-encoding depths (NeRF(pos_emb_xyz=LX, pos_emb_dir=LD), build-time entries only).
 template <int NL_, int SK_, int U_, int LX_, int LD_>
@@ -44,8 +47,11 @@ struct ShapeImpl {
     static constexpr int kEncQ = enc_q(LX), kDirQ = enc_q(LD);          // 4 and 2 for the reference's L = 10 / 4
     static constexpr bool concat_in(int l) { return l >= 2 && l < NL && (l - 1) % SK == 0; }
     static constexpr bool kConcatBehindLast = (NL - 1) % SK == 0 && NL - 1 > 0;
-    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && !kConcatBehindLast && (U == 256 || U == 128 || U == 64) &&
-                                       LX >= 1 && LX <= 16 && LD >= 1 && LD <= kMaxLd;  // LD: the head accumulator holds U + 3 + 6 LD rows (kAuxS)
+    // the trunk's output behind its last layer: h, and xyz_enc once more when the reference concatenates behind that layer too
+    static constexpr int kTrunkX = kConcatBehindLast ? kXyzDim : 0, kTrunkXQ = kConcatBehindLast ? kEncQ : 0;   // extra rows / head k-steps
+    static constexpr int kTrunkOut = U + kTrunkX;            // rows of the sigma and features kernels (mlp.py:19-22 built on the concat)
+    static constexpr bool kSupported = NL >= 3 && NL <= 16 && SK >= 1 && (U == 256 || U == 128 || U == 64) &&
+                                       LX >= 1 && LX <= kMaxLx && LD >= 1 && LD <= kMaxLd;  // LX, LD: the head accumulator holds U + 99 + 51 rows (kAuxS)
     static constexpr int first_concat() { for (int l = 2; l < NL; ++l) if (concat_in(l)) return l; return 0; }
     static constexpr int kFirstConcat = first_concat();
     // flat fp32 parameter buffer: Keras trainable_variables order (mlp.py:11-27), kernel[in,out] row-major + bias; behind the trunk
@@ -54,10 +60,11 @@ struct ShapeImpl {
     static constexpr int trunk_params() { int n = 0; for (int l = 0; l < NL; ++l) n += fan_in(l) * U + U; return n; }
     static constexpr int kTrunkParams = trunk_params();      // = offset of the sigma kernel
     static constexpr int kHeadReal = U + kDirDim;            // rows of the rgb_features kernel = real rows of the composed head matrix
-    static constexpr int kParamCount = kTrunkParams + (U + 1) + (U * U + U) + (kHeadReal * (U / 2) + U / 2) + ((U / 2) * 3 + 3);
+    static constexpr int kParamCount = kTrunkParams + (kTrunkOut + 1) + (kTrunkOut * U + U) + (kHeadReal * (U / 2) + U / 2) + ((U / 2) * 3 + 3);
+    static constexpr int kHeadMatReal = kTrunkOut + kDirDim;  // real rows of the COMPOSED head matrix: h, [xyz_enc,] dir_enc
     // forward stream: stage st = trunk layer st (st < NL) or the head (st == NL); order: stage, out tile, k-step
     static constexpr int kFwdStages = NL + 1;
-    static constexpr int fwd_nks(int st) { return st == 0 ? kEncQ : st == NL ? kKs + kDirQ : (concat_in(st) ? kKs + kEncQ : kKs); }
+    static constexpr int fwd_nks(int st) { return st == 0 ? kEncQ : st == NL ? kKs + kTrunkXQ + kDirQ : (concat_in(st) ? kKs + kEncQ : kKs); }
     static constexpr int fwd_not(int st) { return st == NL ? 1 : kOt; }
     static constexpr int fwd_b0(int st) { int n = 0; for (int q = 0; q < st; ++q) n += fwd_nks(q) * fwd_not(q); return n; }
     static constexpr int kFwdBlocks = fwd_b0(NL + 1);
@@ -73,11 +80,13 @@ struct ShapeImpl {
     // saved runs (see "saved tensors" below).  act: [h0] h1 .. h_{NL-1} (kKs blocks each), the 4 enc blocks directly behind
     // h_{c-1} for the FIRST concat layer c (its weight-gradient job then reads ONE contiguous range; later concat layers read two), in
     // front of everything when there is no concat layer, and the 2 dir blocks at the end, directly behind h_{NL-1} (the head job's
-    // range).  dz: dz_0 .. dz_{NL-1} (kKs each), dz_head (2).
+    // range) -- with a SECOND copy of the enc blocks between the two when the head takes [h ; xyz_enc ; dir_enc] (kActHeadEnc: the head
+    // job still reads one contiguous range).  dz: dz_0 .. dz_{NL-1} (kKs each), dz_head (2).
     static constexpr int kFirstSaved = kSaveH0 ? 0 : 1;
     static constexpr int kActEnc = kFirstConcat ? kKs * (kFirstConcat - kFirstSaved) : 0;
     static constexpr int act_h(int l) { return kKs * (l - kFirstSaved) + ((kFirstConcat == 0 || l >= kFirstConcat) ? kEncQ : 0); }   // l = kFirstSaved .. NL-1
-    static constexpr int kActDir = kKs * (NL - kFirstSaved) + kEncQ, kActBlocks = kActDir + kDirQ;
+    static constexpr int kActHeadEnc = kKs * (NL - kFirstSaved) + kEncQ;      // = act_h(NL - 1) + kKs
+    static constexpr int kActDir = kActHeadEnc + kTrunkXQ, kActBlocks = kActDir + kDirQ;
     static constexpr int kDzHead = kKs * NL, kDzBlocks = kDzHead + 2;
     // dz of the last trunk layer is mask * (H dz_head) with 4 input channels: at width 256 its weight-gradient job recomputes it
     // (wgrad_body.h wgrad_last_recompute) and dgrad does not write it -- unless that layer takes [h ; xyz_enc] (then the job is the
@@ -85,8 +94,9 @@ struct ShapeImpl {
     static constexpr bool kSaveLastDz = concat_in(NL - 1) || U != 256;
     static constexpr int kMaskBlocks = NL;                   // relu masks: one 1 KiB block per trunk layer per tile (16 B per lane = 128 bits)
     static constexpr int kWgradJobs = NL + 1, kHeadJob = NL; // job j = trunk layer j; the last one = the head
-    // collapsed head (below): U h features + 16 kDirQ dir slots (32, 27 of them real, for LD = 4)
-    static constexpr int kHeadRows = U + 16 * kDirQ;
+    // collapsed head (below): U h features [+ 16 kEncQ xyz slots] + 16 kDirQ dir slots (32, 27 of them real, for LD = 4); the matrix
+    // is stored by REAL row (kHeadMatReal of them), the slot count only sizes its region
+    static constexpr int kHeadRows = U + 16 * kTrunkXQ + 16 * kDirQ;
     static constexpr int kHeadOff = kParamCount;             // H[row][c], c = 0..2 rgb, 3 sigma
     static constexpr int kHeadBiasOff = kHeadOff + kHeadRows * 4;
     static constexpr int kExtParamCount = kHeadBiasOff + 4;  // floats in a net's weight buffer
@@ -155,7 +165,7 @@ inline std::vector<TensorInfo> tensor_table() {
     int off = 0;
     auto add = [&](int fi, int fo) { t.push_back({off, fi, fo}); off += fi * fo; t.push_back({off, 1, fo}); off += fo; };
     for (int l = 0; l < S::NL; ++l) add(S::fan_in(l), S::U);
-    add(S::U, 1); add(S::U, S::U); add(S::kHeadReal, S::U / 2); add(S::U / 2, 3);       // sigma, features, rgb_features, rgb
+    add(S::kTrunkOut, 1); add(S::kTrunkOut, S::U); add(S::kHeadReal, S::U / 2); add(S::U / 2, 3);       // sigma, features, rgb_features, rgb
     return t;
 }
 // index of a tensor in the table: trunk layer l -> l; then sigma, features, rgb_features, rgb
@@ -172,9 +182,10 @@ template <class S> constexpr int LSIG = S::NL;
 // packing tables address them like any other tensor.  The gradients of the six head tensors are recovered exactly (chain rule on
 // the same identity) from M = [h ; dir_enc]^T dz_rgb (283x3) and s = sum dz_rgb, which the wgrad head job accumulates
 // in an auxiliary buffer (optim.hip head_expand).
-// auxiliary gradient buffer of one net: M[row][c] (row = 0..U-1 h, then the 3 + 6 LD dir rows; c = 0..2), then s[c] at kAuxS (sized for U = 256, LD = kMaxLd)
-constexpr int kMaxDirDim = 3 + 6 * kMaxLd;                                     // 51
-constexpr int kAuxM = 0, kAuxS = (256 + kMaxDirDim) * 3, kAuxCount = 928;      // 921 + 3 sums, rounded up
+// auxiliary gradient buffer of one net: M[row][c] (row = 0..U-1 h, [then the 3 + 6 LX xyz rows of a trunk that ends in a concat,] then
+// the 3 + 6 LD dir rows; c = 0..2), then s[c] at kAuxS (sized for U = 256, LX = kMaxLx, LD = kMaxLd)
+constexpr int kMaxDirDim = 3 + 6 * kMaxLd, kMaxXyzDim = 3 + 6 * kMaxLx;        // 51, 99
+constexpr int kAuxM = 0, kAuxS = (256 + kMaxXyzDim + kMaxDirDim) * 3, kAuxCount = 1224;      // 1218 + 3 sums, rounded up
 
 // ---- slot maps: which reference feature sits in (k-step q, lane-half h, element j) of a B-operand block
 // encoded position: 64 slots (4 k-steps).  half 0: x, y, sin(2^i p_c);  half 1: z, pad, cos(2^i p_c).
@@ -211,14 +222,19 @@ struct PackTables {
     std::vector<int32_t> bwd;       // kBwdBlocks*512
 };
 
-// row of the head matrix for k-step ks of the HEAD stage: h features, then the dir encoding slots
+// row of the head matrix for k-step ks of the HEAD stage: h features, [the xyz encoding slots of a trunk that ends in a concat,] then
+// the dir encoding slots
 template <class S>
 inline int head_in_row(int ks, int h, int j) {
     if (ks < S::kKs) return hid_feature(ks, h, j);
-    const int e = enc_feature(ks - S::kKs, h, j, S::LD);
-    return e < 0 ? -1 : S::U + e;
+    if (ks < S::kKs + S::kTrunkXQ) {
+        const int e = enc_feature(ks - S::kKs, h, j, S::LX);
+        return e < 0 ? -1 : S::U + e;
+    }
+    const int e = enc_feature(ks - S::kKs - S::kTrunkXQ, h, j, S::LD);
+    return e < 0 ? -1 : S::kTrunkOut + e;
 }
-template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= S::kHeadReal || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
+template <class S> inline int hidx(int row, int c) { return (row < 0 || row >= S::kHeadMatReal || c < 0 || c > 3) ? -1 : S::kHeadOff + row * 4 + c; }
 
 // input feature (row of the layer's kernel) for forward stage `st` k-step `ks`, half h, element j
 template <class S>
@@ -350,7 +366,7 @@ template <class S>
 constexpr WgradJob wgrad_job(int j) {
     constexpr int K = S::kKs, T = S::kOt;
     if (j == 0) return {0, S::kActEnc, S::kActEnc, S::kEncQ / 2, 0, T, 0};
-    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), T + S::kDirQ / 2, S::kDzHead, 1, -1};   // [h ; dir] x (r,g,b,sigma): dir sits behind h
+    if (j == S::NL) return {5, S::act_h(S::NL - 1), S::act_h(S::NL - 1), T + (S::kTrunkXQ + S::kDirQ) / 2, S::kDzHead, 1, -1};   // [h ; (enc ;) dir] x (r,g,b,sigma): one range behind h
     if (j == 1 && !S::kSaveH0) return {1, S::kActEnc, S::kActEnc, T, K, T, 1};                        // h0 recomputed: the table rows are h0 features
     if (S::concat_in(j)) return {3, S::act_h(j - 1), S::kActEnc - K, T + S::kEncQ / 2, K * j, T, j};             // input tile T + k -> block act_blk2 + K + 2k
     if (j == S::NL - 1 && !S::kSaveLastDz) return {4, S::act_h(j - 1), S::act_h(j - 1), T, K * j, T, j};
@@ -381,7 +397,12 @@ inline int wgrad_in_row(int jb, int tr) {
     const int kind = wgrad_job<S>(jb).kind;
     if (kind == 0) return encrow(tr, S::LX);
     if (kind == 3) return tr < S::U ? tr : (encrow(tr - S::U, S::LX) < 0 ? -1 : S::U + encrow(tr - S::U, S::LX));
-    if (kind == 5) return tr < S::U ? tr : (encrow(tr - S::U, S::LD) < 0 ? -1 : S::U + encrow(tr - S::U, S::LD));
+    if (kind == 5) {
+        if (tr < S::U) return tr;
+        if (tr < S::U + 16 * S::kTrunkXQ) return encrow(tr - S::U, S::LX) < 0 ? -1 : S::U + encrow(tr - S::U, S::LX);
+        const int e = encrow(tr - S::U - 16 * S::kTrunkXQ, S::LD);
+        return e < 0 ? -1 : S::kTrunkOut + e;
+    }
     return tr;
 }
 // destination of wgrad output element (tile-row tr, column tc): index into the flat gradient, kAuxBase + index into the
@@ -394,7 +415,7 @@ inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) 
         if (tr == -2) return tc == 3 ? bidx(tt, LSIG<S>, 0) : S::kAuxBase + kAuxS + tc;
         const int row = wgrad_in_row<S>(jb, tr);
         if (row < 0) return -1;
-        if (tc == 3) return row < S::U ? kidx(tt, LSIG<S>, row, 0) : -1;
+        if (tc == 3) return row < S::kTrunkOut ? kidx(tt, LSIG<S>, row, 0) : -1;
         return S::kAuxBase + kAuxM + row * 3 + tc;
     }
     if (tr == -2) return bidx(tt, J.layer, tc);
@@ -404,6 +425,7 @@ inline int wgrad_dst(const std::vector<TensorInfo>& tt, int jb, int tr, int tc) 
 // ---- run-time view of a shape (host): what knerf_api.hip needs to size buffers and pick instantiations
 struct ShapeInfo {
     int id, n_layers, skip, units, lx, ld, dir_dim, dir_slots;
+    int trunk_x, trunk_x_slots;     // rows / slots of xyz_enc in the trunk's output (a concat behind the last layer), else 0
     int param_count, ext_param_count, trunk_params, head_off, head_bias_off;
     int fwd_blocks, fwd_bias_tiles, bwd_blocks;
     int act_blocks, dz_blocks, mask_blocks;
@@ -415,6 +437,7 @@ template <class S>
 inline ShapeInfo make_shape_info(int id) {
     ShapeInfo i{};
     i.id = id; i.n_layers = S::NL; i.skip = S::SK; i.units = S::U; i.lx = S::LX; i.ld = S::LD; i.dir_dim = S::kDirDim; i.dir_slots = 16 * S::kDirQ;
+    i.trunk_x = S::kTrunkX; i.trunk_x_slots = 16 * S::kTrunkXQ;
     i.param_count = S::kParamCount; i.ext_param_count = S::kExtParamCount; i.trunk_params = S::kTrunkParams;
     i.head_off = S::kHeadOff; i.head_bias_off = S::kHeadBiasOff;
     i.fwd_blocks = S::kFwdBlocks; i.fwd_bias_tiles = S::kFwdBiasTiles; i.bwd_blocks = S::kBwdBlocks;

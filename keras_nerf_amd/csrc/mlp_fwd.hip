@@ -56,13 +56,14 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, bf16x8 
 
 // store schedule of the SAVE variant: the kEncQ (4) enc blocks up front; per trunk layer 2 blocks behind every out tile (none for
 // layer_0 where h0 is not saved) and one mask block at its end, the kDirQ (2) dir blocks right behind the last trunk layer (counted as
-// that stage's end-of-stage stores); the head stage stores nothing
+// that stage's end-of-stage stores) -- preceded by a second copy of the kEncQ enc blocks when the head takes [h ; xyz_enc ; dir_enc]
+// (Shape::kTrunkXQ, a concat behind the last layer); the head stage stores nothing
 template <class S>
 constexpr StoreSched<S::kFwdStages> make_fwd_stores() {
     StoreSched<S::kFwdStages> t{};
     for (int st = 0; st < S::kFwdStages; ++st)
         t.st[st] = StoreStage{S::fwd_b0(st), S::fwd_nks(st), S::fwd_not(st), (st == S::NL || (st == 0 && !S::kSaveH0)) ? 0 : 2,
-                              st == S::NL ? 0 : (st == S::NL - 1 ? 1 + S::kDirQ : 1), 0};
+                              st == S::NL ? 0 : (st == S::NL - 1 ? 1 + S::kTrunkXQ + S::kDirQ : 1), 0};
     t.initial = S::kEncQ;
     return t;
 }
@@ -186,7 +187,20 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         if constexpr (l % 2) run(x, y); else run(y, x);
     });
     // head: [h_{NL-1}, dir_enc] -> (r, g, b, sigma) pre-activations, one out tile on the composed matrix (layout.h); lanes of
-    // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).
+    // half 0 hold rows 0-3 in acc[0..3].  sigmoid on rgb (mlp.py:26-27,48), relu on sigma (mlp.py:19-20,42).  A trunk that ends in a
+    // concat (mlp.py:36-38 behind the LAST layer) hands [h, xyz_enc] to sigma and features: QH more k-steps between h and dir_enc,
+    // the encoding recomputed once more and saved a second time right behind h_{NL-1}, where the head's weight-gradient job reads it
+    constexpr int QH = S::kTrunkXQ;
+    bf16x8 ench[QH > 0 ? QH : 1];
+    if constexpr (QH > 0) {
+        encode<S::LX, QX>(px, py, pz, h, ench);
+#ifndef KNERF_ABLATE_ENC_IO
+        if (SAVE) {
+#pragma unroll
+            for (int q = 0; q < QH; ++q) store_block(act, S::kActHeadEnc + q, lane, ench[q]);
+        }
+#endif
+    }
     bf16x8 dirc[QD];
     encode<S::LD, QD>(dx, dy, dz, h, dirc);
 #ifndef KNERF_ABLATE_ENC_IO
@@ -196,8 +210,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     }
 #endif
     auto head = [&](bf16x8 (&in)[K]) {
-        dense_stage<S::fwd_b0(S::NL), K + QD, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * S::NL),
-                                [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : dirc[ks >= K ? ks - K : 0]; },
+        dense_stage<S::fwd_b0(S::NL), K + QH + QD, 1, S::kFwdBlocks>(ring, pf, lane, grp, waits, bias_init(T * S::NL),
+                                [&](int ks) { return ks < K ? in[ks < K ? ks : 0] : (ks < K + QH ? ench[(ks >= K && ks < K + QH) ? ks - K : 0] : dirc[ks >= K + QH ? ks - K - QH : 0]); },
                                 [&](int, f32x16 acc) {
                                     if (valid && h == 0) {
                                         f32x4 r;

@@ -138,28 +138,30 @@ hipError_t launch_step_set(int step, int* step_state, float* lr_t, const AdamHyp
 // Offsets of the six tensors behind the trunk in the flat parameter vector (Keras order: sigma, features, rgb_features, rgb)
 namespace {
 // the six tensors behind the trunk, from the offset of the first float behind the last trunk layer (layout.h Shape::kTrunkParams)
-// the trunk width U and the width D of the direction encoding (27): sigma [U,1], features [U,U], rgb_features [U+D, U/2], rgb [U/2, 3];
-// DS = direction slots of the composed head (16 per k-step: 32)
+// the trunk width U, the width X of xyz_enc in the trunk's OUTPUT (63 when the reference concatenates behind the last layer too,
+// mlp.py:36-38; else 0) and the width D of the direction encoding (27): sigma [U+X,1], features [U+X,U], rgb_features [U+D, U/2],
+// rgb [U/2, 3]; XS, DS = slots of the two encodings in the composed head (16 per k-step: 64 / 32)
 struct HeadOff {
     int ws, bs, wf, bf, wr, br, wc, bc, head, head_bias;
-    __device__ HeadOff(int off_l, int U, int D, int DS) {
-        ws = off_l; bs = ws + U;
-        wf = bs + 1; bf = wf + U * U;
+    __device__ HeadOff(int off_l, int U, int X, int XS, int D, int DS) {
+        ws = off_l; bs = ws + U + X;
+        wf = bs + 1; bf = wf + (U + X) * U;
         wr = bf + U; br = wr + (U + D) * (U / 2);
         wc = br + U / 2; bc = wc + (U / 2) * 3;
-        head = bc + 3; head_bias = head + (U + DS) * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
+        head = bc + 3; head_bias = head + (U + XS + DS) * 4;     // = Shape::kHeadOff (the parameter count), kHeadBiasOff
     }
 };
 static_assert(DefaultShape::kTrunkParams + 257 + 256 * 257 + 283 * 128 + 128 + 128 * 3 + 3 == DefaultShape::kParamCount && DefaultShape::kHeadRows == 288, "head tensor offsets");
 constexpr int kMaxU = 256;
 }  // namespace
 
-// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < U);  H[U+m][0..2] = (W_r2 W_c)[m], H[U+m][3] = 0 (m < D; 0 up to DS);
+// H[i][0..2] = (W_f (W_r1 W_c))[i], H[i][3] = w_s[i]  (i < Tr = U + X: the rows of the features / sigma kernels);
+// H[Tr+m][0..2] = (W_r2 W_c)[m], H[Tr+m][3] = 0 (m < D; 0 up to DS);
 // bias = ((b_f W_r1 + b_r) W_c + b_c, b_s).  fp32, one workgroup of 256 threads; ~0.6 MFLOP at U = 256.
-__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l, int U, int D, int DS) {
+__global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1, int off_l, int U, int X, int XS, int D, int DS) {
     float* w = blockIdx.x == 0 ? w0 : w1;       // one workgroup per net
-    const HeadOff o(off_l, U, D, DS);
-    const int U2 = U / 2, R = U + D;
+    const HeadOff o(off_l, U, X, XS, D, DS);
+    const int U2 = U / 2, R = U + D, Tr = U + X;
     __shared__ float P[kMaxU + kMaxDirDim][3];   // W_r W_c : rows 0..U-1 = W_r1 W_c, U..U+26 = W_r2 W_c
     __shared__ float wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
@@ -173,16 +175,16 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
     }
     __syncthreads();
     float* H = w + o.head;
-    if (tid < U) {   // row tid of A = W_f P1
+    for (int i = tid; i < Tr; i += 256) {   // row i of A = W_f P1
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float* wf = w + o.wf + (size_t)tid * U;
+        const float* wf = w + o.wf + (size_t)i * U;
         for (int j = 0; j < U; ++j) { const float v = wf[j]; a0 += v * P[j][0]; a1 += v * P[j][1]; a2 += v * P[j][2]; }
-        H[tid * 4 + 0] = a0; H[tid * 4 + 1] = a1; H[tid * 4 + 2] = a2; H[tid * 4 + 3] = w[o.ws + tid];
+        H[i * 4 + 0] = a0; H[i * 4 + 1] = a1; H[i * 4 + 2] = a2; H[i * 4 + 3] = w[o.ws + i];
     }
     if (tid < DS) {
-        const int r = U + tid;
+        const int r = Tr + tid, pr = U + tid;             // row of H, row of P
         const bool real = tid < D;
-        H[r * 4 + 0] = real ? P[r][0] : 0.f; H[r * 4 + 1] = real ? P[r][1] : 0.f; H[r * 4 + 2] = real ? P[r][2] : 0.f; H[r * 4 + 3] = 0.f;
+        H[r * 4 + 0] = real ? P[pr][0] : 0.f; H[r * 4 + 1] = real ? P[pr][1] : 0.f; H[r * 4 + 2] = real ? P[pr][2] : 0.f; H[r * 4 + 3] = 0.f;
     }
     if (tid < 3) {
         float c = w[o.bc + tid];
@@ -192,27 +194,27 @@ __global__ __launch_bounds__(256) void head_compose_kernel(float* w0, float* w1,
     }
     if (tid == 3) w[o.head_bias + 3] = w[o.bs];
 }
-hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, int dir_dim, int dir_slots, hipStream_t stream) {
-    if (units > kMaxU || dir_dim > kMaxDirDim || dir_slots > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units, dir_dim, dir_slots);
+hipError_t launch_head_compose(float* w0, float* w1, int trunk_params, int units, int trunk_x, int trunk_x_slots, int dir_dim, int dir_slots, hipStream_t stream) {
+    if (units > kMaxU || dir_dim > kMaxDirDim || dir_slots > 64 || trunk_x > kMaxXyzDim) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_compose_kernel, dim3(w1 ? 2 : 1), dim3(256), 0, stream, w0, w1, trunk_params, units, trunk_x, trunk_x_slots, dir_dim, dir_slots);
     return hipGetLastError();
 }
 
-// aux: M[row][c] = sum_s [h ; dir][s][row] dz_rgb[s][c] (row < U + D), s[c] = sum_s dz_rgb[s][c].  With M1 = rows 0..U-1,
-// M2 = rows U..U+26, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
+// aux: M[row][c] = sum_s [h ; (xyz ;) dir][s][row] dz_rgb[s][c] (row < Tr + D, Tr = U + X), s[c] = sum_s dz_rgb[s][c].  With M1 = rows
+// 0..Tr-1 (the trunk's output), M2 = rows Tr..Tr+26, P1 = W_r1 W_c and Q = W_f^T M1 + b_f (x) s  (= sum_s features[s]^T dz_rgb[s]):
 //   d rgb/kernel          = W_r1^T Q + W_r2^T M2 + b_r (x) s        d rgb/bias          = s
 //   d rgb_features/kernel = [Q ; M2] W_c^T                          d rgb_features/bias = s W_c^T
 //   d features/kernel     = M1 P1^T                                 d features/bias     = s P1^T
 // -- the chain rule through the three linear layers (what the tape yields at nerf.py:376-377 for those six tensors),
 // evaluated on sums over samples instead of per sample.  Added to grad; aux is zeroed.  One workgroup of 1024 threads.
-struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l, U, D, DS; };
+struct HeadExpandArgs { const float* w[2]; float* aux[2]; float* grad[2]; int off_l, U, X, XS, D, DS; };
 __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     const float* w = a.w[blockIdx.x]; float* aux = a.aux[blockIdx.x]; float* grad = a.grad[blockIdx.x];      // one workgroup per net
-    const int U = a.U, U2 = U / 2, R = U + a.D;
-    const HeadOff o(a.off_l, U, a.D, a.DS);
-    __shared__ float M[kMaxU + kMaxDirDim][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
+    const int U = a.U, U2 = U / 2, R = U + a.D, Tr = U + a.X;
+    const HeadOff o(a.off_l, U, a.X, a.XS, a.D, a.DS);
+    __shared__ float M[kMaxU + kMaxXyzDim + kMaxDirDim][3], s_[3], P1[kMaxU][3], Q[kMaxU][3], wc[kMaxU / 2][3];
     const int tid = threadIdx.x;
-    for (int i = tid; i < R * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
+    for (int i = tid; i < (Tr + a.D) * 3; i += 1024) M[i / 3][i % 3] = aux[kAuxM + i];
     if (tid < 3) s_[tid] = aux[kAuxS + tid];
     for (int i = tid; i < U2 * 3; i += 1024) wc[i / 3][i % 3] = w[o.wc + i];
     __syncthreads();
@@ -226,12 +228,12 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
         const int j = tid - 256;
         const float bf = w[o.bf + j];
         float a0 = bf * s_[0], a1 = bf * s_[1], a2 = bf * s_[2];
-        for (int i = 0; i < U; ++i) { const float v = w[o.wf + (size_t)i * U + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
+        for (int i = 0; i < Tr; ++i) { const float v = w[o.wf + (size_t)i * U + j]; a0 += v * M[i][0]; a1 += v * M[i][1]; a2 += v * M[i][2]; }
         Q[j][0] = a0; Q[j][1] = a1; Q[j][2] = a2;
     }
     __syncthreads();
-    // features: kernel [U,U] += M1 P1^T, bias += s P1^T
-    for (int e = tid; e < U * U; e += 1024) {
+    // features: kernel [Tr,U] += M1 P1^T, bias += s P1^T
+    for (int e = tid; e < Tr * U; e += 1024) {
         const int i = e / U, j = e - i * U;
         grad[o.wf + e] += M[i][0] * P1[j][0] + M[i][1] * P1[j][1] + M[i][2] * P1[j][2];
     }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
     // rgb_features: kernel [U+27, U/2] += [Q ; M2] W_c^T, bias += s W_c^T
     for (int e = tid; e < R * U2; e += 1024) {
         const int r = e / U2, k = e - r * U2;
-        const float* v = r < U ? Q[r] : M[r];
+        const float* v = r < U ? Q[r] : M[Tr + (r - U)];
         grad[o.wr + e] += v[0] * wc[k][0] + v[1] * wc[k][1] + v[2] * wc[k][2];
     }
     if (tid < U2) grad[o.br + tid] += s_[0] * wc[tid][0] + s_[1] * wc[tid][1] + s_[2] * wc[tid][2];
@@ -248,15 +250,15 @@ __global__ __launch_bounds__(1024) void head_expand_kernel(HeadExpandArgs a) {
         const int k = tid / 3, c = tid % 3;
         float a = w[o.br + k] * s_[c];
         for (int j = 0; j < U; ++j) a += w[o.wr + (size_t)j * U2 + k] * Q[j][c];
-        for (int m = U; m < R; ++m) a += w[o.wr + (size_t)m * U2 + k] * M[m][c];
+        for (int m = U; m < R; ++m) a += w[o.wr + (size_t)m * U2 + k] * M[Tr + (m - U)][c];
         grad[o.wc + tid] += a;
     }
     if (tid < 3) grad[o.bc + tid] += s_[tid];
 }
-hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int dir_dim, int dir_slots,
-                              hipStream_t stream) {
-    if (units > kMaxU || dir_dim > kMaxDirDim) return hipErrorInvalidValue;
-    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units, dir_dim, dir_slots};
+hipError_t launch_head_expand(const float* w0, float* aux0, float* grad0, const float* w1, float* aux1, float* grad1, int trunk_params, int units, int trunk_x,
+                              int trunk_x_slots, int dir_dim, int dir_slots, hipStream_t stream) {
+    if (units > kMaxU || dir_dim > kMaxDirDim || trunk_x > kMaxXyzDim) return hipErrorInvalidValue;
+    HeadExpandArgs a{{w0, w1}, {aux0, aux1}, {grad0, grad1}, trunk_params, units, trunk_x, trunk_x_slots, dir_dim, dir_slots};
     hipLaunchKernelGGL(head_expand_kernel, dim3(2), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }

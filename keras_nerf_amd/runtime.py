@@ -127,7 +127,7 @@ class KnerfContext:
         if not force_generic and encoded_widths is None and self.get_option("general_shape_path"):
             # a shape outside the library's list: where the fused kernels could cover it, build them (opt-in) or say how; else say what it costs
             eff = (padded_width(dense_units) if pad_width else None) or dense_units       # the width the fused kernels would run it at
-            coverable = (eff in FUSED_WIDTHS and 3 <= n_layers <= 16 and skip_layer >= 1 and (n_layers - 1) % skip_layer != 0
+            coverable = (eff in FUSED_WIDTHS and 3 <= n_layers <= 16 and skip_layer >= 1
                          and 1 <= pos_emb_xyz <= 16 and 1 <= pos_emb_dir <= 8 and not (eff == 256 and pos_emb_xyz == 16 and pos_emb_dir >= 5))
             spec = f"{n_layers},{skip_layer},{eff}" + ("" if (pos_emb_xyz, pos_emb_dir) == (10, 4) else f",{pos_emb_xyz},{pos_emb_dir}")
             if auto_build is None:
@@ -186,7 +186,7 @@ class KnerfContext:
         if generic:                                        # the padded shape is not in the library either: build it when allowed
             if auto_build is None:
                 auto_build = os.environ.get("KNERF_AUTO_BUILD", "") not in ("", "0")
-            coverable = (3 <= c.n_layers <= 16 and c.skip_layer >= 1 and (c.n_layers - 1) % c.skip_layer != 0 and 1 <= c.pos_emb_xyz <= 16
+            coverable = (3 <= c.n_layers <= 16 and c.skip_layer >= 1 and 1 <= c.pos_emb_xyz <= 16
                          and 1 <= c.pos_emb_dir <= 8 and not (wide == 256 and c.pos_emb_xyz == 16 and c.pos_emb_dir >= 5))
             if coverable and auto_build:
                 self._rebuild_for(f"{c.n_layers},{c.skip_layer},{wide}" + ("" if (c.pos_emb_xyz, c.pos_emb_dir) == (10, 4) else f",{c.pos_emb_xyz},{c.pos_emb_dir}"))

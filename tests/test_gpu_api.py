@@ -1,5 +1,6 @@
 """The reference's class surface (NeRF / NeRFUtils / NeRFMLP / RaysGenerator) on the GPU: shapes and semantics the
 reference's own tests assert (tests/model/nerf/*.py, tests/data/test_rays.py there) plus numeric parity with the oracle."""
+import json
 import os
 
 import numpy as np
