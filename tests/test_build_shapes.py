@@ -18,7 +18,7 @@ PROG = r'''
 using namespace knerf;
 int main() {
     std::printf("%d %d\n", kNumBuiltinShapes, kNumFusedShapes);
-    const int ids[4] = {fused_shape_id(6, 3, 128), fused_shape_id(8, 2, 128), fused_shape_id(8, 4, 256), fused_shape_id(7, 3, 256)};
+    const int ids[4] = {fused_shape_id(6, 3, 128), fused_shape_id(8, 2, 128), fused_shape_id(8, 4, 256), fused_shape_id(7, 2, 256)};
     std::printf("%d %d %d %d %d %d\n", ids[0], ids[1], ids[2], ids[3], fused_shape_id(8, 4, 256, 12, 3), fused_shape_id(8, 4, 256, 12, 4));
     for (int k = kNumBuiltinShapes; k < kNumFusedShapes; ++k) {
         const ShapeInfo& s = shape_info(k);
@@ -36,7 +36,9 @@ def test_parse_shapes_accepts_covered_triples_and_names_the_others():
     assert B.parse_shapes(["6,3,128", "8,2,128;6,4,256", "6,3,128"]) == [(6, 3, 128), (8, 2, 128), (6, 4, 256)]
     assert B.parse_shapes([]) == [] and B.parse_shapes([""]) == []
     assert B.parse_shapes(["8,4,256,6,2;8,4,128,10,4"]) == [(8, 4, 256, 6, 2), (8, 4, 128)]           # the reference's encodings need no ShapeL entry
-    for bad in ("8,4,96", "2,1,256", "9,4,256", "4,3,256", "8,4", "a,b,c", "8,0,256", "8,4,256,10", "8,4,256,17,4", "8,4,256,10,9", "8,4,256,0,4"):     # width, depth, concat behind the last layer (x2), arity, type, skip, arity, encodings (x3)
+    # round 6: a concat behind the LAST layer ((n_layers - 1) % skip_layer == 0: 9/4, 4/3, 5/2 ...) is covered -- the head takes [h ; xyz_enc ; dir_enc]
+    assert B.parse_shapes(["9,4,256", "4,3,256;5,2,128", "5,4,64,6,2"]) == [(9, 4, 256), (4, 3, 256), (5, 2, 128), (5, 4, 64, 6, 2)]
+    for bad in ("8,4,96", "2,1,256", "8,4", "a,b,c", "8,0,256", "8,4,256,10", "8,4,256,17,4", "8,4,256,10,9", "8,4,256,0,4"):     # width, depth, arity, type, skip, arity, encodings (x3)
         with pytest.raises(ValueError):
             B.parse_shapes([bad])
     with pytest.raises(ValueError):
@@ -54,23 +56,25 @@ def test_layout_header_with_extra_shapes(tmp_path):
     src = tmp_path / "shapes.cpp"
     src.write_text(PROG)
     exe = tmp_path / "shapes"
-    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(14, 6, 3, 128) X(15, 8, 2, 128) X(16, 8, 4, 256, 12, 3)",
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "keras_nerf_amd", "csrc"), "-DKNERF_EXTRA_SHAPES(X)=X(14, 6, 3, 128) X(15, 8, 2, 128) X(16, 8, 4, 256, 12, 3) X(17, 9, 4, 256) X(18, 5, 4, 64, 6, 2)",
                         str(src), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
-    assert out[0].split() == ["14", "17"]
+    assert out[0].split() == ["14", "19"]
     assert out[1].split() == ["14", "15", "0", "-1", "16", "-1"]
-    for line, (nl, sk, u, lx, ld, qx, qd) in zip(out[2:5], ((6, 3, 128, 10, 4, 4, 2), (8, 2, 128, 10, 4, 4, 2), (8, 4, 256, 12, 3, 6, 2))):
+    for line, (nl, sk, u, lx, ld, qx, qd) in zip(out[2:7], ((6, 3, 128, 10, 4, 4, 2), (8, 2, 128, 10, 4, 4, 2), (8, 4, 256, 12, 3, 6, 2), (9, 4, 256, 10, 4, 4, 2),
+                                                          (5, 4, 64, 6, 2, 4, 2))):
         v = [int(x) for x in line.split()]
         cfg = O.NerfConfig(n_layers=nl, dense_units=u, skip_layer=sk, pos_emb_xyz=lx, pos_emb_dir=ld)
         n_concat = sum(1 for name, i, o in O.layer_shapes(cfg) if name.startswith("layer_") and i == u + 3 + 6 * lx)
         ks, ot = u // 16, u // 32
         assert v[:3] == [nl, sk, u] and v[3] == O.param_count(cfg) and v[7:9] == [lx, ld]
-        assert v[4] == qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + ks + qd          # six encoding k-steps for pos_emb_xyz = 12
+        qt = qx if (nl - 1) % sk == 0 else 0            # a trunk that ends in a concat: the head takes [h ; xyz_enc ; dir_enc] (round 6)
+        assert v[4] == qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + ks + qt + qd          # six encoding k-steps for pos_emb_xyz = 12
         assert v[5] == ot + (nl - 1) * ks * ot and v[6] == nl + 1
         saves_h0 = u != 256 or qx != 4
-        assert v[9] == ks * (nl - 1 + saves_h0) + qx + qd
-    assert [int(x) for x in out[5].split()] == [(4 * 4 + 5 * 8 * 4 + 1 * 4 * 4 + 8 + 2) * 512, (4 * 6 + 1) * 32, (4 + 5 * 8 * 4) * 512]
+        assert v[9] == ks * (nl - 1 + saves_h0) + qx + qt + qd             # ... and its act run holds the enc blocks a second time, behind h_{NL-1}
+    assert [int(x) for x in out[7].split()] == [(4 * 4 + 5 * 8 * 4 + 1 * 4 * 4 + 8 + 2) * 512, (4 * 6 + 1) * 32, (4 + 5 * 8 * 4) * 512]
 
 
 def test_spill_report_of_the_build_guard():

@@ -16,6 +16,12 @@ Expected counts (csrc/layout.h, chain.h, mlp_fwd.hip, bwd_body.h, wgrad_body.h):
   wgrad     per instantiation, all nine jobs inlined: LDS-DMA = sum over jobs of (staging slots NS) x (copies per wave and tile G)
             = 6x3 (layer_0) + 4 x 4x4 (layers 2,3,4,6) + 4x5 (layer_5) + 6x4 (head) + 6x3 (layer_1) + 8x3 (layer_7) = 168;
             MFMA = 2 x accumulators per wave: 6 + 4 x 18 + 22 + 4 + (18 + 2 x 4 recompute sites) + (18 + 2 x 1) = 150.
+
+Round 6, Shape<9, 4, 256> -- a trunk that ends in a concat, the head takes [h ; xyz_enc ; dir_enc] (build-time entry, compiled here as
+slice 14): forward MFMA = 32 + 7 x 128 + 160 + (16 + 4 + 2) = 1110, LDS-DMA 2 x (5 + 69 + 69) = 286, stores 4 enc + 1 mask (layer_0) +
+8 x 17 + (4 enc again + 2 dir) + 1 raw = 148; dgrad MFMA 8 + 8 x 128 = 1032, LDS-DMA 2 x (5 + 64 + 64) = 266, stores 1 + 8 x 16 = 129;
+wgrad LDS-DMA 18 + 18 + 5 x 16 + 20 + 24 (layer_8, dz recomputed) + 6 x 4 (head: 22 + 2 blocks per tile) = 184, MFMA 6 + 26 + 5 x 18 + 22 + 20 +
+4 (head: twelve rows over eight waves = two accumulators) = 168.
 """
 import hashlib
 import os
@@ -41,8 +47,12 @@ def _flags():
 SLICE0 = ["-DKNERF_SHAPE_SLICE=0", "-DKNERF_OWN_0=,"]      # what build.py passes for slice 0 (csrc/layout.h KNERF_PICK)
 
 
-def _asm(name):
+CBL = ["-DKNERF_SHAPE_SLICE=14", "-DKNERF_OWN_14=,", "-DKNERF_EXTRA_SHAPES(X)=X(14, 9, 4, 256)"]      # build.py --add-shape=9,4,256 as slice 14
+
+
+def _asm(name, slice_flags=None):
     """gfx950 assembly of csrc/<name>.hip, cached under the temp dir by the hash of every source and header it may include"""
+    SLICE0 = slice_flags or globals()["SLICE0"]
     h = hashlib.sha1()
     for f in sorted(os.listdir(CSRC)) + ["../../include/knerf.h"]:
         p = os.path.join(CSRC, f)
@@ -83,6 +93,15 @@ def isa():
     return {"mlp_fwd": _kernels(fwd), "mlp_bwd": _kernels(bwd), "wgrad": _kernels(wg)}
 
 
+@pytest.fixture(scope="module")
+def isa_cbl():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    with ThreadPoolExecutor(3) as ex:
+        fwd, bwd, wg = ex.map(lambda n: _asm(n, CBL), ["mlp_fwd", "mlp_bwd", "wgrad"])
+    return {"mlp_fwd": _kernels(fwd), "mlp_bwd": _kernels(bwd), "wgrad": _kernels(wg)}
+
+
 EXPECT = {
     # kernel-name fragment: (file, instantiation tags, {mnemonic: count})
     # (kernels are templates on the trunk shape: Shape<8, 4, 256> = "5ShapeILi8ELi4ELi256EEE" in the mangled names)
@@ -93,13 +112,33 @@ EXPECT = {
 }
 
 
+EXPECT_CBL = {
+    "mlp_fwd_kernelINS_5ShapeILi9ELi4ELi256EEELb1E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 1110, "global_load_lds_dwordx4": 286, "global_store_dwordx4": 148}),
+    "mlp_fwd_kernelINS_5ShapeILi9ELi4ELi256EEELb0E": ("mlp_fwd", 2, {"v_mfma_f32_32x32x16_bf16": 1110, "global_load_lds_dwordx4": 286, "global_store_dwordx4": 1}),
+    "mlp_bwd_kernelINS_5ShapeILi9ELi4ELi256EEE": ("mlp_bwd", 2, {"v_mfma_f32_32x32x16_bf16": 1032, "global_load_lds_dwordx4": 266, "global_store_dwordx4": 129}),
+    "wgrad_kernelINS_5ShapeILi9ELi4ELi256EEE": ("wgrad", 4, {"v_mfma_f32_32x32x16_bf16": 168, "global_load_lds_dwordx4": 184}),
+}
+
+
+@pytest.mark.parametrize("frag", sorted(EXPECT_CBL))
+def test_counted_waits_of_a_trunk_that_ends_in_a_concat(isa_cbl, frag):
+    """the head stage with four more k-steps and the second copy of the enc blocks (round 6): same guard, the counts of Shape<9, 4, 256>"""
+    # ten jobs in one kernel: two scalar registers go to lanes of a vector register (v_writelane, no memory: private segment 0, no
+    # scratch instruction -- asserted below), which does not enter the vmcnt the waits count; build.py tolerates exactly this
+    _check_counts(isa_cbl, frag, EXPECT_CBL, sgpr_to_lanes_ok=True)
+
+
 @pytest.mark.parametrize("frag", sorted(EXPECT))
 def test_counted_waits_still_match_the_emitted_instructions(isa, frag):
+    _check_counts(isa, frag, EXPECT)
+
+
+def _check_counts(isa, frag, EXPECT, sgpr_to_lanes_ok=False):
     fname, n_inst, counts = EXPECT[frag]
     ks = {k: v for k, v in isa[fname].items() if frag in k}
     assert len(ks) == n_inst, (frag, sorted(isa[fname]))
     for name, (body, meta) in ks.items():
-        assert meta.get("vgpr_spill_count") == 0 and meta.get("sgpr_spill_count") == 0, (name, meta)
+        assert meta.get("vgpr_spill_count") == 0 and (meta.get("sgpr_spill_count") == 0 or sgpr_to_lanes_ok), (name, meta)
         assert meta.get("private_segment_fixed_size") == 0, (name, meta)
         assert not re.search(r"^\s+scratch_", body, re.M), f"{name}: scratch instruction (spill or stack object)"
         assert not re.search(r"^\s+buffer_(load|store)", body, re.M), f"{name}: buffer access (stack?)"

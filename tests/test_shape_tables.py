@@ -10,7 +10,7 @@ from keras_nerf_amd import _lib
 from keras_nerf_amd import debug as D
 from oracle import nerf_oracle as O
 
-AUX_S = (256 + 51) * 3    # csrc/layout.h kAuxS: the head accumulator keeps s behind the largest M (width 256, pos_emb_dir 8)
+AUX_S = (256 + 99 + 51) * 3    # csrc/layout.h kAuxS: the head accumulator keeps s behind the largest M (width 256, pos_emb_xyz 16 in a trunk that ends in a concat, pos_emb_dir 8)
 
 
 def _n_shapes():
@@ -53,7 +53,12 @@ def _check_tables(k):
     fwd, bias, bwd = D.debug_table(0, k), D.debug_table(1, k), D.debug_table(2, k)
     n_concat = sum(1 for name, i, o in shapes if name.startswith("layer_") and i == U + xd)
     ks, ot = U // 16, U // 32
-    assert fwd.size == (qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + (ks + qd)) * 512       # layer_0, U-wide layers, concat extras, head
+    # a trunk that ends in a concat ((nl - 1) % sk == 0, mlp.py:36-38): sigma / features take [h ; xyz_enc] -- xt more real rows and
+    # qt more k-steps in the composed head (round 6)
+    cbl = nl > 1 and (nl - 1) % sk == 0
+    xt, qt = (xd, qx) if cbl else (0, 0)
+    assert dict((name, i) for name, i, o in shapes)["sigma"] == U + xt and dict((name, i) for name, i, o in shapes)["features"] == U + xt
+    assert fwd.size == (qx * ot + (nl - 1) * ks * ot + n_concat * qx * ot + (ks + qt + qd)) * 512       # layer_0, U-wide layers, concat extras, head
     assert bias.size == (ot * nl + 1) * 32
     assert bwd.size == (ot + (nl - 1) * ks * ot) * 512
     # forward stream + bias: every trunk parameter once, nothing of the four tensors behind the trunk, the composed head behind n
@@ -62,7 +67,7 @@ def _check_tables(k):
     np.add.at(used, bias[(bias >= 0) & (bias < n)], 1)
     assert (used[:n_trunk] == 1).all() and not used[n_trunk:].any()
     head = np.concatenate([fwd[fwd >= n], bias[bias >= n]]) - n
-    assert sorted(head) == sorted([r * 4 + c for r in range(U + dd) for c in range(4)] + [(U + 16 * qd) * 4 + c for c in range(4)])
+    assert sorted(head) == sorted([r * 4 + c for r in range(U + xt + dd) for c in range(4)] + [(U + 16 * qt + 16 * qd) * 4 + c for c in range(4)])
     # dgrad stream: layers 1 .. NL-1 (their first U input rows: no gradient flows into the encodings) and the head's h rows, each once
     vals, counts = np.unique(bwd[bwd >= 0], return_counts=True)
     assert counts.max() == 1
@@ -74,11 +79,11 @@ def _check_tables(k):
             exp.append(np.arange(off, off + U * o))                 # rows 0 .. U-1 of kernel[in, out]
         off += i * o + o
     assert np.array_equal(np.sort(bwd[(bwd >= 0) & (bwd < n)]), np.concatenate(exp))
-    # weight-gradient destinations: trunk + sigma gradients once each; head accumulator M [(U+27) x 3] and s [3] once each
+    # weight-gradient destinations: trunk + sigma gradients once each; head accumulator M [(U [+63] +27) x 3] and s [3] once each
     dst, job_off = D.debug_table(3, k), D.debug_table(4, k)
     assert job_off.size == nl + 2 and job_off[0] == 0 and job_off[-1] == dst.size and (np.diff(job_off) > 0).all()
     g = dst[(dst >= 0) & (dst < n)]
-    assert np.array_equal(np.sort(g), np.arange(n_trunk + U + 1))
+    assert np.array_equal(np.sort(g), np.arange(n_trunk + U + xt + 1))
     aux = np.sort(dst[dst >= n] - n)
-    assert np.array_equal(aux, np.concatenate([np.arange((U + dd) * 3), AUX_S + np.arange(3)]))
+    assert np.array_equal(aux, np.concatenate([np.arange((U + xt + dd) * 3), AUX_S + np.arange(3)]))
     assert dst.min() >= -1
