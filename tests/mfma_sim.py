@@ -58,7 +58,7 @@ def bias_acc(bias_tab, flat, tile):
 
 FWD_STAGES = [(0, 4, 8), (32, 16, 8), (160, 16, 8), (288, 16, 8), (416, 16, 8), (544, 20, 8), (704, 16, 8), (832, 16, 8),
               (960, 18, 1)]
-N_PARAMS, HEAD_ROWS, AUX_M, AUX_S, AUX_COUNT = 595844, 288, 0, (256 + 51) * 3, 928
+N_PARAMS, HEAD_ROWS, AUX_M, AUX_S, AUX_COUNT = 595844, 288, 0, (256 + 99 + 51) * 3, 1224      # csrc/layout.h kAuxS / kAuxCount (round 6: room for the xyz rows of a trunk that ends in a concat)
 
 
 def extended_weights(params, cfg):
