@@ -2,6 +2,7 @@
 # One gpurun call's worth of the round's evidence (run from the repo root on the GPU box):
 #   bash tools/measure_round.sh <outdir> [stage ...]      stages: tests bench prof pmc cfgs fit opts bound shapes half stores
 #                                                          round 5: sparsity lds masklayout gensk fuzzgen rehearsal refs
+#                                                          round 6: retry (the launcher's second attempt, rehearsed over gloo) cbl (trunks that end in a concat)
 # Every stage writes small files under <outdir>; profiles/ holds the copies that are committed (profiles/README.md).
 set -u
 OUT=${1:-gpurun_out/measure}; shift || true
@@ -66,6 +67,15 @@ for l in open('$OUT/shapes_kbench.jsonl'):
     rehearsal) # an N = 3 line over gloo on one GPU (control flow and the line's diagnostics fields, not a measurement)
            KNERF_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 3 --config cfg4 --steps 10 --warmup 2 --no-cpu-baseline 2> $OUT/rehearsal.err | grep "^{" > $OUT/bench_cfg4_3ranks_gloo.json || fault rehearsal
            python -c "import json; l=json.load(open('$OUT/bench_cfg4_3ranks_gloo.json')); print('rehearsal', l['n_gpus'], l['replica_drift'], l['allreduce_us_standalone']['median'])" ;;
+    retry) # the launcher's one-shot second attempt (keras_nerf_amd/parallel.py _launch_attempts): both ranks of the first set fail in the first all-reduce
+           KNERF_DIST_BACKEND=gloo KNERF_BENCH_INJECT_FAILURE="*:first_all_reduce@1" timeout -k 10 300 python bench.py --gpus 2 --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/retry.err | grep "^{" > $OUT/bench_cfg4_2ranks_launch_retry.json || fault retry
+           python -c "import json; l=json.load(open('$OUT/bench_cfg4_2ranks_launch_retry.json')); print('retry', l['n_gpus'], l['launch_attempts'], l['ipc_mode_legacy_env'], l['replica_drift'])" ;;
+    cbl)   # round 6: a concat behind the last trunk layer on the fused kernels against the general-shape kernels; needs libknerf_hip_xshape.so
+           : > $OUT/cbl_kbench.jsonl
+           for sh in 9,256,4,10,4 5,128,2,10,4 5,64,4,6,2; do
+             timeout -k 10 120 python tools/kbench.py --lib keras_nerf_amd/libknerf_hip_xshape.so --shape $sh --tag fused_$sh >> $OUT/cbl_kbench.jsonl 2>> $OUT/cbl_kbench.err || fault "cbl $sh"
+             KNERF_FORCE_GENERIC=1 timeout -k 10 120 python tools/kbench.py --lib keras_nerf_amd/libknerf_hip_xshape.so --shape $sh --tag generic_$sh >> $OUT/cbl_kbench.jsonl 2>> $OUT/cbl_kbench.err || fault "cbl generic $sh"
+           done; grep -c kernels $OUT/cbl_kbench.jsonl ;;
     refs)  # the command lines the reference's source comments quote a time for, as bench configs
            for c in ref1 ref2 ref3; do timeout -k 10 200 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err || fault $c; python -c "import json; l=json.load(open('$OUT/bench_$c.json')); print('$c', l['ms_per_step'], l['value'], l['vs_baseline'], l['baseline'])"; done ;;
   esac
