@@ -253,7 +253,9 @@ def bench_render(args, world, rank, wh, chunks, desc, backend="nccl"):
         prof = nerf._ctx.profile_read(); nerf._ctx.profile_enable(False)
         ms, cnt = prof["mlp_fwd_fine"]
         avg = ms / max(cnt, 1)
-        flop = FWD_FLOP_EXEC * chunks * (nerf.n_coarse + nerf.n_fine)         # executed FLOPs (collapsed head), not the 12-layer count
+        # executed FLOPs (collapsed head, not the 12-layer count) of ONE launch: the launches of the profiled frame cover wh * wh rays
+        # between them (merge_render_rays: normally one launch per frame; round 5 left `chunks` here and under-reported 16x)
+        flop = FWD_FLOP_EXEC * (wh * wh / max(cnt, 1)) * (nerf.n_coarse + nerf.n_fine)
         roofline = {"bound": "mfma", "kernel": "mlp_fwd_fine", "achieved": flop / (avg * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": flop / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg,
                     "launches": cnt, "kernel_ms_per_frame": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
