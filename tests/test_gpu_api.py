@@ -315,6 +315,43 @@ def test_train_script_as_the_one_rank_of_a_real_rccl_group(tmp_path):
     assert sorted(os.listdir(tmp_path / "model" / "scene")) == ["coarse.h5", "fine.h5", "model_config.json"]
 
 
+def test_two_rank_data_parallel_step_at_cfg4_size(tmp_path):
+    """cfg4's per-GPU workload -- chair-shaped 128 x 128, ONE image per rank, coarse 64 + fine 128, four chunks of 4,096 rays -- as a
+    two-rank data-parallel job (train.py:75-157; gloo, both ranks on this GPU: RCCL refuses two ranks on one device and the pool has
+    no second one): mirrored start, identical weights after the step on both ranks, equal to ONE process that accumulates both
+    shards' gradients (SUM) and applies one Adam step.  The oracle follows the same semantics at a size it can run in the test below."""
+    import socket
+    import subprocess
+    import sys
+    from keras_nerf_amd.runtime import KnerfContext
+    from tests.dp_gpu_worker import problem
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", KNERF_DP_SHAPE="cfg4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert a["o"].shape == (1, 128, 128, 3) and a["t"].shape == (1, 128, 128, 64)
+    np.testing.assert_array_equal(a["w_start"], b["w_start"])
+    np.testing.assert_array_equal(a["w_end"], b["w_end"])
+    assert np.abs(a["w_end"] - a["w_start"]).max() > 1e-4 and float(a["coarse_loss"]) != float(b["coarse_loss"])
+    poses, focal, img, u = problem("cfg4")
+    ctx = KnerfContext(white_background=True)
+    n = ctx.param_count
+    ctx.set_weights(0, a["w_start"][:n]); ctx.set_weights(1, a["w_start"][n:])
+    for rank, z in enumerate((a, b)):
+        ctx.train_batch(z["o"].reshape(-1, 3), z["d"].reshape(-1, 3), z["t"].reshape(-1, 64), img[rank].reshape(-1, 3),
+                        u[rank].reshape(-1, 128), seed=0, ray_chunks=4096)
+    ctx.apply_adam()
+    w = np.concatenate([ctx.get_weights(0), ctx.get_weights(1)])
+    moved = np.abs(a["w_end"] - a["w_start"]) > 1e-5
+    assert moved.mean() > 0.5 and np.mean(np.sign(w - a["w_start"])[moved] == np.sign(a["w_end"] - a["w_start"])[moved]) > 0.999
+    np.testing.assert_allclose(w, a["w_end"], atol=2e-5)                      # fp32 atomics: summation order only
+    ctx.close()
+
+
 def test_two_rank_data_parallel_step_on_the_gpu(tmp_path):
     """train.py:75-157 semantics with two processes on this GPU (gloo; tests/dp_gpu_worker.py): both ranks start from rank
     0's weights, SUM their accumulated gradients and end with identical weights that equal a single-process step on the

@@ -7,7 +7,7 @@ cfg3  400x400, batch 1: ray_chunks 16384 violates the divisibility assert (nerf.
       equals ten train_chunk calls; the gradients of a sampled sub-chunk against the oracle.
 cfg1  the coarse-only configuration (n_fine = 0) TRAINED, not only rendered: gradients of both nets against the oracle -- at 16 x 16 in
       one chunk, and AS WRITTEN (64 x 64, four chunks of 1,024 through knerf_train_batch) through an exact zero-gradient property.
-cfg4 needs eight GPUs and is the driver's to run; its per-GPU work is cfg2's with one image.
+cfg4 needs eight GPUs and is the driver's to run; its per-GPU workload runs as a TWO-rank data-parallel job (gloo, one GPU) in tests/test_gpu_api.py::test_two_rank_data_parallel_step_at_cfg4_size.
 """
 import numpy as np
 import pytest
