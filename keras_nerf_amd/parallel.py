@@ -154,6 +154,11 @@ def rank_fail(what: str, exc: BaseException, tag: str = "knerf", code: int = RAN
     tail = rccl_log_tail()
     text = (f"[{tag} rank {r}/{w}] FAILED in {what} on {dev} (backend {backend}, {IPC_VAR}={os.environ.get(IPC_VAR, '<unset>')}): "
             f"{type(exc).__name__}: {exc}\n{tb}" + (f"[{tag} rank {r}/{w}] RCCL log tail ({os.environ.get('NCCL_DEBUG', '')}):\n{tail}\n" if tail else ""))
+    if code == RANK_FAILED_SETUP and not os.environ.get("KNERF_LAUNCH_DIR"):
+        # under an external launcher (torch.distributed.run) nothing is retried: say what the self-spawning launcher would have tried
+        alt = "unset" if os.environ.get(IPC_VAR) == "0" else "0"
+        text += (f"[{tag} rank {r}/{w}] hint: the process group never came up under {IPC_VAR}={os.environ.get(IPC_VAR, '<unset>')}; if the log above names "
+                 f"hipIpc* / IPC handles, rerun with {IPC_VAR} {alt} (`python bench.py --gpus N` without a launcher tries that by itself, once)\n")
     print(text, file=sys.stderr, flush=True)
     job = os.environ.get("KNERF_LAUNCH_DIR")
     if job:
