@@ -43,6 +43,15 @@ def hang_unless_zero(out_dir):
     dist.all_reduce(torch.ones(1))           # never completes: rank 1 is gone
 
 
+def record_pid_and_wait(out_dir):
+    """a healthy rank that is simply busy: the launcher is what gets the signal"""
+    import time
+    import torch.distributed as dist
+    with open(os.path.join(out_dir, f"pid{dist.get_rank()}"), "w") as f:
+        f.write(str(os.getpid()))
+    time.sleep(600)
+
+
 def ignore_sigterm_and_hang(out_dir):
     """a rank that cannot be talked out of its collective: SIGTERM ignored (as inside a driver call) -- the launcher must escalate"""
     import signal

@@ -262,6 +262,33 @@ def test_launch_escalates_to_sigkill_for_ranks_that_ignore_sigterm(tmp_path, mon
         assert not os.path.exists(f"/proc/{pid}"), f"rank {k} (pid {pid}) survived its launcher"
 
 
+def test_a_plain_sigterm_to_the_launcher_takes_the_ranks_along(tmp_path):
+    """a launcher killed by a plain SIGTERM (a scheduler's time limit, `timeout` without -k) had no handler -- no exception,
+    no clean-up, orphan ranks holding their GPUs.  launch() turns the signal into SystemExit, and _wait_ranks stops the ranks by handle
+    on its way out."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from keras_nerf_amd import parallel; from tests.launch_worker import record_pid_and_wait; "
+            "parallel.launch(record_pid_and_wait, 2, args=(%r,), backend='gloo')") % (root, str(tmp_path))
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_launch_env())
+    t_end = time.time() + 120
+    while time.time() < t_end and not all(os.path.exists(tmp_path / f"pid{k}") and open(tmp_path / f"pid{k}").read() for k in range(2)):
+        time.sleep(0.2)
+    pids = [int(open(tmp_path / f"pid{k}").read()) for k in range(2)]
+    assert all(os.path.exists(f"/proc/{pid}") for pid in pids)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-2000:])
+    t_end = time.time() + 20
+    while time.time() < t_end and any(os.path.exists(f"/proc/{pid}") for pid in pids):
+        time.sleep(0.2)
+    for pid in pids:
+        assert not os.path.exists(f"/proc/{pid}"), f"rank pid {pid} survived its launcher"
+
+
 def test_init_rank_refusals_name_the_problem(monkeypatch):
     """the checks in front of init_process_group: a rank without a GPU under the RCCL backend, and a world of one (nothing to join)"""
     import torch
