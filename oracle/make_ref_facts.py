@@ -11,6 +11,9 @@ holds NUMBERS AND IDENTIFIERS ONLY, per function of the path (SURVEY.md section 
                (axis=-1, exclusive=True, side="right", activation="relu", units=3 ...) and the number of positional arguments
     compares   comparison operators with a constant on one side ("< 1e-05", "> 0", "== 0")
     binops     binary operators with a constant operand ("1.0 - ", "2.0 ** ", "% ", "// 2")
+    dict_keys  the string keys of the dict literals it builds ("image", "depth", "weights"; the log names)
+and, under "_classes", for NeRF / NeRFUtils / NeRFMLP: the method names with their parameter names and the attributes assigned on
+`self` anywhere in the class (what a script that drives the reference -- oracle/make_tf_golden.py -- may touch).
 
 What this buys: the oracle (oracle/nerf_oracle.py) is a RESTATEMENT; its constants, keyword choices and comparison directions were
 typed by hand from the reference.  tests/test_ref_facts.py holds, per fact, the executable check on the oracle that corresponds to
@@ -83,8 +86,25 @@ def facts_of(fn: ast.FunctionDef) -> dict:
                 binops.append(f"{'' if l is _const else repr(l)} {op} {'' if r is _const else repr(r)}".strip())
     calls.sort(key=lambda c: c.pop("line_order"))
     del doc
-    return {"literals": sorted(lits), "calls": calls, "compares": sorted(compares), "binops": sorted(binops),
+    keys = sorted({k.value for node in ast.walk(fn) if isinstance(node, ast.Dict) for k in node.keys
+                   if isinstance(k, ast.Constant) and isinstance(k.value, str)})
+    return {"literals": sorted(lits), "calls": calls, "compares": sorted(compares), "binops": sorted(binops), "dict_keys": keys,
             "arg_defaults": {a.arg: _const(d) for a, d in zip(fn.args.args[len(fn.args.args) - len(fn.args.defaults):], fn.args.defaults) if _const(d) is not _const}}
+
+
+def class_surface(tree: ast.Module, cls: str) -> dict:
+    """identifiers only: {method: [parameter names]}, the attributes assigned on self, and the string keys of every dict literal"""
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            methods = {f.name: [a.arg for a in f.args.args[1:]] + ([f"**{f.args.kwarg.arg}"] if f.args.kwarg else [])
+                       for f in node.body if isinstance(f, ast.FunctionDef)}
+            attrs = sorted({t.attr for n in ast.walk(node) if isinstance(n, (ast.Assign, ast.AugAssign, ast.AnnAssign))
+                            for t in (n.targets if isinstance(n, ast.Assign) else [n.target])
+                            if isinstance(t, ast.Attribute) and isinstance(t.value, ast.Name) and t.value.id == "self"})
+            keys = sorted({k.value for n in ast.walk(node) if isinstance(n, ast.Dict) for k in n.keys
+                           if isinstance(k, ast.Constant) and isinstance(k.value, str)})
+            return {"methods": methods, "self_attrs": attrs, "dict_keys": keys}
+    raise SystemExit(f"class {cls} not found")
 
 
 def main():
@@ -103,6 +123,9 @@ def main():
         if missing:
             raise SystemExit(f"{rel}: functions not found: {missing}")
         out[rel] = {n: found[n] for n in names}
+    out["_classes"] = {}
+    for rel, cls in (("keras_nerf/model/nerf/nerf.py", "NeRF"), ("keras_nerf/model/nerf/utils.py", "NeRFUtils"), ("keras_nerf/model/nerf/mlp.py", "NeRFMLP")):
+        out["_classes"][cls] = class_surface(ast.parse(open(os.path.join(args.reference, rel)).read()), cls)
     with open(args.out, "w") as f:
         json.dump({"_made_by": "oracle/make_ref_facts.py (ast of the reference's text: numbers and identifiers only)", **out}, f, indent=1, sort_keys=True)
     print(args.out, {k: len(v) for k, v in out.items()})

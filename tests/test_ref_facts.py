@@ -206,3 +206,45 @@ def test_rays_and_pose_constants():
     assert DU["pose_spherical"]["binops"] == ["/ 180.0", "/ 180.0"]
     assert O.get_focal_from_fov(0.6911112070083618, 100) == pytest.approx(138.88887889922103, rel=1e-6)       # the reference's own known answer
     np.testing.assert_allclose(O.pose_spherical(0.0, 0.0, 4.0), [[-1, 0, 0, 0], [0, 0, 1, 4], [0, 1, 0, 0], [0, 0, 0, 1]], atol=1e-7)
+
+
+def test_the_script_that_will_drive_the_reference_under_tensorflow_touches_only_what_exists():
+    """oracle/make_tf_golden.py has never run (no TensorFlow in this pipeline).  Short of running it, everything it touches on the
+    reference's objects is checked against the reference's text: the methods it calls and the attributes it reads on a `NeRF`, the
+    keywords it passes, the positional counts, the result-dict keys and log names it reads (shake the bugs out
+    before the day TensorFlow exists -- statically, since a stand-in library is not allowed)."""
+    src = ast.parse(open(os.path.join(ROOT, "oracle", "make_tf_golden.py")).read())
+    nerf_c, utils_c = FACTS["_classes"]["NeRF"], FACTS["_classes"]["NeRFUtils"]
+    used = {n.attr for n in ast.walk(src) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == "nerf"}
+    assert used == {"compile", "coarse", "fine", "_predict_and_render_chunk", "coarse_optimizer", "fine_optimizer", "nerf_utils", "train_step"}
+    assert used <= set(nerf_c["methods"]) | set(nerf_c["self_attrs"])
+    calls = {}
+    for n in ast.walk(src):
+        if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute):
+            calls.setdefault(n.func.attr, []).append(n)
+    # compile: every keyword is a parameter of the reference's compile (run_eagerly travels in **kwargs to Keras, nerf.py:78-105)
+    (comp,) = calls["compile"]
+    kws = {k.arg for k in comp.keywords}
+    params = [p for p in nerf_c["methods"]["compile"] if not p.startswith("**")]
+    assert not comp.args and kws - {"run_eagerly"} <= set(params) and "**kwargs" in nerf_c["methods"]["compile"]
+    assert {"optimizer", "loss", "batch_size", "image_height", "image_width", "ray_chunks"} <= kws           # the ones without a default
+    # _predict_and_render_chunk(ray_chunks[, coarse_weights_chunk]); train_step(data); the sampler's three positional arguments
+    assert nerf_c["methods"]["_predict_and_render_chunk"] == ["ray_chunks", "coarse_weights_chunk"]
+    assert sorted(len(c.args) for c in calls["_predict_and_render_chunk"]) == [1, 2] and all(not c.keywords for c in calls["_predict_and_render_chunk"])
+    assert nerf_c["methods"]["train_step"] == ["inputs"] and all(len(c.args) == 1 for c in calls["train_step"])
+    assert utils_c["methods"]["fine_hierarchical_sampling_chunk"] == ["mid_points", "weights", "n_samples"]
+    assert all(len(c.args) == 3 for c in calls["fine_hierarchical_sampling_chunk"])
+    # NeRF() with no arguments relies on the reference's defaults being the kernels' shape (checked above against NerfConfig)
+    assert all(not (c.args or c.keywords) for n_ in ast.walk(src) if isinstance(n_, ast.Call) and isinstance(n_.func, ast.Name) and n_.func.id == "NeRF" for c in [n_])
+    # result keys read from the chunk forward, and the log names read from train_step's return value
+    subs = {(n.value.id, n.slice.value) for n in ast.walk(src) if isinstance(n, ast.Subscript) and isinstance(n.value, ast.Name)
+            and isinstance(n.slice, ast.Constant) and isinstance(n.slice.value, str)}
+    chunk_keys = set(N["_predict_and_render_chunk"]["dict_keys"])
+    assert chunk_keys == {"image", "depth", "weights"}
+    assert {k for v, k in subs if v in ("coarse", "fine")} <= chunk_keys
+    assert {k for v, k in subs if v == "logs"} == {"coarse_loss", "fine_loss"} <= set(nerf_c["dict_keys"])
+    # ... and this implementation's NeRF offers the same surface the script uses (the import-swapped script would run here too)
+    from keras_nerf_amd.model.nerf.nerf import NeRF
+    for name in ("compile", "_predict_and_render_chunk", "train_step"):
+        assert callable(getattr(NeRF, name))
+    assert list(inspect.signature(NeRF._predict_and_render_chunk).parameters)[1:3] == ["ray_chunks", "coarse_weights_chunk"]
