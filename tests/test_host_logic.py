@@ -432,3 +432,33 @@ def test_zero_gradient_messages_are_the_references(caplog):
         assert len([g for g in got if "Gradient" in g[1]]) == len(want)
         dead = [g[1] for g in got if "Every sample tile" in g[1]]
         assert len(dead) == sum(1 for live, total in stats if total > 0 and live == 0), (stats, dead)
+
+
+def test_auto_build_does_not_compile_from_inside_a_multi_rank_job(monkeypatch, caplog, tmp_path):
+    """KNERF_AUTO_BUILD is two minutes of hipcc behind a file lock -- eight ranks taking turns inside the process
+    group's time-outs.  With torch.distributed initialised and world > 1 a shape that is not built yet is NOT compiled (warning with the
+    command to build it beforehand; the context stays on the general-shape kernels); a library built earlier is adopted as it is."""
+    import logging
+    import torch.distributed as dist
+    from keras_nerf_amd import build as B
+    from keras_nerf_amd.runtime import KnerfContext
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 8)
+    monkeypatch.setattr(dist, "get_rank", lambda *a, **k: 3)
+    monkeypatch.setattr(B, "build", lambda **kw: (_ for _ in ()).throw(AssertionError("hipcc must not be started from a rank")))
+    ctx = object.__new__(KnerfContext)              # no GPU needed: the decision is taken before the library is touched
+    adopted = []
+    ctx._adopt_library = lambda path, spec: adopted.append((os.path.basename(path), spec))
+    with caplog.at_level(logging.WARNING):
+        assert ctx._rebuild_for("7,5,128") is None
+    msg = " ".join(r.getMessage() for r in caplog.records)
+    assert not adopted and "not compiling shape 7,5,128 from rank 3 of a 8-rank job" in msg and "--variant=auto_7_5_128 --add-shape=7,5,128" in msg
+    # built beforehand (by one process): loaded without a compiler run
+    here = os.path.dirname(os.path.abspath(B.__file__))
+    built = os.path.join(here, "libknerf_hip_auto_7_5_128.so")
+    open(built, "wb").close()
+    try:
+        ctx._rebuild_for("7,5,128")
+        assert adopted == [("libknerf_hip_auto_7_5_128.so", "7,5,128")]
+    finally:
+        os.remove(built)
