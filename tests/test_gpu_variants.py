@@ -68,6 +68,22 @@ def test_build_time_extra_shapes_run_on_the_fused_kernels():
         ctx.close()
 
 
+def test_a_trunk_that_ends_in_a_concat_in_the_weight_gradient_kernels_many_tile_regime():
+    """Shape<9, 4, 256> (round 6: the head's weight-gradient job has eleven input tiles, the forward saves the enc blocks twice) at
+    1,024 rays = 2,048 + 6,144 sample tiles, i.e. many tiles per workgroup in every job, list mode and contiguous mode, against the
+    oracle in kernel arithmetic per gradient tensor (tools/oracle_check_chunk.py; the 4,096-ray run of the bench's launch sizes is
+    profiles/r06_oracle_check_4096_rays_shape_9_4_256.json: 1.1e-3 coarse / 1.8e-3 fine)"""
+    from keras_nerf_amd import build as B
+    lib = B.build(verbose=False, variant="xshape", add_shapes=XSHAPES)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "oracle_check_chunk.py"), "--rays", "1024", "--sub", "256", "--shape", "9,4,256", "--lib", lib],
+                       capture_output=True, text=True, timeout=400)
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r.returncode == 0 and out["ok"] and out["general_shape_path"] == 0.0, out
+    for mode in ("skip_dead_tiles_1", "skip_dead_tiles_0"):
+        assert out[mode]["coarse_worst"] < 1.5e-2 and out[mode]["fine_worst"] < 1.5e-2 and max(out[mode]["loss_err"]) < 1e-5, out      # measured 2.4e-3 / 8.3e-3
+    assert out["list_vs_contiguous_rel"] < 1e-5
+
+
 AUTO_SHAPE = (6, 2, 128)      # coverable by the fused kernels, not in the built-in list; prebuilt as libknerf_hip_auto_6_2_128.so (build() of __graft_entry__)
 
 

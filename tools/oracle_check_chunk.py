@@ -13,6 +13,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if "--lib" in sys.argv:          # before keras_nerf_amd._lib reads it
+    os.environ["KNERF_LIB"] = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -30,6 +32,9 @@ def main():
     ap.add_argument("--threads", type=int, default=min(6, os.cpu_count() or 1), help="host threads evaluating oracle sub-batches side by side (~0.7 GB each at --sub 512)")
     ap.add_argument("--batch", default=None, help="IMAGES,WH,RAY_CHUNKS: a whole train_batch instead of one chunk, e.g. 2,128,4096 = BASELINE cfg2's step "
                                                   "(8 chunks, grouped coarse weight-gradient launches); the oracle then needs ~12 min of host time")
+    ap.add_argument("--shape", default=None, help="NL,SK,U[,LX,LD]: another trunk shape (with --lib: a library built with --add-shape for it; "
+                                                  "round 6: 9,4,256 = a trunk that ends in a concat, eleven input tiles in the head's weight-gradient job)")
+    ap.add_argument("--lib", default=None, help="library to load instead of the product (KNERF_LIB)")
     args = ap.parse_args()
     n_images, ray_chunks = 1, None
     if args.batch:
@@ -38,13 +43,19 @@ def main():
     else:
         wh = int(round(args.rays ** 0.5))
     assert n_images * wh * wh == args.rays and args.rays % args.sub == 0
-    P = make_problem(n_images=n_images, wh=wh, weight_scale=1.5, bias_std=0.05)
+    shape_kw = {}
+    if args.shape:
+        v = [int(x) for x in args.shape.split(",")]
+        shape_kw = dict(n_layers=v[0], skip_layer=v[1], dense_units=v[2], **(dict(pos_emb_xyz=v[3], pos_emb_dir=v[4]) if len(v) == 5 else {}))
+    P = make_problem(n_images=n_images, wh=wh, weight_scale=1.5, bias_std=0.05, cfg=O.NerfConfig(**shape_kw) if shape_kw else None)
     cfg, N = P["cfg"], P["N"]
+    S = cfg.n_coarse + cfg.n_fine
     o, d, t, u, img = P["o"].reshape(N, 3), P["d"].reshape(N, 3), P["t"].reshape(N, -1), P["u"].reshape(N, -1), P["img"].reshape(N, 3)
-    out = {"rays": N, "tiles": {"coarse": N * 64 // 32, "fine": N * 192 // 32}}
+    out = {"rays": N, "tiles": {"coarse": N * cfg.n_coarse // 32, "fine": N * S // 32}, "shape": args.shape or "8,4,256"}
     got = {}
     for skip in (1, 0):
-        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip))
+        ctx = KnerfContext(white_background=True, options=dict(skip_dead_tiles=skip), **shape_kw)
+        out["general_shape_path"] = ctx.get_option("general_shape_path")
         ctx.set_weights(0, O.flatten_params(P["cp"])); ctx.set_weights(1, O.flatten_params(P["fp"]))
         loss = torch.zeros(2, device="cuda")
         ci = torch.empty((N, 3), device="cuda"); fi = torch.empty_like(ci)
@@ -55,15 +66,15 @@ def main():
             # the merged t-values of every chunk: the sampler is bit-exact and the weights have not moved, so a render of the same
             # rays with the same u reproduces them (the last chunk's are still in the training workspace: compared below)
             tf_all = ctx.render_batch(o, d, t, u, ray_chunks=ray_chunks, out=dict(c_image=torch.empty_like(ci), f_image=torch.empty_like(fi),
-                                      t_fine=torch.empty((N, 192), device="cuda")))["t_fine"].cpu().numpy()
-            last = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:ray_chunks * 192].reshape(ray_chunks, 192)
+                                      t_fine=torch.empty((N, S), device="cuda")))["t_fine"].cpu().numpy()
+            last = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:ray_chunks * S].reshape(ray_chunks, S)
             out["t_fine_of_render_equals_training"] = bool(np.array_equal(tf_all[-ray_chunks:], last))
             out["wgrad_group"] = ctx.get_option("wgrad_group")
         else:
             ctx.train_chunk(o, d, t, img, u, inv_chunks=1.0, loss=loss, c_image=ci, f_image=fi)
             torch.cuda.synchronize()
             g_now = ctx.grads_view().cpu().numpy().copy()
-            tf_all = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * 192].reshape(N, 192).copy()
+            tf_all = debug_buffer(ctx, 5).view(torch.float32).cpu().numpy()[:N * S].reshape(N, S).copy()
         got[skip] = dict(g=g_now, loss=loss.cpu().numpy().copy(), ci=ci.cpu().numpy(), fi=fi.cpu().numpy(), t_fine=tf_all)
         n = ctx.param_count
         ctx.close()
