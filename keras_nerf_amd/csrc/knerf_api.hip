@@ -723,7 +723,7 @@ int knerf_render_chunk(knerf_ctx* ctx, void* stream, const float* o, const float
 int knerf_render_batch(knerf_ctx* ctx, void* stream, const float* o, const float* d, const float* t, const float* u, uint64_t seed,
                        int n_rays, int ray_chunks, float* c_image, float* c_depth, float* c_weights, float* f_image, float* f_depth,
                        float* f_weights, float* t_fine) {
-    if (!ctx) return KNERF_ERR_INVALID;
+    if (int r = check_rays(ctx, "render_batch")) return r;            // (before any workspace is sized: a stand-alone-MLP context has none)
     if (ray_chunks <= 0 || n_rays <= 0 || n_rays % ray_chunks != 0)
         return fail(ctx, KNERF_ERR_INVALID, "render_batch: ray_chunks must be a divisor of the number of rays");   // nerf.py:100
     const size_t Nc = (size_t)ctx->cfg.n_coarse, Nf = (size_t)ctx->cfg.n_fine, Na = Nc + Nf;
