@@ -7,8 +7,9 @@ partial import; reading the source as text is study) -- and nothing of its text 
 holds NUMBERS AND IDENTIFIERS ONLY, per function of the path:
 
     literals   every numeric literal of the function (defaults of its arguments included), as a sorted list of reprs
-    calls      the dotted names of the calls it makes, in source order, each with the keyword arguments whose values are constants
-               (axis=-1, exclusive=True, side="right", activation="relu", units=3 ...) and the number of positional arguments
+    calls      {dotted name of a TensorFlow op or of a method of the object itself: [per occurrence: the keyword arguments whose
+               values are constants (axis=-1, exclusive=True, side="right", activation="relu", units=3 ...) and the number of
+               positional arguments]} -- grouped by name; the interleaving of different calls (the function's structure) is NOT kept
     compares   comparison operators with a constant on one side ("< 1e-05", "> 0", "== 0")
     binops     binary operators with a constant operand ("1.0 - ", "2.0 ** ", "% ", "// 2")
     dict_keys  the string keys of the dict literals it builds ("image", "depth", "weights"; the log names)
@@ -73,7 +74,8 @@ def facts_of(fn: ast.FunctionDef) -> dict:
             if name is None:
                 continue
             kw = {k.arg: _const(k.value) for k in node.keywords if k.arg and _const(k.value) is not _const}
-            calls.append({"name": name, "n_positional": len(node.args), "const_kwargs": kw, "line_order": (node.lineno, node.col_offset)})
+            if name.startswith(("tf.", "self.")):          # TensorFlow ops and the object's own methods: what the oracle restates
+                calls.append({"name": name, "n_positional": len(node.args), "const_kwargs": kw, "line_order": (node.lineno, node.col_offset)})
         elif isinstance(node, ast.Compare) and len(node.ops) == 1:
             l, r = _const(node.left), _const(node.comparators[0])
             op = OPS.get(type(node.ops[0]))
@@ -85,6 +87,10 @@ def facts_of(fn: ast.FunctionDef) -> dict:
             if op and ((l is not _const) != (r is not _const)) and not (isinstance(l, str) or isinstance(r, str)):
                 binops.append(f"{'' if l is _const else repr(l)} {op} {'' if r is _const else repr(r)}".strip())
     calls.sort(key=lambda c: c.pop("line_order"))
+    grouped = {}
+    for c in calls:
+        grouped.setdefault(c.pop("name"), []).append(c)
+    calls = dict(sorted(grouped.items()))
     del doc
     keys = sorted({k.value for node in ast.walk(fn) if isinstance(node, ast.Dict) for k in node.keys
                    if isinstance(k, ast.Constant) and isinstance(k.value, str)})
